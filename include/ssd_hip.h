@@ -1,0 +1,172 @@
+/*
+ * ssd_hip.h -- C ABI of libssd_hip.so: the MI355X (gfx950) RetinaNet inference path
+ * that replaces the TensorFlow session behind TropComplique/single-shot-detector's
+ * `Detector` (reference paths below are relative to the reference repository).
+ *
+ * The reference has no FFI/plugin layer of its own (it is Python on TF 1.12); the
+ * boundary it does have is the frozen graph's tensor contract
+ *     images:0 uint8 [1,H,W,3]  ->  boxes:0 [1,2000,4] f32, labels:0 [1,2000] i32,
+ *                                   scores:0 [1,2000] f32, num_boxes:0 [1] i32
+ * (create_pb.py:40,72; inference/detector.py:21-27,51-52; model.py:70-73).  ssd_forward()
+ * is that `sess.run`, generalised over the batch dimension.  The other entry points are
+ * the pieces the graph is assembled from, exported so that each can be parity-tested
+ * against the CPU oracle exactly where the reference defines it.
+ *
+ * Conventions
+ *   - plain C types only; every pointer named *_dev is device (HIP) memory owned by the
+ *     caller, every pointer named *_host is host memory; the library owns its weights
+ *     and workspace arena.
+ *   - layout NHWC fp32, conv kernels HWIO, exactly the reference's TF variable layout.
+ *   - return value: 0 (SSD_OK) or a negative code; ssd_last_error() gives the text for
+ *     the calling thread.  Nothing throws across the ABI.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  ssd_forward and
+ *     ssd_postprocess only enqueue work: no hidden synchronisation.  The stage entry
+ *     points that take host weights (ssd_conv2d, ssd_depthwise3x3, ssd_first_conv)
+ *     are test conveniences and synchronise before returning.
+ *   - one handle per device; calls on one handle must be serialised by the caller.
+ */
+#ifndef SSD_HIP_H
+#define SSD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSD_OK 0
+#define SSD_ERR_INVALID (-1)   /* bad argument / unsupported shape           */
+#define SSD_ERR_HIP (-2)       /* a HIP runtime call failed                  */
+#define SSD_ERR_STATE (-3)     /* call out of order (e.g. forward before finalize) */
+#define SSD_ERR_WEIGHT (-4)    /* missing / mis-shaped / unknown variable    */
+
+#define SSD_ACT_NONE 0
+#define SSD_ACT_RELU 1         /* tf.nn.relu  */
+#define SSD_ACT_RELU6 2        /* tf.nn.relu6 */
+
+#define SSD_BACKBONE_MOBILENET 0   /* detector/backbones/mobilenet_v1.py  */
+#define SSD_BACKBONE_SHUFFLENET 1  /* detector/backbones/shufflenet_v2.py */
+
+typedef struct ssd_handle ssd_handle;
+
+/* The inference keys of config_mobilenet.json / config_shufflenet.json (:7-12,21),
+ * consumed by model.py:22-30,46,57-61. */
+typedef struct ssd_config {
+    int32_t backbone;            /* SSD_BACKBONE_*                       */
+    float depth_multiplier;      /* "depth_multiplier"                   */
+    int32_t num_classes;         /* "num_classes"                        */
+    float score_threshold;       /* "score_threshold"                    */
+    float iou_threshold;         /* "iou_threshold"                      */
+    int32_t max_boxes_per_class; /* "max_boxes_per_class"                */
+    int32_t min_dimension;       /* "min_dimension" (create_pb.py:24)    */
+    int32_t device;              /* HIP device index (visible_device_list, inference/detector.py:6) */
+} ssd_config;
+
+/* ---- lifetime: replaces Detector.__init__ (inference/detector.py:6-34) ------------- */
+int ssd_create(const ssd_config *cfg, ssd_handle **out);
+void ssd_destroy(ssd_handle *h);
+const char *ssd_last_error(void);
+
+/* One call per TF variable of the frozen graph, by the reference's variable name
+ * (e.g. "MobilenetV1/Conv2d_3_pointwise/weights", "fpn/p6/kernel",
+ * "class_net/batch_norm_2_for_level_5/moving_variance"; SURVEY.md 8a "Weights").
+ * Replaces tf.import_graph_def of the Const nodes (inference/detector.py:13-19). */
+int ssd_load_weight(ssd_handle *h, const char *name, const float *host, const int64_t *shape,
+                    int32_t ndim);
+/* Checks that every variable of the configured architecture was loaded, computes the
+ * batch-norm scale factors, re-lays the kernels out for the HIP kernels and uploads. */
+int ssd_finalize(ssd_handle *h);
+
+/* ---- the hot path: replaces sess.run(output_ops, {images: ...})
+ *      (inference/detector.py:51-52) = create_pb.py:42-47 + model.py:13-77 ------------ */
+/* images_dev uint8 [B,H,W,3]; H, W multiples of 128 with min(H,W) == min_dimension
+ * (resize_keeping_aspect_ratio, pipeline.py:138-194, is then the identity).
+ * Outputs, T = num_classes*max_boxes_per_class (2000): boxes_dev f32 [B,T,4]
+ * (ymin,xmin,ymax,xmax, normalised, already divided by box_scaler, model.py:67-68),
+ * labels_dev i32 [B,T], scores_dev f32 [B,T], num_boxes_dev i32 [B]; zero padded. */
+int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W,
+                float *boxes_dev, int32_t *labels_dev, float *scores_dev,
+                int32_t *num_boxes_dev, void *stream);
+
+/* Copy a retained intermediate of the last ssd_forward to the host in the reference's
+ * logical NHWC channel order (synchronises).  Names: "c3","c4","c5" (backbone outputs),
+ * "p3".."p7" (feature_extractor.py:71-76), "encoded_boxes" [B,N,4] and
+ * "class_predictions" [B,N,C] (box_predictor.py:102-104).  dims_out receives 4 ints. */
+int ssd_get_tensor(ssd_handle *h, const char *name, float *host_dst, int64_t capacity_floats,
+                   int32_t *dims_out);
+
+/* Same, device to device: dst_dev receives the tensor in logical channel order; enqueued
+ * on `stream` without synchronising (SSD.raw_predictions, ssd.py:37-40). */
+int ssd_get_tensor_dev(ssd_handle *h, const char *name, float *dst_dev, int64_t capacity_floats,
+                       int32_t *dims_out, void *stream);
+
+/* Per-kernel-class timing with HIP events on the forward's stream (bench.py roofline).
+ * classes: 0 conv3x3 MFMA, 1 pointwise MFMA, 2 depthwise, 3 first conv, 4 postprocess,
+ * 5 other.  ssd_profile_read synchronises the recorded events. */
+int ssd_profile_enable(ssd_handle *h, int32_t on);
+int ssd_profile_read(ssd_handle *h, int32_t cls, double *total_ms, int64_t *launches,
+                     double *flops, double *bytes);
+int ssd_profile_reset(ssd_handle *h);
+
+/* ---- pieces of the graph, each where the reference defines it ---------------------- */
+
+/* AnchorGenerator.__call__ (anchor_generator.py:40-120) with model.py:37-42 constants. */
+int32_t ssd_num_anchors(int32_t H, int32_t W);
+int ssd_anchors(int32_t H, int32_t W, float *anchors_host /* [N,4] */);
+
+/* Dense k x k convolution (k = 1 or 3) on the MFMA implicit-GEMM kernel:
+ * slim.conv2d / tf.layers.conv2d / conv2d_same (mobilenet_v1.py:49,66;
+ * layer_utils.py:15-43; box_predictor.py:117-130,144-154; feature_extractor.py:57-69).
+ * out = act( bn( conv(in) ) + bias + upsample2(up) ), each term optional (NULL).
+ * pad_beg: 1 for 'same' stride 1 and for conv2d_same stride 2 (explicit pad),
+ * 0 for TF 'SAME' stride 2 on even sizes and for k = 1.
+ * bn_*: moving_mean, gamma*rsqrt(var+eps), beta (batch_norm_relu, layer_utils.py:5-12).
+ * up_dev: coarser map [B,OH/2,OW/2,Cout] added after nearest x2 upsampling
+ * (feature_extractor.py:67,79-100).  Cin must be a multiple of 8. */
+int ssd_conv2d(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t Cin,
+               const float *w_host /* [k,k,Cin,Cout] */, int32_t k, int32_t Cout,
+               int32_t stride, int32_t pad_beg, int32_t OH, int32_t OW,
+               const float *bn_mean_host, const float *bn_sf_host, const float *bn_beta_host,
+               const float *bias_host, const float *up_dev, int32_t act, float *out_dev,
+               void *stream);
+
+/* depthwise_conv (depthwise_conv.py:5-26): 3x3, weights [3,3,C,1], optional BN + act. */
+int ssd_depthwise3x3(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t C,
+                     const float *w_host, int32_t stride, int32_t pad_beg, int32_t OH,
+                     int32_t OW, const float *bn_mean_host, const float *bn_sf_host,
+                     const float *bn_beta_host, int32_t act, float *out_dev, void *stream);
+
+/* uint8 image -> /255 -> 2x-1 -> 3x3 stride-2 'SAME' conv -> BN -> act, fused
+ * (create_pb.py:42-47; mobilenet_v1.py:34,49; shufflenet_v2.py:37,50). */
+int ssd_first_conv(const uint8_t *images_dev, int32_t B, int32_t H, int32_t W,
+                   const float *w_host /* [3,3,3,Cout] */, int32_t Cout,
+                   const float *bn_mean_host, const float *bn_sf_host,
+                   const float *bn_beta_host, int32_t act, float *out_dev, void *stream);
+
+/* slim.max_pool2d 3x3 stride 2 'SAME' (shufflenet_v2.py:51-54). */
+int ssd_maxpool3x3s2(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t C,
+                     float *out_dev, void *stream);
+
+/* concat_shuffle_split (shufflenet_v2.py:94-115) on [rows, D] tensors. */
+int ssd_concat_shuffle_split(const float *x_dev, const float *y_dev, int64_t rows, int32_t D,
+                             float *xo_dev, float *yo_dev, void *stream);
+
+/* SSD.get_predictions (ssd.py:42-69) = sigmoid + batch_multiclass_non_max_suppression
+ * (nms.py:48-102, decode box_utils.py:114-142, tf.image.non_max_suppression of TF r1.12)
+ * + boxes /= box_scaler (model.py:67-68).
+ * logits_dev [B,N,C], codes_dev [B,N,4], anchors_dev [N,4]; outputs as ssd_forward.
+ * workspace_dev: ssd_postprocess_workspace_bytes(B,N,C,max_boxes_per_class) bytes. */
+size_t ssd_postprocess_workspace_bytes(int32_t B, int32_t N, int32_t C,
+                                       int32_t max_boxes_per_class);
+int ssd_postprocess(const float *logits_dev, const float *codes_dev, const float *anchors_dev,
+                    int32_t B, int32_t N, int32_t C, float score_threshold, float iou_threshold,
+                    int32_t max_boxes_per_class, const float *box_scaler_host /* [4] or NULL */,
+                    float *boxes_dev, int32_t *labels_dev, float *scores_dev,
+                    int32_t *num_boxes_dev, void *workspace_dev, size_t workspace_bytes,
+                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSD_HIP_H */

@@ -1,0 +1,516 @@
+/*
+ * ssd_oracle.c -- CPU restatement (ORACLE) of the RetinaNet inference path of
+ * TropComplique/single-shot-detector.  TEST INFRASTRUCTURE ONLY.
+ *
+ *   * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ *     load this library.  The product (single-shot-detector_amd/) never does.
+ *   * PARITY UNPINNED: the reference executes inside TensorFlow 1.12, which is
+ *     neither vendored in /root/reference nor installable here, and the
+ *     reference ships no tests / golden vectors.  This
+ *     file restates the published semantics of the TF ops at the reference's
+ *     call sites; it is pinned only by the known-answer values derivable from
+ *     the reference source (tests/test_oracle_known_answers.py) and by an
+ *     independent library cross-check (torch CPU convolutions).
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference).  Layout: NHWC, fp32, weights HWIO exactly as the TF
+ * variables are stored.
+ *
+ * Arithmetic contract (what "the same result" means for the HIP path):
+ *   * convolutions accumulate each output element as ONE k-ordered chain of
+ *     fused multiply-adds starting from +0, k running over (ky, kx, ci) with
+ *     ci fastest -- the storage order of an HWIO kernel.  Padded taps add
+ *     nothing.  (TF's own order inside Eigen/cuDNN is unspecified; any order
+ *     is within a few ulp.)
+ *   * everything else (batch norm, bias, decode, IoU) uses separately rounded
+ *     IEEE fp32 operations in the order the reference's graph applies them;
+ *     compile with -ffp-contract=off.
+ *   * exp/sigmoid are the correctly rounded fp32 values of the real function
+ *     (evaluated in double, rounded once).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef __AVX2__
+#include <immintrin.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* create_pb.py:42-47 + mobilenet_v1.py:34 / shufflenet_v2.py:37             */
+/* uint8 -> float, *(1/255), then 2*x - 1 (two separately rounded ops).      */
+ORC_API void orc_preprocess(const uint8_t *img, int64_t n, float *out)
+{
+    const float inv255 = (float)(1.0 / 255.0);
+    for (int64_t i = 0; i < n; ++i) {
+        float x = (float)img[i] * inv255;
+        out[i] = 2.0f * x - 1.0f;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Dense k x k convolution, NHWC, HWIO weights, no bias.                     */
+/* Covers: slim.conv2d 'SAME' (mobilenet_v1.py:49,66; shufflenet_v2.py:50,   */
+/* 69,120-136), tf.layers.conv2d 'same' (layer_utils.py:17-24;               */
+/* box_predictor.py:124-130,148-154) and the explicit-pad 'valid' stride-2   */
+/* form (layer_utils.py:26-43).  The caller passes pad_beg:                  */
+/*   SAME  stride 1, k=3         -> pad_beg 1                                */
+/*   SAME  stride 2, k=3, even n -> pad_beg 0 (TF pads bottom/right only)    */
+/*   conv2d_same stride 2        -> pad_beg 1 (explicit symmetric pad)       */
+/*   k = 1                       -> pad_beg 0                                */
+static void conv_scalar_pos(const float *in, int H, int W, int Cin, const float *w, int k,
+                            int Cout, int stride, int pad_beg, int b, int oy, int ox, float *o)
+{
+    for (int n = 0; n < Cout; ++n) o[n] = 0.0f;
+    for (int ky = 0; ky < k; ++ky) {
+        int iy = oy * stride + ky - pad_beg;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            int ix = ox * stride + kx - pad_beg;
+            if (ix < 0 || ix >= W) continue;
+            const float *a = in + (((int64_t)b * H + iy) * W + ix) * Cin;
+            const float *wp = w + ((int64_t)(ky * k + kx) * Cin) * Cout;
+            for (int ci = 0; ci < Cin; ++ci) {
+                float av = a[ci];
+                const float *wr = wp + (int64_t)ci * Cout;
+                for (int n = 0; n < Cout; ++n) o[n] = fmaf(av, wr[n], o[n]);
+            }
+        }
+    }
+}
+
+/* plain triple loop, used to cross-check the blocked version */
+ORC_API void orc_conv2d_scalar(const float *in, int B, int H, int W, int Cin, const float *w,
+                               int k, int Cout, int stride, int pad_beg, int OH, int OW,
+                               float *out)
+{
+    for (int b = 0; b < B; ++b)
+        for (int oy = 0; oy < OH; ++oy)
+            for (int ox = 0; ox < OW; ++ox)
+                conv_scalar_pos(in, H, W, Cin, w, k, Cout, stride, pad_beg, b, oy, ox,
+                                out + (((int64_t)b * OH + oy) * OW + ox) * Cout);
+}
+
+#ifdef __AVX2__
+#define PB 6 /* output positions per register block */
+/* 6 positions x 16 output channels per block: 12 ymm accumulators.          */
+static void conv_block_avx(const float *const *aptr, int Cin, const float *wp, int Cout,
+                           __m256 acc[PB][2])
+{
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float *wr = wp + (int64_t)ci * Cout;
+        __m256 w0 = _mm256_loadu_ps(wr), w1 = _mm256_loadu_ps(wr + 8);
+        for (int p = 0; p < PB; ++p) {
+            __m256 a = _mm256_broadcast_ss(aptr[p] + ci);
+            acc[p][0] = _mm256_fmadd_ps(a, w0, acc[p][0]);
+            acc[p][1] = _mm256_fmadd_ps(a, w1, acc[p][1]);
+        }
+    }
+}
+#endif
+
+ORC_API void orc_conv2d(const float *in, int B, int H, int W, int Cin, const float *w, int k,
+                        int Cout, int stride, int pad_beg, int OH, int OW, float *out)
+{
+#ifdef __AVX2__
+    if (Cout % 16 == 0) {
+        float *zeros = (float *)calloc((size_t)Cin, sizeof(float));
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+        for (int b = 0; b < B; ++b)
+            for (int oy = 0; oy < OH; ++oy) {
+                for (int ox0 = 0; ox0 < OW; ox0 += PB) {
+                    int np = OW - ox0 < PB ? OW - ox0 : PB;
+                    for (int n0 = 0; n0 < Cout; n0 += 16) {
+                        __m256 acc[PB][2];
+                        for (int p = 0; p < PB; ++p)
+                            acc[p][0] = acc[p][1] = _mm256_setzero_ps();
+                        for (int ky = 0; ky < k; ++ky) {
+                            int iy = oy * stride + ky - pad_beg;
+                            if (iy < 0 || iy >= H) continue;
+                            for (int kx = 0; kx < k; ++kx) {
+                                const float *aptr[PB];
+                                for (int p = 0; p < PB; ++p) {
+                                    int ix = (ox0 + p) * stride + kx - pad_beg;
+                                    /* a zero operand leaves the chain unchanged */
+                                    aptr[p] = (p < np && ix >= 0 && ix < W)
+                                                  ? in + (((int64_t)b * H + iy) * W + ix) * Cin
+                                                  : zeros;
+                                }
+                                conv_block_avx(aptr, Cin,
+                                               w + ((int64_t)(ky * k + kx) * Cin) * Cout + n0,
+                                               Cout, acc);
+                            }
+                        }
+                        for (int p = 0; p < np; ++p) {
+                            float *o = out + (((int64_t)b * OH + oy) * OW + ox0 + p) * Cout + n0;
+                            _mm256_storeu_ps(o, acc[p][0]);
+                            _mm256_storeu_ps(o + 8, acc[p][1]);
+                        }
+                    }
+                }
+            }
+        free(zeros);
+        return;
+    }
+#endif
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b)
+        for (int oy = 0; oy < OH; ++oy)
+            for (int ox = 0; ox < OW; ++ox)
+                conv_scalar_pos(in, H, W, Cin, w, k, Cout, stride, pad_beg, b, oy, ox,
+                                out + (((int64_t)b * OH + oy) * OW + ox) * Cout);
+}
+
+/* ------------------------------------------------------------------------- */
+/* depthwise_conv.py:5-26 -> tf.nn.depthwise_conv2d, weights [3,3,C,1],      */
+/* padding 'SAME'.  One 9-term fma chain per output, (ky,kx) order.          */
+ORC_API void orc_depthwise3x3(const float *in, int B, int H, int W, int C, const float *w,
+                              int stride, int pad_beg, int OH, int OW, float *out)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int oy = 0; oy < OH; ++oy)
+            for (int ox = 0; ox < OW; ++ox) {
+                float *o = out + (((int64_t)b * OH + oy) * OW + ox) * C;
+                for (int c = 0; c < C; ++c) o[c] = 0.0f;
+                for (int ky = 0; ky < 3; ++ky) {
+                    int iy = oy * stride + ky - pad_beg;
+                    if (iy < 0 || iy >= H) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        int ix = ox * stride + kx - pad_beg;
+                        if (ix < 0 || ix >= W) continue;
+                        const float *a = in + (((int64_t)b * H + iy) * W + ix) * C;
+                        const float *wr = w + (int64_t)(ky * 3 + kx) * C;
+                        for (int c = 0; c < C; ++c) o[c] = fmaf(a[c], wr[c], o[c]);
+                    }
+                }
+            }
+}
+
+/* ------------------------------------------------------------------------- */
+/* tf.layers.batch_normalization(fused=True, training=False), epsilon 1e-3:  */
+/* layer_utils.py:5-12, mobilenet_v1.py:22-31, shufflenet_v2.py:25-34.       */
+/* TF's inference kernel: sf = gamma * rsqrt(var + eps); y = (x-mean)*sf+beta*/
+/* act: 0 none, 1 relu (tf.nn.relu), 2 relu6 (tf.nn.relu6).                  */
+ORC_API void orc_bn_scale(const float *gamma, const float *var, int C, float eps, float *sf)
+{
+    for (int c = 0; c < C; ++c) sf[c] = gamma[c] * (1.0f / sqrtf(var[c] + eps));
+}
+
+static inline float act_apply(float v, int act)
+{
+    if (act >= 1) v = v > 0.0f ? v : 0.0f;
+    if (act == 2) v = v < 6.0f ? v : 6.0f;
+    return v;
+}
+
+ORC_API void orc_bn_act(float *x, int64_t rows, int C, const float *mean, const float *sf,
+                        const float *beta, int act)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; ++r) {
+        float *p = x + r * C;
+        for (int c = 0; c < C; ++c) {
+            float v = (p[c] - mean[c]) * sf[c];
+            v = v + beta[c];
+            p[c] = act_apply(v, act);
+        }
+    }
+}
+
+/* tf.layers.conv2d(use_bias=True): box_predictor.py:124-130,148-154 */
+ORC_API void orc_bias_add(float *x, int64_t rows, int C, const float *bias)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; ++r)
+        for (int c = 0; c < C; ++c) x[r * C + c] = x[r * C + c] + bias[c];
+}
+
+/* tf.nn.relu on a whole tensor (feature_extractor.py:60, input of p7) */
+ORC_API void orc_relu(const float *x, int64_t n, float *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = x[i] > 0.0f ? x[i] : 0.0f;
+}
+
+/* ------------------------------------------------------------------------- */
+/* slim.max_pool2d 3x3 stride 2 'SAME' (shufflenet_v2.py:51-54): even input, */
+/* pad only bottom/right; padded cells do not take part in the max.          */
+ORC_API void orc_maxpool3x3s2(const float *in, int B, int H, int W, int C, float *out)
+{
+    int OH = (H + 1) / 2, OW = (W + 1) / 2;
+    int pad_h = ((OH - 1) * 2 + 3 - H) > 0 ? ((OH - 1) * 2 + 3 - H) / 2 : 0;
+    int pad_w = ((OW - 1) * 2 + 3 - W) > 0 ? ((OW - 1) * 2 + 3 - W) / 2 : 0;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int oy = 0; oy < OH; ++oy)
+            for (int ox = 0; ox < OW; ++ox) {
+                float *o = out + (((int64_t)b * OH + oy) * OW + ox) * C;
+                for (int c = 0; c < C; ++c) o[c] = -INFINITY;
+                for (int ky = 0; ky < 3; ++ky) {
+                    int iy = oy * 2 + ky - pad_h;
+                    if (iy < 0 || iy >= H) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        int ix = ox * 2 + kx - pad_w;
+                        if (ix < 0 || ix >= W) continue;
+                        const float *a = in + (((int64_t)b * H + iy) * W + ix) * C;
+                        for (int c = 0; c < C; ++c) o[c] = a[c] > o[c] ? a[c] : o[c];
+                    }
+                }
+            }
+}
+
+/* ------------------------------------------------------------------------- */
+/* shufflenet_v2.py:94-115 concat_shuffle_split: z[2d+g] = (g ? y : x)[d],   */
+/* new x = z[:D], new y = z[D:].                                             */
+ORC_API void orc_concat_shuffle_split(const float *x, const float *y, int64_t rows, int D,
+                                      float *xo, float *yo)
+{
+    for (int64_t r = 0; r < rows; ++r)
+        for (int j = 0; j < 2 * D; ++j) {
+            float v = (j & 1) ? y[r * D + (j >> 1)] : x[r * D + (j >> 1)];
+            if (j < D) xo[r * D + j] = v;
+            else yo[r * D + (j - D)] = v;
+        }
+}
+
+/* ------------------------------------------------------------------------- */
+/* feature_extractor.py:67,79-100: out = nearest_upsample_x2(coarse)+lateral */
+ORC_API void orc_upsample2_add(const float *coarse, const float *lateral, int B, int h, int w,
+                               int C, float *out)
+{
+    int H = 2 * h, W = 2 * w;
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const float *cp = coarse + (((int64_t)b * h + y / 2) * w + x / 2) * C;
+                int64_t o = (((int64_t)b * H + y) * W + x) * C;
+                for (int c = 0; c < C; ++c) out[o + c] = cp[c] + lateral[o + c];
+            }
+}
+
+/* ------------------------------------------------------------------------- */
+/* anchor_generator.py:40-120 (+ tile_anchors :123-170) with the constants   */
+/* of model.py:37-42.  All arithmetic in fp32 like the TF graph; `scales`    */
+/* are Python doubles (m * scale) converted to fp32 constants (:75).         */
+ORC_API int orc_num_anchors(int H, int W)
+{
+    static const int strides[5] = {8, 16, 32, 64, 128};
+    int n = 0;
+    for (int l = 0; l < 5; ++l) {
+        int h = (int)ceilf((float)H / (float)strides[l]);
+        int w = (int)ceilf((float)W / (float)strides[l]);
+        n += h * w * 6;
+    }
+    return n;
+}
+
+ORC_API void orc_anchors(int H, int W, float *out /* [N,4] */)
+{
+    static const int strides[5] = {8, 16, 32, 64, 128};
+    static const double base_scales[5] = {32, 64, 128, 256, 512};
+    static const double mult[2] = {1.0, 1.4142};
+    static const double ars[3] = {1.0, 2.0, 0.5};
+    float image_height = (float)H, image_width = (float)W;
+    int64_t idx = 0;
+    for (int l = 0; l < 5; ++l) {
+        float stride = (float)strides[l];
+        int h = (int)ceilf(image_height / stride);
+        int w = (int)ceilf(image_width / stride);
+        float scales[6], ratios[6], heights[6], widths[6];
+        int a = 0;
+        for (int m = 0; m < 2; ++m)       /* itertools.product(multipliers, ratios) */
+            for (int r = 0; r < 3; ++r, ++a) {
+                scales[a] = (float)(mult[m] * base_scales[l]);
+                ratios[a] = (float)ars[r];
+            }
+        for (a = 0; a < 6; ++a) {
+            float rs = sqrtf(ratios[a]);
+            heights[a] = scales[a] / rs;
+            widths[a] = scales[a] * rs;
+        }
+        float t = ((float)h - 1.0f) * stride;
+        float offset_y = 0.5f * (image_height - t);
+        t = ((float)w - 1.0f) * stride;
+        float offset_x = 0.5f * (image_width - t);
+        for (int i = 0; i < h; ++i) {
+            float cy = (float)i * stride;
+            cy = cy + offset_y;
+            for (int j = 0; j < w; ++j) {
+                float cx = (float)j * stride;
+                cx = cx + offset_x;
+                for (a = 0; a < 6; ++a) {
+                    float hh = 0.5f * heights[a], hw = 0.5f * widths[a];
+                    out[idx * 4 + 0] = (cy - hh) / image_height;
+                    out[idx * 4 + 1] = (cx - hw) / image_width;
+                    out[idx * 4 + 2] = (cy + hh) / image_height;
+                    out[idx * 4 + 3] = (cx + hw) / image_width;
+                    ++idx;
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* ssd.py:60 tf.sigmoid; correctly rounded fp32 value of 1/(1+e^-x).         */
+ORC_API float orc_sigmoid(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
+
+static inline float exp_f32(float x) { return (float)exp((double)x); }
+
+/* box_utils.py:114-142 decode (+ :64-77 to_center_coordinates),             */
+/* SCALE_FACTORS constants.py:15; then nms.py:77 clip_by_value(0, 1).        */
+ORC_API void orc_decode_clip(const float *codes, const float *anchors, int64_t n, float *out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const float *a = anchors + i * 4, *c = codes + i * 4;
+        float ha = a[2] - a[0], wa = a[3] - a[1];
+        float t = 0.5f * ha;
+        float cya = a[0] + t;
+        t = 0.5f * wa;
+        float cxa = a[1] + t;
+        float ty = c[0] / 10.0f, tx = c[1] / 10.0f, th = c[2] / 5.0f, tw = c[3] / 5.0f;
+        float h = exp_f32(th) * ha, w = exp_f32(tw) * wa;
+        t = ty * ha;
+        float cy = t + cya;
+        t = tx * wa;
+        float cx = t + cxa;
+        float hh = 0.5f * h, hw = 0.5f * w;
+        float b[4] = {cy - hh, cx - hw, cy + hh, cx + hw};
+        for (int k = 0; k < 4; ++k) {
+            float v = b[k];
+            v = v < 0.0f ? 0.0f : v;
+            v = v > 1.0f ? 1.0f : v;
+            out[i * 4 + k] = v;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* tf.image.non_max_suppression == NonMaxSuppressionV3 of TensorFlow r1.12   */
+/* (tensorflow/core/kernels/non_max_suppression_op.cc; third-party, pinned   */
+/* by README.md:22, absent from /root/reference -- published algorithm):     */
+/*   candidates: score > score_threshold (strict), visited by descending     */
+/*   score; kept iff IoU with every kept box is NOT > iou_threshold; stops   */
+/*   at max_output_size.  IoU: corners min/max-normalised, 0 when either     */
+/*   area <= 0, inter / (area_i + area_j - inter).                           */
+/* TF 1.12 orders equal scores by std::priority_queue (unspecified); this    */
+/* restatement fixes it: equal scores -> lower box index first.              */
+static inline float fminf_(float a, float b) { return a < b ? a : b; }
+static inline float fmaxf_(float a, float b) { return a > b ? a : b; }
+
+ORC_API int orc_iou_greater(const float *bi, const float *bj, float thr)
+{
+    float ymin_i = fminf_(bi[0], bi[2]), xmin_i = fminf_(bi[1], bi[3]);
+    float ymax_i = fmaxf_(bi[0], bi[2]), xmax_i = fmaxf_(bi[1], bi[3]);
+    float ymin_j = fminf_(bj[0], bj[2]), xmin_j = fminf_(bj[1], bj[3]);
+    float ymax_j = fmaxf_(bj[0], bj[2]), xmax_j = fmaxf_(bj[1], bj[3]);
+    float area_i = (ymax_i - ymin_i) * (xmax_i - xmin_i);
+    float area_j = (ymax_j - ymin_j) * (xmax_j - xmin_j);
+    if (area_i <= 0.0f || area_j <= 0.0f) return 0;
+    float iy0 = fmaxf_(ymin_i, ymin_j), ix0 = fmaxf_(xmin_i, xmin_j);
+    float iy1 = fminf_(ymax_i, ymax_j), ix1 = fminf_(xmax_i, xmax_j);
+    float ih = fmaxf_(iy1 - iy0, 0.0f), iw = fmaxf_(ix1 - ix0, 0.0f);
+    float inter = ih * iw;
+    float uni = area_i + area_j;
+    uni = uni - inter;
+    float iou = inter / uni;
+    return iou > thr;
+}
+
+typedef struct { float score; int idx; } cand_t;
+static int cand_cmp(const void *a, const void *b)
+{
+    const cand_t *x = (const cand_t *)a, *y = (const cand_t *)b;
+    if (x->score > y->score) return -1;
+    if (x->score < y->score) return 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+ORC_API int orc_nms(const float *boxes, const float *scores, int64_t score_stride, int n,
+                    int max_out, float iou_thr, float score_thr, int *selected)
+{
+    cand_t *c = (cand_t *)malloc(sizeof(cand_t) * (size_t)(n > 0 ? n : 1));
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        float s = scores[(int64_t)i * score_stride];
+        if (s > score_thr) { c[m].score = s; c[m].idx = i; ++m; }
+    }
+    qsort(c, (size_t)m, sizeof(cand_t), cand_cmp);
+    int k = 0;
+    for (int q = 0; q < m && k < max_out; ++q) {
+        int keep = 1;
+        for (int j = k - 1; j >= 0; --j)
+            if (orc_iou_greater(boxes + (int64_t)c[q].idx * 4, boxes + (int64_t)selected[j] * 4,
+                                iou_thr)) { keep = 0; break; }
+        if (keep) selected[k++] = c[q].idx;
+    }
+    free(c);
+    return k;
+}
+
+/* ------------------------------------------------------------------------- */
+/* One image of nms.py:48-102 (`fn`) + ssd.py:60 + model.py:67-68:           */
+/* sigmoid -> keep rows with max score >= thr -> decode -> clip -> per-class */
+/* NMS in class order -> concat -> zero-pad to C*max_per_class -> /box_scaler*/
+ORC_API void orc_postprocess_image(const float *logits /*[N,C]*/, const float *codes /*[N,4]*/,
+                                   const float *anchors /*[N,4]*/, int N, int C,
+                                   float score_thr, float iou_thr, int max_per_class,
+                                   const float *box_scaler /*[4]*/, float *out_boxes,
+                                   float *out_scores, int32_t *out_labels, int32_t *out_num)
+{
+    int *keep = (int *)malloc(sizeof(int) * (size_t)N);
+    float *prob = (float *)malloc(sizeof(float) * (size_t)N * C);
+    int m = 0;
+    for (int i = 0; i < N; ++i) {
+        float mx = -1.0f;
+        for (int c = 0; c < C; ++c) {
+            float s = orc_sigmoid(logits[(int64_t)i * C + c]);
+            prob[(int64_t)i * C + c] = s;
+            mx = s > mx ? s : mx;
+        }
+        if (mx >= score_thr) keep[m++] = i;            /* nms.py:71 (>=) */
+    }
+    float *mc = (float *)malloc(sizeof(float) * 4 * (size_t)(m + 1));
+    float *ma = (float *)malloc(sizeof(float) * 4 * (size_t)(m + 1));
+    float *ms = (float *)malloc(sizeof(float) * (size_t)C * (size_t)(m + 1));
+    float *mb = (float *)malloc(sizeof(float) * 4 * (size_t)(m + 1));
+    for (int q = 0; q < m; ++q) {                      /* boolean_mask, nms.py:72-74 */
+        memcpy(mc + q * 4, codes + (int64_t)keep[q] * 4, 16);
+        memcpy(ma + q * 4, anchors + (int64_t)keep[q] * 4, 16);
+        memcpy(ms + (int64_t)q * C, prob + (int64_t)keep[q] * C, sizeof(float) * (size_t)C);
+    }
+    orc_decode_clip(mc, ma, m, mb);                    /* nms.py:76-77 */
+    int total = C * max_per_class;
+    memset(out_boxes, 0, sizeof(float) * 4 * (size_t)total);
+    memset(out_scores, 0, sizeof(float) * (size_t)total);
+    memset(out_labels, 0, sizeof(int32_t) * (size_t)total);
+    int *sel = (int *)malloc(sizeof(int) * (size_t)max_per_class);
+    int nb = 0;
+    for (int c = 0; c < C; ++c) {                      /* nms.py:31-40 */
+        int k = orc_nms(mb, ms + c, C, m, max_per_class, iou_thr, score_thr, sel);
+        for (int j = 0; j < k; ++j, ++nb) {
+            for (int t = 0; t < 4; ++t)
+                out_boxes[nb * 4 + t] = mb[sel[j] * 4 + t] / box_scaler[t];
+            out_scores[nb] = ms[(int64_t)sel[j] * C + c];
+            out_labels[nb] = c;
+        }
+    }
+    *out_num = nb;
+    free(sel); free(mb); free(ms); free(ma); free(mc); free(prob); free(keep);
+}
+
+ORC_API void orc_postprocess(const float *logits, const float *codes, const float *anchors,
+                             int B, int N, int C, float score_thr, float iou_thr,
+                             int max_per_class, const float *box_scaler, float *out_boxes,
+                             float *out_scores, int32_t *out_labels, int32_t *out_num)
+{
+    int total = C * max_per_class;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b)                        /* tf.map_fn, nms.py:96-101 */
+        orc_postprocess_image(logits + (int64_t)b * N * C, codes + (int64_t)b * N * 4, anchors,
+                              N, C, score_thr, iou_thr, max_per_class, box_scaler,
+                              out_boxes + (int64_t)b * total * 4, out_scores + (int64_t)b * total,
+                              out_labels + (int64_t)b * total, out_num + b);
+}

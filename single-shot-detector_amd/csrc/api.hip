@@ -1,0 +1,1215 @@
+// Host side of libssd_hip.so: the C ABI of include/ssd_hip.h.
+//   * weight container keyed by the reference's TF variable names
+//   * finalize: batch-norm scale factors, channel re-ordering / padding, kernel re-layout
+//   * layer plan per (B,H,W): the reference graph (create_pb.py + model.py PREDICT) as a
+//     flat list of kernel launches on one stream, no host synchronisation
+//   * stage entry points used by the parity tests
+// No CPU fallback exists: every entry point either launches HIP kernels or fails.
+#include "../../include/ssd_hip.h"
+#include "ssd_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+// ----------------------------------------------------------------------------- errors
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(SSD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+#define SSDCHK(expr)                                                                         \
+    do {                                                                                     \
+        int r_ = (expr);                                                                     \
+        if (r_ != SSD_OK) return r_;                                                         \
+    } while (0)
+
+extern "C" const char *ssd_last_error(void) { return g_err.c_str(); }
+
+// ----------------------------------------------------------------------------- helpers
+struct Tensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct DevPool {
+    std::vector<void *> ptrs;
+    int alloc(void **out, size_t bytes)
+    {
+        if (bytes == 0) bytes = 256;
+        HIPCHK(hipMalloc(out, bytes));
+        ptrs.push_back(*out);
+        return SSD_OK;
+    }
+    template <class T> int upload(T **out, const std::vector<T> &v)
+    {
+        void *p = nullptr;
+        SSDCHK(alloc(&p, v.size() * sizeof(T)));
+        if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        *out = (T *)p;
+        return SSD_OK;
+    }
+    void free_all()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+    }
+};
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// physical position p -> logical channel (or -1 for a pad channel)
+static std::vector<int> phys_map(int C, int Cp)
+{
+    std::vector<int> m(Cp);
+    for (int p = 0; p < Cp; ++p) {
+        int l = ssd_logical_of_phys(p);
+        m[p] = l < C ? l : -1;
+    }
+    return m;
+}
+static std::vector<int> ident_map(int C, int Cp)
+{
+    std::vector<int> m(Cp);
+    for (int p = 0; p < Cp; ++p) m[p] = p < C ? p : -1;
+    return m;
+}
+
+struct BnHost { std::vector<float> mean, sf, beta; };
+
+// batch_norm_relu (layer_utils.py:5-12): sf = gamma * rsqrt(var + 1e-3)
+static void bn_pack(const float *gamma, const float *beta, const float *mean, const float *var,
+                    const std::vector<int> &outmap, BnHost &o)
+{
+    const float eps = 1e-3f;
+    for (int p : outmap) {
+        if (p < 0) { o.mean.push_back(0.f); o.sf.push_back(0.f); o.beta.push_back(0.f); continue; }
+        o.mean.push_back(mean[p]);
+        float s = 1.0f / sqrtf(var[p] + eps);
+        o.sf.push_back(gamma[p] * s);
+        o.beta.push_back(beta[p]);
+    }
+}
+
+struct ConvW {
+    float *wt = nullptr, *mean = nullptr, *sf = nullptr, *beta = nullptr, *bias = nullptr;
+    int CinP = 0, CoutP = 0, CoutPad = 0, taps = 1, tile = IGEMM_128x128;
+    int Cin_l = 0, Cout_l = 0;
+};
+
+static int pick_tile(int CoutP) { return CoutP <= 32 ? IGEMM_128x32 : (CoutP <= 64 ? IGEMM_128x64 : IGEMM_128x128); }
+
+// w: HWIO [k,k,Cin_l,Cout_l] -> wt [taps][CoutPad][CinP]
+static int pack_conv(DevPool &pool, const float *w, int k, int Cin_l, int Cout_l, const std::vector<int> &inmap,
+                     const std::vector<int> &outmap, ConvW &cw)
+{
+    cw.taps = k * k;
+    cw.CinP = (int)inmap.size();
+    cw.CoutP = (int)outmap.size();
+    cw.tile = pick_tile(cw.CoutP);
+    cw.CoutPad = round_up(cw.CoutP, igemm_tile_bn(cw.tile));
+    cw.Cin_l = Cin_l;
+    cw.Cout_l = Cout_l;
+    std::vector<float> t((size_t)cw.taps * cw.CoutPad * cw.CinP, 0.0f);
+    for (int tap = 0; tap < cw.taps; ++tap)
+        for (int n = 0; n < cw.CoutP; ++n) {
+            if (outmap[n] < 0) continue;
+            float *dst = &t[((size_t)tap * cw.CoutPad + n) * cw.CinP];
+            for (int p = 0; p < cw.CinP; ++p)
+                if (inmap[p] >= 0) dst[p] = w[((size_t)tap * Cin_l + inmap[p]) * Cout_l + outmap[n]];
+        }
+    return pool.upload(&cw.wt, t);
+}
+
+static int upload_bn(DevPool &pool, const BnHost &b, ConvW &cw)
+{
+    SSDCHK(pool.upload(&cw.mean, b.mean));
+    SSDCHK(pool.upload(&cw.sf, b.sf));
+    return pool.upload(&cw.beta, b.beta);
+}
+
+struct DwW { float *w = nullptr, *mean = nullptr, *sf = nullptr, *beta = nullptr; int Cp = 0; };
+
+// ----------------------------------------------------------------------------- ops
+struct Op {
+    int cls;            // profile class
+    double flops, bytes;
+    std::function<hipError_t(hipStream_t)> run;
+};
+
+struct LevelDesc {
+    int H, W, OH, OW;
+    long long in_off, out_off, out_bstride;
+    int out_rstride, param_off;
+    long long res_off;
+};
+
+static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2, const float *res, int B, int stride,
+                       int pad, int act, const std::vector<LevelDesc> &lv, bool dense)
+{
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.wt = cw.wt; a.out = out; a.out2 = out2;
+    a.mean = cw.mean; a.sf = cw.sf; a.beta = cw.beta; a.bias = cw.bias; a.res = res;
+    a.B = B; a.Cin = cw.CinP; a.Cout = cw.CoutP; a.CoutPad = cw.CoutPad; a.taps = cw.taps;
+    a.stride = stride; a.pad = pad; a.act = act;
+    a.nlevels = (int)lv.size();
+    a.n_tiles_n = cw.CoutPad / igemm_tile_bn(cw.tile);
+    a.dense_out = dense ? 1 : 0;
+    int tiles = 0;
+    double rows = 0, inb = 0;
+    const int BM = igemm_tile_bm(cw.tile);
+    for (size_t i = 0; i < lv.size(); ++i) {
+        IgemmLevel &L = a.lv[i];
+        L.H = lv[i].H; L.W = lv[i].W; L.OH = lv[i].OH; L.OW = lv[i].OW;
+        L.M = B * L.OH * L.OW;
+        L.tile_begin = tiles;
+        tiles += (L.M + BM - 1) / BM;
+        L.param_off = lv[i].param_off;
+        L.out_rstride = lv[i].out_rstride;
+        L.in_off = lv[i].in_off; L.out_off = lv[i].out_off; L.out_bstride = lv[i].out_bstride;
+        L.res_off = lv[i].res_off;
+        rows += L.M;
+        inb += (double)B * L.H * L.W * cw.Cin_l * 4.0;
+    }
+    Op op;
+    op.cls = cw.taps == 9 ? 0 : 1;
+    op.flops = 2.0 * rows * cw.taps * cw.Cin_l * cw.Cout_l;
+    op.bytes = inb + rows * cw.Cout_l * 4.0 + (double)cw.taps * cw.Cin_l * cw.Cout_l * 4.0;
+    const int tile = cw.tile;
+    op.run = [a, tile, tiles](hipStream_t s) { return launch_igemm(tile, a, tiles, s); };
+    return op;
+}
+
+// ----------------------------------------------------------------------------- handle
+struct Retained { const float *dev; int B, H, W, C, Cp; bool permuted; };
+
+struct EvPair { hipEvent_t a, b; int cls; };
+
+struct ssd_handle {
+    ssd_config cfg;
+    std::map<std::string, Tensor> vars;
+    bool finalized = false;
+    DevPool wpool;      // weights
+    DevPool apool;      // activations / workspace of the current plan
+    // packed weights
+    DwW first;                          // first conv (w = [27][CoutP])
+    int firstCp = 0, firstAct = SSD_ACT_RELU6;
+    std::vector<DwW> dw;                // depthwise layers in execution order
+    std::vector<ConvW> pw;              // backbone pointwise layers in execution order
+    ConvW lat[3], pconv[5];             // fpn lateral3..5, p3..p7
+    ConvW tower[2][4], final_[2];       // [box, class]
+    std::vector<int *> tabs;            // shufflenet gather tables (device)
+    int c_ch[3] = {0, 0, 0};            // logical channels of c3, c4, c5
+    // plan
+    int pB = 0, pH = 0, pW = 0;
+    std::vector<Op> ops;
+    const uint8_t *cur_images = nullptr;
+    float *o_boxes = nullptr, *o_scores = nullptr; int32_t *o_labels = nullptr, *o_num = nullptr;
+    PostArgs post;
+    std::map<std::string, Retained> retained;
+    int N = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<EvPair> evs;
+    double acc_ms[6] = {0}, acc_flops[6] = {0}, acc_bytes[6] = {0};
+    long long acc_n[6] = {0};
+};
+
+static const Tensor *getvar(ssd_handle *h, const std::string &n, std::initializer_list<int64_t> shape)
+{
+    auto it = h->vars.find(n);
+    if (it == h->vars.end()) { fail(SSD_ERR_WEIGHT, "missing variable " + n); return nullptr; }
+    const Tensor &t = it->second;
+    std::vector<int64_t> want(shape);
+    if (t.shape != want) {
+        std::string s = "variable " + n + " has shape [";
+        for (auto d : t.shape) s += std::to_string(d) + ",";
+        s += "] expected [";
+        for (auto d : want) s += std::to_string(d) + ",";
+        fail(SSD_ERR_WEIGHT, s + "]");
+        return nullptr;
+    }
+    return &t;
+}
+
+static int get_bn(ssd_handle *h, const std::string &scope, int C, const std::vector<int> &outmap, BnHost &o)
+{
+    const Tensor *g = getvar(h, scope + "/gamma", {C}), *b = getvar(h, scope + "/beta", {C});
+    const Tensor *m = getvar(h, scope + "/moving_mean", {C}), *v = getvar(h, scope + "/moving_variance", {C});
+    if (!g || !b || !m || !v) return SSD_ERR_WEIGHT;
+    bn_pack(g->data.data(), b->data.data(), m->data.data(), v->data.data(), outmap, o);
+    return SSD_OK;
+}
+
+// dense conv + optional BN, standard physical maps on both sides
+static int load_conv(ssd_handle *h, const std::string &wname, const std::string &bnscope, int k, int Cin, int Cout,
+                     ConvW &cw, bool out_identity = false)
+{
+    const Tensor *w = getvar(h, wname, {k, k, Cin, Cout});
+    if (!w) return SSD_ERR_WEIGHT;
+    std::vector<int> inmap = phys_map(Cin, round_up(Cin, 32));
+    std::vector<int> outmap = out_identity ? ident_map(Cout, Cout) : phys_map(Cout, round_up(Cout, 32));
+    SSDCHK(pack_conv(h->wpool, w->data.data(), k, Cin, Cout, inmap, outmap, cw));
+    if (!bnscope.empty()) {
+        BnHost b;
+        SSDCHK(get_bn(h, bnscope, Cout, outmap, b));
+        SSDCHK(upload_bn(h->wpool, b, cw));
+    }
+    return SSD_OK;
+}
+
+static int load_dw(ssd_handle *h, const std::string &scope, const std::string &bnname, int C, DwW &d)
+{
+    const Tensor *w = getvar(h, scope + "/depthwise_weights", {3, 3, C, 1});
+    if (!w) return SSD_ERR_WEIGHT;
+    d.Cp = round_up(C, 32);
+    std::vector<int> map = phys_map(C, d.Cp);
+    std::vector<float> t((size_t)9 * d.Cp, 0.0f);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int p = 0; p < d.Cp; ++p)
+            if (map[p] >= 0) t[(size_t)tap * d.Cp + p] = w->data[(size_t)tap * C + map[p]];
+    SSDCHK(h->wpool.upload(&d.w, t));
+    BnHost b;
+    SSDCHK(get_bn(h, scope + "/" + bnname, C, map, b));
+    SSDCHK(h->wpool.upload(&d.mean, b.mean));
+    SSDCHK(h->wpool.upload(&d.sf, b.sf));
+    return h->wpool.upload(&d.beta, b.beta);
+}
+
+static int load_first(ssd_handle *h, const std::string &scope, const std::string &bnname, int Cout)
+{
+    const Tensor *w = getvar(h, scope + "/weights", {3, 3, 3, Cout});
+    if (!w) return SSD_ERR_WEIGHT;
+    const int Cp = round_up(Cout, 32);
+    std::vector<int> map = phys_map(Cout, Cp);
+    std::vector<float> t((size_t)27 * Cp, 0.0f);
+    for (int r = 0; r < 27; ++r)
+        for (int p = 0; p < Cp; ++p)
+            if (map[p] >= 0) t[(size_t)r * Cp + p] = w->data[(size_t)r * Cout + map[p]];
+    SSDCHK(h->wpool.upload(&h->first.w, t));
+    BnHost b;
+    SSDCHK(get_bn(h, scope + "/" + bnname, Cout, map, b));
+    SSDCHK(h->wpool.upload(&h->first.mean, b.mean));
+    SSDCHK(h->wpool.upload(&h->first.sf, b.sf));
+    SSDCHK(h->wpool.upload(&h->first.beta, b.beta));
+    h->first.Cp = Cp;
+    h->firstCp = Cp;
+    return SSD_OK;
+}
+
+// mobilenet_v1.py:52-58
+static const int MB_STRIDE[13] = {1, 2, 1, 2, 1, 2, 1, 1, 1, 1, 1, 2, 1};
+static const int MB_FILT[13] = {64, 128, 128, 256, 256, 512, 512, 512, 512, 512, 512, 1024, 1024};
+static int mb_depth(int x, float dm) { int v = (int)(x * dm); return v > 8 ? v : 8; }
+
+static int shuffle_initial_depth(float dm)
+{
+    // shufflenet_v2.py:22 `possibilities`, keyed by str(depth_multiplier) (model.py:29)
+    if (dm == 0.5f) return 48;
+    if (dm == 1.0f) return 116;
+    if (dm == 1.5f) return 176;
+    if (dm == 2.0f) return 224;
+    return -1;
+}
+
+static int finalize_mobilenet(ssd_handle *h)
+{
+    const float dm = h->cfg.depth_multiplier;
+    int c = mb_depth(32, dm);
+    SSDCHK(load_first(h, "MobilenetV1/Conv2d_0", "BatchNorm", c));
+    h->firstAct = SSD_ACT_RELU6;
+    h->dw.resize(13);
+    h->pw.resize(13);
+    for (int i = 0; i < 13; ++i) {
+        char s[96];
+        snprintf(s, sizeof s, "MobilenetV1/Conv2d_%d_depthwise", i + 1);
+        SSDCHK(load_dw(h, s, "BatchNorm", c, h->dw[i]));
+        const int f = mb_depth(MB_FILT[i], dm);
+        snprintf(s, sizeof s, "MobilenetV1/Conv2d_%d_pointwise", i + 1);
+        SSDCHK(load_conv(h, std::string(s) + "/weights", std::string(s) + "/BatchNorm", 1, c, f, h->pw[i]));
+        c = f;
+        if (i == 4) h->c_ch[0] = c;
+        if (i == 10) h->c_ch[1] = c;
+        if (i == 12) h->c_ch[2] = c;
+    }
+    return SSD_OK;
+}
+
+// ShuffleNet layer order (execution order used by the plan):
+//   per stage: unit_1 {before, dw, after, second dw, second after}, units 2..n {before, dw, after}
+//   then Conv5.
+static int finalize_shufflenet(ssd_handle *h)
+{
+    const int D0 = shuffle_initial_depth(h->cfg.depth_multiplier);
+    if (D0 < 0) return fail(SSD_ERR_INVALID, "shufflenet depth_multiplier must be 0.5, 1.0, 1.5 or 2.0");
+    SSDCHK(load_first(h, "ShuffleNetV2/Conv1", "batch_norm", 24));
+    h->firstAct = SSD_ACT_RELU;
+    const int units[3] = {4, 8, 4};
+    int cin = 24, out = D0;
+    for (int st = 0; st < 3; ++st) {
+        const int D = out / 2;
+        char base[64];
+        snprintf(base, sizeof base, "ShuffleNetV2/Stage%d", st + 2);
+        std::string u1 = std::string(base) + "/unit_1";
+        ConvW cw; DwW d;
+        SSDCHK(load_conv(h, u1 + "/conv1x1_before/weights", u1 + "/conv1x1_before/batch_norm", 1, cin, cin, cw)); h->pw.push_back(cw);
+        SSDCHK(load_dw(h, u1 + "/depthwise", "batch_norm", cin, d)); h->dw.push_back(d);
+        cw = ConvW();
+        SSDCHK(load_conv(h, u1 + "/conv1x1_after/weights", u1 + "/conv1x1_after/batch_norm", 1, cin, D, cw)); h->pw.push_back(cw);
+        d = DwW();
+        SSDCHK(load_dw(h, u1 + "/second_branch/depthwise", "batch_norm", cin, d)); h->dw.push_back(d);
+        cw = ConvW();
+        SSDCHK(load_conv(h, u1 + "/second_branch/conv1x1_after/weights", u1 + "/second_branch/conv1x1_after/batch_norm", 1, cin, D, cw)); h->pw.push_back(cw);
+        for (int j = 2; j <= units[st]; ++j) {
+            std::string u = std::string(base) + "/unit_" + std::to_string(j);
+            cw = ConvW();
+            SSDCHK(load_conv(h, u + "/conv1x1_before/weights", u + "/conv1x1_before/batch_norm", 1, D, D, cw)); h->pw.push_back(cw);
+            d = DwW();
+            SSDCHK(load_dw(h, u + "/depthwise", "batch_norm", D, d)); h->dw.push_back(d);
+            cw = ConvW();
+            SSDCHK(load_conv(h, u + "/conv1x1_after/weights", u + "/conv1x1_after/batch_norm", 1, D, D, cw)); h->pw.push_back(cw);
+        }
+        // gather tables for this stage: shuffle (two outputs) and final concat
+        const int Dp = round_up(D, 32), Cc = round_up(2 * D, 32);
+        std::vector<int> tx(2 * Dp, -1), ty(2 * Dp, -1), tc(2 * Cc, -1);
+        for (int p = 0; p < Dp; ++p) {
+            const int j = ssd_logical_of_phys(p);
+            if (j >= D) continue;
+            const int zx = j, zy = D + j;
+            tx[2 * p] = zx & 1; tx[2 * p + 1] = ssd_phys_of_logical(zx >> 1);
+            ty[2 * p] = zy & 1; ty[2 * p + 1] = ssd_phys_of_logical(zy >> 1);
+        }
+        for (int p = 0; p < Cc; ++p) {
+            const int j = ssd_logical_of_phys(p);
+            if (j >= 2 * D) continue;
+            tc[2 * p] = j < D ? 0 : 1;
+            tc[2 * p + 1] = ssd_phys_of_logical(j < D ? j : j - D);
+        }
+        int *dx, *dy, *dc;
+        SSDCHK(h->wpool.upload(&dx, tx)); SSDCHK(h->wpool.upload(&dy, ty)); SSDCHK(h->wpool.upload(&dc, tc));
+        h->tabs.push_back(dx); h->tabs.push_back(dy); h->tabs.push_back(dc);
+        cin = out;
+        if (st == 0) h->c_ch[0] = out;
+        if (st == 1) h->c_ch[1] = out;
+        out *= 2;
+    }
+    const int fin = h->cfg.depth_multiplier == 2.0f ? 2048 : 1024;
+    ConvW cw;
+    SSDCHK(load_conv(h, "ShuffleNetV2/Conv5/weights", "ShuffleNetV2/Conv5/batch_norm", 1, cin, fin, cw));
+    h->pw.push_back(cw);
+    h->c_ch[2] = fin;
+    return SSD_OK;
+}
+
+static int finalize_fpn_heads(ssd_handle *h)
+{
+    // feature_extractor.py:55-74
+    for (int i = 0; i < 3; ++i) {
+        char n[48];
+        snprintf(n, sizeof n, "fpn/lateral%d/kernel", i + 3);
+        SSDCHK(load_conv(h, n, "", 1, h->c_ch[i], 256, h->lat[i]));
+    }
+    for (int i = 0; i < 5; ++i) {
+        char n[48], b[48];
+        snprintf(n, sizeof n, "fpn/p%d/kernel", i + 3);
+        snprintf(b, sizeof b, "fpn/p%d_batch_norm", i + 3);
+        SSDCHK(load_conv(h, n, b, 3, i == 3 ? h->c_ch[2] : 256, 256, h->pconv[i]));
+    }
+    // box_predictor.py:107-155: conv weights shared across levels, batch norm per level
+    const char *nets[2] = {"box_net", "class_net"};
+    const int A = 6, C = h->cfg.num_classes;
+    for (int t = 0; t < 2; ++t) {
+        for (int i = 0; i < 4; ++i) {
+            char n[64];
+            snprintf(n, sizeof n, "%s/conv3x3_%d/kernel", nets[t], i);
+            ConvW &cw = h->tower[t][i];
+            SSDCHK(load_conv(h, n, "", 3, 256, 256, cw));
+            BnHost b;
+            std::vector<int> outmap = phys_map(256, 256);
+            for (int l = 3; l <= 7; ++l) {
+                char s[80];
+                snprintf(s, sizeof s, "%s/batch_norm_%d_for_level_%d", nets[t], i, l);
+                SSDCHK(get_bn(h, s, 256, outmap, b));
+            }
+            SSDCHK(upload_bn(h->wpool, b, cw));
+        }
+        const int Cout = t == 0 ? 4 * A : C * A;
+        const std::string scope = std::string(nets[t]) + (t == 0 ? "/encoded_boxes" : "/logits");
+        ConvW &cw = h->final_[t];
+        SSDCHK(load_conv(h, scope + "/kernel", "", 3, 256, Cout, cw, /*out_identity=*/true));
+        const Tensor *bias = getvar(h, scope + "/bias", {Cout});
+        if (!bias) return SSD_ERR_WEIGHT;
+        SSDCHK(h->wpool.upload(&cw.bias, bias->data));
+    }
+    return SSD_OK;
+}
+
+// ----------------------------------------------------------------------------- anchors
+static const int A_STRIDES[5] = {8, 16, 32, 64, 128};
+
+extern "C" int32_t ssd_num_anchors(int32_t H, int32_t W)
+{
+    int n = 0;
+    for (int l = 0; l < 5; ++l) {
+        const int h = (int)ceilf((float)H / (float)A_STRIDES[l]), w = (int)ceilf((float)W / (float)A_STRIDES[l]);
+        n += h * w * 6;
+    }
+    return n;
+}
+
+// anchor_generator.py:40-170 in the fp32 arithmetic of the TF graph (host side, once per
+// image size).  Constants: model.py:37-42.
+extern "C" int ssd_anchors(int32_t H, int32_t W, float *out)
+{
+    if (H <= 0 || W <= 0 || !out) return fail(SSD_ERR_INVALID, "ssd_anchors: bad arguments");
+    static const double base[5] = {32, 64, 128, 256, 512}, mult[2] = {1.0, 1.4142}, ars[3] = {1.0, 2.0, 0.5};
+    const float ih = (float)H, iw = (float)W;
+    long long idx = 0;
+    for (int l = 0; l < 5; ++l) {
+        const float stride = (float)A_STRIDES[l];
+        const int h = (int)ceilf(ih / stride), w = (int)ceilf(iw / stride);
+        float hh[6], hw[6];
+        int a = 0;
+        for (int m = 0; m < 2; ++m)
+            for (int r = 0; r < 3; ++r, ++a) {
+                const float scale = (float)(mult[m] * base[l]);
+                const float rs = sqrtf((float)ars[r]);
+                const float height = scale / rs, width = scale * rs;
+                hh[a] = 0.5f * height;
+                hw[a] = 0.5f * width;
+            }
+        float t = ((float)h - 1.0f) * stride;
+        const float offy = 0.5f * (ih - t);
+        t = ((float)w - 1.0f) * stride;
+        const float offx = 0.5f * (iw - t);
+        for (int i = 0; i < h; ++i) {
+            float cy = (float)i * stride;
+            cy = cy + offy;
+            for (int j = 0; j < w; ++j) {
+                float cx = (float)j * stride;
+                cx = cx + offx;
+                for (a = 0; a < 6; ++a, ++idx) {
+                    out[idx * 4 + 0] = (cy - hh[a]) / ih;
+                    out[idx * 4 + 1] = (cx - hw[a]) / iw;
+                    out[idx * 4 + 2] = (cy + hh[a]) / ih;
+                    out[idx * 4 + 3] = (cx + hw[a]) / iw;
+                }
+            }
+        }
+    }
+    return SSD_OK;
+}
+
+// ----------------------------------------------------------------------------- lifetime
+extern "C" int ssd_create(const ssd_config *cfg, ssd_handle **out)
+{
+    if (!cfg || !out) return fail(SSD_ERR_INVALID, "ssd_create: null argument");
+    if (cfg->backbone != SSD_BACKBONE_MOBILENET && cfg->backbone != SSD_BACKBONE_SHUFFLENET)
+        return fail(SSD_ERR_INVALID, "ssd_create: unknown backbone");
+    if (cfg->num_classes < 1 || cfg->max_boxes_per_class < 1)
+        return fail(SSD_ERR_INVALID, "ssd_create: num_classes and max_boxes_per_class must be >= 1");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(SSD_ERR_INVALID, "ssd_create: no such HIP device");
+    HIPCHK(hipSetDevice(cfg->device));
+    ssd_handle *h = new ssd_handle();
+    h->cfg = *cfg;
+    *out = h;
+    return SSD_OK;
+}
+
+extern "C" void ssd_destroy(ssd_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (auto &e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    h->apool.free_all();
+    h->wpool.free_all();
+    delete h;
+}
+
+extern "C" int ssd_load_weight(ssd_handle *h, const char *name, const float *host, const int64_t *shape, int32_t ndim)
+{
+    if (!h || !name || !host || !shape || ndim < 1 || ndim > 4) return fail(SSD_ERR_INVALID, "ssd_load_weight: bad arguments");
+    if (h->finalized) return fail(SSD_ERR_STATE, "ssd_load_weight after ssd_finalize");
+    Tensor t;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 1) return fail(SSD_ERR_INVALID, "ssd_load_weight: non-positive dimension");
+        t.shape.push_back(shape[i]);
+        n *= shape[i];
+    }
+    t.data.assign(host, host + n);
+    h->vars[name] = std::move(t);
+    return SSD_OK;
+}
+
+extern "C" int ssd_finalize(ssd_handle *h)
+{
+    if (!h) return fail(SSD_ERR_INVALID, "ssd_finalize: null handle");
+    if (h->finalized) return fail(SSD_ERR_STATE, "ssd_finalize called twice");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int r = h->cfg.backbone == SSD_BACKBONE_MOBILENET ? finalize_mobilenet(h) : finalize_shufflenet(h);
+    if (r == SSD_OK) r = finalize_fpn_heads(h);
+    if (r != SSD_OK) {
+        h->wpool.free_all();
+        h->dw.clear(); h->pw.clear(); h->tabs.clear();
+        return r;
+    }
+    h->vars.clear();   // host copies no longer needed
+    h->finalized = true;
+    return SSD_OK;
+}
+
+// ----------------------------------------------------------------------------- plan
+struct Pyr { int h[5], w[5]; long long off[5]; long long total; };
+
+static Pyr make_pyr(int B, int H, int W, int C)
+{
+    Pyr p;
+    long long o = 0;
+    for (int l = 0; l < 5; ++l) {
+        p.h[l] = (H + A_STRIDES[l] - 1) / A_STRIDES[l];
+        p.w[l] = (W + A_STRIDES[l] - 1) / A_STRIDES[l];
+        p.off[l] = o;
+        o += (long long)B * p.h[l] * p.w[l] * C;
+    }
+    p.total = o;
+    return p;
+}
+
+static Op make_dw_op(const DwW &d, const float *in, int B, int H, int W, int stride, int act, float *out, int Cl)
+{
+    const int OH = H / stride, OW = W / stride, pad = stride == 1 ? 1 : 0;
+    Op op;
+    op.cls = 2;
+    op.flops = 2.0 * 9 * (double)B * OH * OW * Cl;
+    op.bytes = ((double)B * H * W + (double)B * OH * OW) * Cl * 4.0;
+    const DwW dd = d;
+    op.run = [=](hipStream_t s) {
+        return launch_depthwise(in, B, H, W, dd.Cp, dd.w, stride, pad, OH, OW, dd.mean, dd.sf, dd.beta, act, out, s);
+    };
+    return op;
+}
+
+static LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long in_off = 0, long long out_off = 0,
+                             int param_off = 0, long long res_off = 0)
+{
+    LevelDesc d;
+    d.H = H; d.W = W; d.OH = OH; d.OW = OW;
+    d.in_off = in_off; d.out_off = out_off;
+    d.out_bstride = (long long)OH * OW * CoutP;
+    d.out_rstride = CoutP;
+    d.param_off = param_off;
+    d.res_off = res_off;
+    return d;
+}
+
+static int build_plan(ssd_handle *h, int B, int H, int W)
+{
+    h->apool.free_all();
+    h->ops.clear();
+    h->retained.clear();
+    h->pB = h->pH = h->pW = 0;
+    DevPool &ap = h->apool;
+    auto falloc = [&](float **p, long long nfloats) { return ap.alloc((void **)p, (size_t)nfloats * sizeof(float)); };
+
+    // ---------------- backbone
+    float *C3 = nullptr, *C4 = nullptr, *C5 = nullptr;
+    const int h2 = H / 2, w2 = W / 2;
+    if (h->cfg.backbone == SSD_BACKBONE_MOBILENET) {
+        long long maxf = (long long)B * h2 * w2 * h->firstCp;
+        {
+            int c = h->firstCp, hh = h2, ww = w2;
+            for (int i = 0; i < 13; ++i) {
+                hh /= MB_STRIDE[i]; ww /= MB_STRIDE[i];
+                long long a = (long long)B * hh * ww * h->dw[i].Cp, b = (long long)B * hh * ww * h->pw[i].CoutP;
+                if (a > maxf) maxf = a;
+                if (b > maxf) maxf = b;
+                c = h->pw[i].CoutP;
+            }
+            (void)c;
+        }
+        float *X, *Y;
+        SSDCHK(falloc(&X, maxf));
+        SSDCHK(falloc(&Y, maxf));
+        {
+            Op op;
+            op.cls = 3;
+            op.flops = 2.0 * 27 * (double)B * h2 * w2 * h->pw[0].Cin_l;
+            op.bytes = (double)B * H * W * 3 + (double)B * h2 * w2 * h->pw[0].Cin_l * 4.0;
+            ssd_handle *hh = h;
+            const DwW f = h->first;
+            const int act = h->firstAct;
+            op.run = [=](hipStream_t s) {
+                return launch_first_conv(hh->cur_images, B, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, X, s);
+            };
+            h->ops.push_back(op);
+        }
+        float *cur = X;
+        int ch = h2, cwid = w2;
+        for (int i = 0; i < 13; ++i) {
+            const int s = MB_STRIDE[i];
+            float *dwo = (cur == X) ? Y : X;
+            h->ops.push_back(make_dw_op(h->dw[i], cur, B, ch, cwid, s, SSD_ACT_RELU6, dwo, h->pw[i].Cin_l));
+            ch /= s; cwid /= s;
+            const ConvW &cw = h->pw[i];
+            float *pwo;
+            if (i == 4 || i == 10 || i == 12) {
+                SSDCHK(falloc(&pwo, (long long)B * ch * cwid * cw.CoutP));
+                if (i == 4) C3 = pwo; else if (i == 10) C4 = pwo; else C5 = pwo;
+                const char *nm = i == 4 ? "c3" : (i == 10 ? "c4" : "c5");
+                h->retained[nm] = Retained{pwo, B, ch, cwid, cw.Cout_l, cw.CoutP, true};
+            } else {
+                pwo = (dwo == X) ? Y : X;
+            }
+            h->ops.push_back(make_conv_op(cw, dwo, pwo, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU6,
+                                          {dense_level(ch, cwid, ch, cwid, cw.CoutP)}, true));
+            cur = pwo;
+        }
+    } else {
+        // ---------------- ShuffleNet v2 (shufflenet_v2.py:50-69,79-137)
+        const int units[3] = {4, 8, 4};
+        const int fc = h->firstCp;
+        float *F, *MP;
+        SSDCHK(falloc(&F, (long long)B * h2 * w2 * fc));
+        const int h4 = h2 / 2, w4 = w2 / 2;
+        SSDCHK(falloc(&MP, (long long)B * h4 * w4 * fc));
+        {
+            Op op;
+            op.cls = 3;
+            op.flops = 2.0 * 27 * (double)B * h2 * w2 * 24;
+            op.bytes = (double)B * H * W * 3 + (double)B * h2 * w2 * 24 * 4.0;
+            ssd_handle *hh = h;
+            const DwW f = h->first;
+            const int act = h->firstAct;
+            op.run = [=](hipStream_t s) {
+                return launch_first_conv(hh->cur_images, B, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s);
+            };
+            h->ops.push_back(op);
+            Op mp;
+            mp.cls = 5; mp.flops = 0;
+            mp.bytes = ((double)B * h2 * w2 + (double)B * h4 * w4) * 24 * 4.0;
+            mp.run = [=](hipStream_t s) { return launch_maxpool(F, B, h2, w2, fc, MP, s); };
+            h->ops.push_back(mp);
+        }
+        const float *cur = MP;
+        int ch = h4, cwid = w4, ipw = 0, idw = 0;
+        for (int st = 0; st < 3; ++st) {
+            const int oh = ch / 2, ow = cwid / 2;
+            const long long rows = (long long)B * oh * ow;
+            // unit_1
+            const ConvW &before = h->pw[ipw], &after = h->pw[ipw + 1], &after2 = h->pw[ipw + 2];
+            const DwW &d1 = h->dw[idw], &d2 = h->dw[idw + 1];
+            ipw += 3; idw += 2;
+            const int Dp = after.CoutP, D = after.Cout_l;
+            float *t1, *t2, *t3, *Xa, *Xb, *Ya, *Yb, *U, *V;
+            SSDCHK(falloc(&t1, (long long)B * ch * cwid * before.CoutP));
+            SSDCHK(falloc(&t2, rows * d1.Cp));
+            SSDCHK(falloc(&t3, rows * d2.Cp));
+            SSDCHK(falloc(&Xa, rows * Dp)); SSDCHK(falloc(&Xb, rows * Dp));
+            SSDCHK(falloc(&Ya, rows * Dp)); SSDCHK(falloc(&Yb, rows * Dp));
+            SSDCHK(falloc(&U, rows * Dp)); SSDCHK(falloc(&V, rows * Dp));
+            h->ops.push_back(make_conv_op(before, cur, t1, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+                                          {dense_level(ch, cwid, ch, cwid, before.CoutP)}, true));
+            h->ops.push_back(make_dw_op(d1, t1, B, ch, cwid, 2, SSD_ACT_NONE, t2, before.Cout_l));
+            h->ops.push_back(make_conv_op(after, t2, Ya, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+                                          {dense_level(oh, ow, oh, ow, Dp)}, true));
+            h->ops.push_back(make_dw_op(d2, cur, B, ch, cwid, 2, SSD_ACT_NONE, t3, before.Cin_l));
+            h->ops.push_back(make_conv_op(after2, t3, Xa, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+                                          {dense_level(oh, ow, oh, ow, Dp)}, true));
+            float *x = Xa, *y = Ya, *xs = Xb, *ys = Yb;
+            const int *tabx = h->tabs[st * 3], *taby = h->tabs[st * 3 + 1], *tabc = h->tabs[st * 3 + 2];
+            for (int j = 2; j <= units[st]; ++j) {
+                {   // concat_shuffle_split: (x, y) -> (xs, ys)
+                    Op g;
+                    g.cls = 5; g.flops = 0; g.bytes = 4.0 * rows * D * 4.0;
+                    const float *cx = x, *cy = y; float *ox = xs, *oy = ys;
+                    g.run = [=](hipStream_t s) {
+                        hipError_t e = launch_gather_channels(cx, Dp, cy, Dp, rows, tabx, Dp, ox, s);
+                        if (e != hipSuccess) return e;
+                        return launch_gather_channels(cx, Dp, cy, Dp, rows, taby, Dp, oy, s);
+                    };
+                    h->ops.push_back(g);
+                }
+                const ConvW &b2 = h->pw[ipw], &a2 = h->pw[ipw + 1];
+                const DwW &dd = h->dw[idw];
+                ipw += 2; idw += 1;
+                h->ops.push_back(make_conv_op(b2, xs, U, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+                                              {dense_level(oh, ow, oh, ow, Dp)}, true));
+                h->ops.push_back(make_dw_op(dd, U, B, oh, ow, 1, SSD_ACT_NONE, V, D));
+                // new x overwrites the old x buffer (dead after the shuffle); y' = ys
+                h->ops.push_back(make_conv_op(a2, V, x, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+                                              {dense_level(oh, ow, oh, ow, Dp)}, true));
+                // now (x, ys) is the live pair; old y and xs are free
+                float *oldy = y;
+                y = ys; ys = oldy;
+            }
+            // concat([x, y]) -> stage output
+            const int Cc = round_up(2 * D, 32);
+            float *S;
+            SSDCHK(falloc(&S, rows * Cc));
+            {
+                Op g;
+                g.cls = 5; g.flops = 0; g.bytes = 4.0 * rows * D * 4.0;
+                const float *cx = x, *cy = y;
+                g.run = [=](hipStream_t s) { return launch_gather_channels(cx, Dp, cy, Dp, rows, tabc, Cc, S, s); };
+                h->ops.push_back(g);
+            }
+            if (st == 0) { C3 = S; h->retained["c3"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
+            if (st == 1) { C4 = S; h->retained["c4"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
+            cur = S;
+            ch = oh; cwid = ow;
+        }
+        const ConvW &c5 = h->pw[ipw];
+        SSDCHK(falloc(&C5, (long long)B * ch * cwid * c5.CoutP));
+        h->ops.push_back(make_conv_op(c5, cur, C5, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+                                      {dense_level(ch, cwid, ch, cwid, c5.CoutP)}, true));
+        h->retained["c5"] = Retained{C5, B, ch, cwid, c5.Cout_l, c5.CoutP, true};
+    }
+
+    // ---------------- FPN (feature_extractor.py:40-76)
+    const Pyr py = make_pyr(B, H, W, 256);
+    float *P, *X5, *X4, *X3, *T6;
+    SSDCHK(falloc(&P, py.total));
+    SSDCHK(falloc(&X5, (long long)B * py.h[2] * py.w[2] * 256));
+    SSDCHK(falloc(&X4, (long long)B * py.h[1] * py.w[1] * 256));
+    SSDCHK(falloc(&X3, (long long)B * py.h[0] * py.w[0] * 256));
+    SSDCHK(falloc(&T6, (long long)B * py.h[3] * py.w[3] * 256));
+    auto lvl = [&](int l, int CoutP) { return dense_level(py.h[l], py.w[l], py.h[l], py.w[l], CoutP); };
+    // x5 = lateral5(c5); p5 = conv(x5)
+    h->ops.push_back(make_conv_op(h->lat[2], C5, X5, nullptr, nullptr, B, 1, 0, SSD_ACT_NONE, {lvl(2, 256)}, true));
+    {
+        LevelDesc d = lvl(2, 256);
+        d.out_off = py.off[2];
+        h->ops.push_back(make_conv_op(h->pconv[2], X5, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true));
+    }
+    {   // p6 = conv s2 (c5): BN+ReLU -> P6, ReLU(raw) -> T6 (input of p7, :60)
+        LevelDesc d = dense_level(py.h[2], py.w[2], py.h[3], py.w[3], 256);
+        d.out_off = py.off[3];
+        Op op = make_conv_op(h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true);
+        h->ops.push_back(op);
+        LevelDesc d7 = dense_level(py.h[3], py.w[3], py.h[4], py.w[4], 256);
+        d7.out_off = py.off[4];
+        h->ops.push_back(make_conv_op(h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true));
+    }
+    // x4 = up(x5) + lateral4(c4); p4;  x3 = up(x4) + lateral3(c3); p3
+    h->ops.push_back(make_conv_op(h->lat[1], C4, X4, nullptr, X5, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true));
+    {
+        LevelDesc d = lvl(1, 256);
+        d.out_off = py.off[1];
+        h->ops.push_back(make_conv_op(h->pconv[1], X4, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true));
+    }
+    h->ops.push_back(make_conv_op(h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true));
+    {
+        LevelDesc d = lvl(0, 256);
+        d.out_off = py.off[0];
+        h->ops.push_back(make_conv_op(h->pconv[0], X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true));
+    }
+    for (int l = 0; l < 5; ++l) {
+        char nm[8];
+        snprintf(nm, sizeof nm, "p%d", l + 3);
+        h->retained[nm] = Retained{P + py.off[l], B, py.h[l], py.w[l], 256, 256, true};
+    }
+
+    // ---------------- heads (box_predictor.py:36-155), all levels per launch
+    const int C = h->cfg.num_classes, A = 6;
+    long long N = 0, aoff[5];
+    for (int l = 0; l < 5; ++l) { aoff[l] = N; N += (long long)py.h[l] * py.w[l] * A; }
+    h->N = (int)N;
+    float *logits, *codes;
+    SSDCHK(falloc(&logits, (long long)B * N * C));
+    SSDCHK(falloc(&codes, (long long)B * N * 4));
+    for (int t = 0; t < 2; ++t) {
+        float *TA, *TB;
+        SSDCHK(falloc(&TA, py.total));
+        SSDCHK(falloc(&TB, py.total));
+        const float *in = P;
+        float *out = TA;
+        for (int i = 0; i < 4; ++i) {
+            std::vector<LevelDesc> lv;
+            for (int l = 0; l < 5; ++l) lv.push_back(dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, py.off[l], py.off[l], l * 256));
+            h->ops.push_back(make_conv_op(h->tower[t][i], in, out, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true));
+            in = out;
+            out = (out == TA) ? TB : TA;
+        }
+        const int per = t == 0 ? 4 : C;     // values per anchor
+        std::vector<LevelDesc> lv;
+        for (int l = 0; l < 5; ++l) {
+            LevelDesc d = dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 0, py.off[l]);
+            d.out_off = aoff[l] * per;
+            d.out_bstride = N * per;
+            d.out_rstride = A * per;
+            d.param_off = 0;
+            lv.push_back(d);
+        }
+        h->ops.push_back(make_conv_op(h->final_[t], in, t == 0 ? codes : logits, nullptr, nullptr, B, 1, 1, SSD_ACT_NONE, lv, false));
+    }
+    h->retained["encoded_boxes"] = Retained{codes, B, 1, (int)N, 4, 4, false};
+    h->retained["class_predictions"] = Retained{logits, B, 1, (int)N, C, C, false};
+
+    // ---------------- anchors + post-processing
+    std::vector<float> anc((size_t)N * 4);
+    SSDCHK(ssd_anchors(H, W, anc.data()));
+    float *anc_dev;
+    SSDCHK(ap.upload(&anc_dev, anc));
+    void *ws;
+    const size_t wsb = post_workspace_bytes(B, (int)N, C, h->cfg.max_boxes_per_class);
+    SSDCHK(ap.alloc(&ws, wsb));
+    PostArgs &p = h->post;
+    memset(&p, 0, sizeof(p));
+    p.logits = logits; p.codes = codes; p.anchors = anc_dev;
+    p.B = B; p.N = (int)N; p.C = C;
+    p.score_thr = h->cfg.score_threshold; p.iou_thr = h->cfg.iou_threshold;
+    p.max_per_class = h->cfg.max_boxes_per_class;
+    // resize_keeping_aspect_ratio is the identity for the accepted sizes: box_scaler = 1
+    for (int k = 0; k < 4; ++k) p.box_scaler[k] = 1.0f;
+    post_carve(p, ws);
+    h->pB = B; h->pH = H; h->pW = W;
+    return SSD_OK;
+}
+
+static float conservative_logit_bound(float thr)
+{
+    if (!(thr > 0.0f)) return -INFINITY;
+    if (!(thr < 1.0f)) return INFINITY;
+    const double l = log((double)thr / (1.0 - (double)thr));
+    return (float)(l - 1e-3 * (1.0 + fabs(l)));
+}
+
+static hipError_t run_op(ssd_handle *h, const Op &op, hipStream_t s)
+{
+    if (!h->profiling) return op.run(s);
+    EvPair e;
+    e.cls = op.cls;
+    hipError_t r = hipEventCreate(&e.a);
+    if (r != hipSuccess) return r;
+    r = hipEventCreate(&e.b);
+    if (r != hipSuccess) return r;
+    (void)hipEventRecord(e.a, s);
+    r = op.run(s);
+    (void)hipEventRecord(e.b, s);
+    h->evs.push_back(e);
+    h->acc_flops[op.cls] += op.flops;
+    h->acc_bytes[op.cls] += op.bytes;
+    h->acc_n[op.cls] += 1;
+    return r;
+}
+
+extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
+                           int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, void *stream)
+{
+    if (!h || !images_dev || !boxes_dev || !labels_dev || !scores_dev || !num_boxes_dev)
+        return fail(SSD_ERR_INVALID, "ssd_forward: null argument");
+    if (!h->finalized) return fail(SSD_ERR_STATE, "ssd_forward before ssd_finalize");
+    if (B < 1 || H < 128 || W < 128 || H % 128 || W % 128)
+        return fail(SSD_ERR_INVALID, "ssd_forward: H and W must be positive multiples of 128 (pipeline.py:152; anchor_generator.py:6-10)");
+    const int mn = H < W ? H : W;
+    if (mn != h->cfg.min_dimension)
+        return fail(SSD_ERR_INVALID, "ssd_forward: min(H,W) must equal min_dimension (resize path of pipeline.py:138-194 is not part of this build yet)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (B != h->pB || H != h->pH || W != h->pW) {
+        HIPCHK(hipDeviceSynchronize());
+        SSDCHK(build_plan(h, B, H, W));
+    }
+    hipStream_t s = (hipStream_t)stream;
+    h->cur_images = images_dev;
+    for (const Op &op : h->ops) HIPCHK(run_op(h, op, s));
+    PostArgs p = h->post;
+    p.boxes = boxes_dev; p.labels = labels_dev; p.scores = scores_dev; p.num = num_boxes_dev;
+    p.logit_lo = conservative_logit_bound(p.score_thr);
+    Op pop;
+    pop.cls = 4;
+    pop.flops = 0;
+    pop.bytes = (double)B * p.N * (p.C + 8) * 4.0;
+    pop.run = [p](hipStream_t st) { return launch_postprocess(p, st); };
+    HIPCHK(run_op(h, pop, s));
+    return SSD_OK;
+}
+
+extern "C" int ssd_get_tensor(ssd_handle *h, const char *name, float *dst, int64_t cap, int32_t *dims)
+{
+    if (!h || !name || !dst || !dims) return fail(SSD_ERR_INVALID, "ssd_get_tensor: null argument");
+    auto it = h->retained.find(name);
+    if (it == h->retained.end()) return fail(SSD_ERR_INVALID, std::string("ssd_get_tensor: unknown tensor ") + name);
+    const Retained &r = it->second;
+    const long long rows = (long long)r.B * r.H * r.W;
+    if (cap < rows * r.C) return fail(SSD_ERR_INVALID, "ssd_get_tensor: destination too small");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<float> tmp((size_t)rows * r.Cp);
+    HIPCHK(hipMemcpy(tmp.data(), r.dev, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (long long q = 0; q < rows; ++q)
+        for (int c = 0; c < r.C; ++c)
+            dst[q * r.C + c] = tmp[q * r.Cp + (r.permuted ? ssd_phys_of_logical(c) : c)];
+    dims[0] = r.B; dims[1] = r.H; dims[2] = r.W; dims[3] = r.C;
+    return SSD_OK;
+}
+
+// Device-to-device variant of ssd_get_tensor: dst_dev receives the tensor in logical
+// channel order; enqueued on `stream`, no synchronisation.
+extern "C" int ssd_get_tensor_dev(ssd_handle *h, const char *name, float *dst_dev, int64_t cap, int32_t *dims, void *stream)
+{
+    if (!h || !name || !dst_dev || !dims) return fail(SSD_ERR_INVALID, "ssd_get_tensor_dev: null argument");
+    auto it = h->retained.find(name);
+    if (it == h->retained.end()) return fail(SSD_ERR_INVALID, std::string("ssd_get_tensor_dev: unknown tensor ") + name);
+    const Retained &r = it->second;
+    const long long rows = (long long)r.B * r.H * r.W;
+    if (cap < rows * r.C) return fail(SSD_ERR_INVALID, "ssd_get_tensor_dev: destination too small");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (r.permuted) HIPCHK(launch_permute_channels(r.dev, rows, r.C, r.Cp, 0, dst_dev, (hipStream_t)stream));
+    else HIPCHK(hipMemcpyAsync(dst_dev, r.dev, (size_t)rows * r.C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    dims[0] = r.B; dims[1] = r.H; dims[2] = r.W; dims[3] = r.C;
+    return SSD_OK;
+}
+
+// ----------------------------------------------------------------------------- profiling
+extern "C" int ssd_profile_enable(ssd_handle *h, int32_t on)
+{
+    if (!h) return fail(SSD_ERR_INVALID, "null handle");
+    h->profiling = on != 0;
+    return SSD_OK;
+}
+
+static int drain_events(ssd_handle *h)
+{
+    for (auto &e : h->evs) {
+        HIPCHK(hipEventSynchronize(e.b));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+        h->acc_ms[e.cls] += ms;
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    h->evs.clear();
+    return SSD_OK;
+}
+
+extern "C" int ssd_profile_read(ssd_handle *h, int32_t cls, double *total_ms, int64_t *launches, double *flops, double *bytes)
+{
+    if (!h || cls < 0 || cls > 5) return fail(SSD_ERR_INVALID, "ssd_profile_read: bad arguments");
+    SSDCHK(drain_events(h));
+    if (total_ms) *total_ms = h->acc_ms[cls];
+    if (launches) *launches = h->acc_n[cls];
+    if (flops) *flops = h->acc_flops[cls];
+    if (bytes) *bytes = h->acc_bytes[cls];
+    return SSD_OK;
+}
+
+extern "C" int ssd_profile_reset(ssd_handle *h)
+{
+    if (!h) return fail(SSD_ERR_INVALID, "null handle");
+    SSDCHK(drain_events(h));
+    for (int i = 0; i < 6; ++i) { h->acc_ms[i] = h->acc_flops[i] = h->acc_bytes[i] = 0; h->acc_n[i] = 0; }
+    return SSD_OK;
+}
+
+// ----------------------------------------------------------------------------- stage entry points
+static int to_dev(DevPool &pool, const float *host, size_t n, float **out)
+{
+    if (!host) { *out = nullptr; return SSD_OK; }
+    std::vector<float> v(host, host + n);
+    return pool.upload(out, v);
+}
+
+extern "C" int ssd_conv2d(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t Cin, const float *w_host,
+                          int32_t k, int32_t Cout, int32_t stride, int32_t pad_beg, int32_t OH, int32_t OW,
+                          const float *bn_mean, const float *bn_sf, const float *bn_beta, const float *bias_host,
+                          const float *up_dev, int32_t act, float *out_dev, void *stream)
+{
+    if (!in_dev || !w_host || !out_dev || B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (k != 1 && k != 3) ||
+        stride < 1 || OH < 1 || OW < 1 || act < 0 || act > 2)
+        return fail(SSD_ERR_INVALID, "ssd_conv2d: bad arguments");
+    if ((bn_mean || bn_sf || bn_beta) && !(bn_mean && bn_sf && bn_beta))
+        return fail(SSD_ERR_INVALID, "ssd_conv2d: batch-norm vectors must be given together");
+    if ((OH - 1) * stride + k - pad_beg > H + k - 1 || (OW - 1) * stride + k - pad_beg > W + k - 1)
+        return fail(SSD_ERR_INVALID, "ssd_conv2d: output size inconsistent with input size");
+    if (up_dev && ((OH & 1) || (OW & 1))) return fail(SSD_ERR_INVALID, "ssd_conv2d: upsample-add needs even output size");
+    hipStream_t s = (hipStream_t)stream;
+    DevPool pool;
+    int rc = SSD_OK;
+    auto body = [&]() -> int {
+        const int CinP = round_up(Cin, 32), CoutP = round_up(Cout, 8);
+        ConvW cw;
+        std::vector<int> inmap = phys_map(Cin, CinP), outmap = phys_map(Cout, CoutP);
+        SSDCHK(pack_conv(pool, w_host, k, Cin, Cout, inmap, outmap, cw));
+        if (bn_mean) {
+            BnHost b;
+            for (int p : outmap) {
+                b.mean.push_back(p < 0 ? 0.f : bn_mean[p]);
+                b.sf.push_back(p < 0 ? 0.f : bn_sf[p]);
+                b.beta.push_back(p < 0 ? 0.f : bn_beta[p]);
+            }
+            SSDCHK(upload_bn(pool, b, cw));
+        }
+        if (bias_host) {
+            std::vector<float> b;
+            for (int p : outmap) b.push_back(p < 0 ? 0.f : bias_host[p]);
+            SSDCHK(pool.upload(&cw.bias, b));
+        }
+        float *tin, *tout, *tup = nullptr;
+        const long long rin = (long long)B * H * W, rout = (long long)B * OH * OW;
+        SSDCHK(pool.alloc((void **)&tin, (size_t)rin * CinP * 4));
+        SSDCHK(pool.alloc((void **)&tout, (size_t)rout * CoutP * 4));
+        HIPCHK(launch_permute_channels(in_dev, rin, Cin, CinP, 1, tin, s));
+        if (up_dev) {
+            SSDCHK(pool.alloc((void **)&tup, (size_t)(rout / 4) * CoutP * 4));
+            HIPCHK(launch_permute_channels(up_dev, rout / 4, Cout, CoutP, 1, tup, s));
+        }
+        Op op = make_conv_op(cw, tin, tout, nullptr, tup, B, stride, pad_beg, act, {dense_level(H, W, OH, OW, CoutP)}, true);
+        HIPCHK(op.run(s));
+        HIPCHK(launch_permute_channels(tout, rout, Cout, CoutP, 0, out_dev, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return SSD_OK;
+    };
+    rc = body();
+    (void)hipStreamSynchronize(s);
+    pool.free_all();
+    return rc;
+}
+
+extern "C" int ssd_depthwise3x3(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t C, const float *w_host,
+                                int32_t stride, int32_t pad_beg, int32_t OH, int32_t OW, const float *bn_mean,
+                                const float *bn_sf, const float *bn_beta, int32_t act, float *out_dev, void *stream)
+{
+    if (!in_dev || !w_host || !out_dev || B < 1 || C < 1 || stride < 1 || OH < 1 || OW < 1 || act < 0 || act > 2)
+        return fail(SSD_ERR_INVALID, "ssd_depthwise3x3: bad arguments");
+    if ((bn_mean || bn_sf || bn_beta) && !(bn_mean && bn_sf && bn_beta))
+        return fail(SSD_ERR_INVALID, "ssd_depthwise3x3: batch-norm vectors must be given together");
+    hipStream_t s = (hipStream_t)stream;
+    DevPool pool;
+    auto body = [&]() -> int {
+        const int Cp = round_up(C, 8);
+        std::vector<int> map = phys_map(C, Cp);
+        std::vector<float> wt((size_t)9 * Cp, 0.f), m, sf, be;
+        for (int t = 0; t < 9; ++t)
+            for (int p = 0; p < Cp; ++p)
+                if (map[p] >= 0) wt[(size_t)t * Cp + p] = w_host[(size_t)t * C + map[p]];
+        float *dw_, *dm = nullptr, *ds = nullptr, *db = nullptr, *tin, *tout;
+        SSDCHK(pool.upload(&dw_, wt));
+        if (bn_mean) {
+            for (int p : map) { m.push_back(p < 0 ? 0.f : bn_mean[p]); sf.push_back(p < 0 ? 0.f : bn_sf[p]); be.push_back(p < 0 ? 0.f : bn_beta[p]); }
+            SSDCHK(pool.upload(&dm, m)); SSDCHK(pool.upload(&ds, sf)); SSDCHK(pool.upload(&db, be));
+        }
+        const long long rin = (long long)B * H * W, rout = (long long)B * OH * OW;
+        SSDCHK(pool.alloc((void **)&tin, (size_t)rin * Cp * 4));
+        SSDCHK(pool.alloc((void **)&tout, (size_t)rout * Cp * 4));
+        HIPCHK(launch_permute_channels(in_dev, rin, C, Cp, 1, tin, s));
+        HIPCHK(launch_depthwise(tin, B, H, W, Cp, dw_, stride, pad_beg, OH, OW, dm, ds, db, act, tout, s));
+        HIPCHK(launch_permute_channels(tout, rout, C, Cp, 0, out_dev, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return SSD_OK;
+    };
+    int rc = body();
+    (void)hipStreamSynchronize(s);
+    pool.free_all();
+    return rc;
+}
+
+extern "C" int ssd_first_conv(const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, const float *w_host,
+                              int32_t Cout, const float *bn_mean, const float *bn_sf, const float *bn_beta, int32_t act,
+                              float *out_dev, void *stream)
+{
+    if (!images_dev || !w_host || !out_dev || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || Cout < 1 || act < 0 || act > 2)
+        return fail(SSD_ERR_INVALID, "ssd_first_conv: bad arguments (H, W must be even)");
+    if ((bn_mean || bn_sf || bn_beta) && !(bn_mean && bn_sf && bn_beta))
+        return fail(SSD_ERR_INVALID, "ssd_first_conv: batch-norm vectors must be given together");
+    hipStream_t s = (hipStream_t)stream;
+    DevPool pool;
+    auto body = [&]() -> int {
+        const int Cp = round_up(Cout, 8);
+        std::vector<int> map = phys_map(Cout, Cp);
+        std::vector<float> wt((size_t)27 * Cp, 0.f), m, sf, be;
+        for (int t = 0; t < 27; ++t)
+            for (int p = 0; p < Cp; ++p)
+                if (map[p] >= 0) wt[(size_t)t * Cp + p] = w_host[(size_t)t * Cout + map[p]];
+        float *dw_, *dm = nullptr, *ds = nullptr, *db = nullptr, *tout;
+        SSDCHK(pool.upload(&dw_, wt));
+        if (bn_mean) {
+            for (int p : map) { m.push_back(p < 0 ? 0.f : bn_mean[p]); sf.push_back(p < 0 ? 0.f : bn_sf[p]); be.push_back(p < 0 ? 0.f : bn_beta[p]); }
+            SSDCHK(pool.upload(&dm, m)); SSDCHK(pool.upload(&ds, sf)); SSDCHK(pool.upload(&db, be));
+        }
+        const long long rout = (long long)B * (H / 2) * (W / 2);
+        SSDCHK(pool.alloc((void **)&tout, (size_t)rout * Cp * 4));
+        HIPCHK(launch_first_conv(images_dev, B, H, W, dw_, Cp, dm, ds, db, act, tout, s));
+        HIPCHK(launch_permute_channels(tout, rout, Cout, Cp, 0, out_dev, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return SSD_OK;
+    };
+    int rc = body();
+    (void)hipStreamSynchronize(s);
+    pool.free_all();
+    return rc;
+}
+
+extern "C" int ssd_maxpool3x3s2(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t C, float *out_dev, void *stream)
+{
+    if (!in_dev || !out_dev || B < 1 || C < 1 || (C & 3) || (H & 1) || (W & 1) || H < 2 || W < 2)
+        return fail(SSD_ERR_INVALID, "ssd_maxpool3x3s2: bad arguments (C % 4 == 0, even H and W)");
+    HIPCHK(launch_maxpool(in_dev, B, H, W, C, out_dev, (hipStream_t)stream));
+    return SSD_OK;
+}
+
+extern "C" int ssd_concat_shuffle_split(const float *x_dev, const float *y_dev, int64_t rows, int32_t D, float *xo_dev,
+                                        float *yo_dev, void *stream)
+{
+    if (!x_dev || !y_dev || !xo_dev || !yo_dev || rows < 1 || D < 1) return fail(SSD_ERR_INVALID, "ssd_concat_shuffle_split: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DevPool pool;
+    auto body = [&]() -> int {
+        std::vector<int> tx(2 * D), ty(2 * D);
+        for (int j = 0; j < D; ++j) {
+            const int zx = j, zy = D + j;
+            tx[2 * j] = zx & 1; tx[2 * j + 1] = zx >> 1;
+            ty[2 * j] = zy & 1; ty[2 * j + 1] = zy >> 1;
+        }
+        int *dx, *dy;
+        SSDCHK(pool.upload(&dx, tx)); SSDCHK(pool.upload(&dy, ty));
+        HIPCHK(launch_gather_channels(x_dev, D, y_dev, D, rows, dx, D, xo_dev, s));
+        HIPCHK(launch_gather_channels(x_dev, D, y_dev, D, rows, dy, D, yo_dev, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return SSD_OK;
+    };
+    int rc = body();
+    (void)hipStreamSynchronize(s);
+    pool.free_all();
+    return rc;
+}
+
+extern "C" size_t ssd_postprocess_workspace_bytes(int32_t B, int32_t N, int32_t C, int32_t mp)
+{
+    if (B < 1 || N < 1 || C < 1 || mp < 1) return 0;
+    return post_workspace_bytes(B, N, C, mp);
+}
+
+extern "C" int ssd_postprocess(const float *logits_dev, const float *codes_dev, const float *anchors_dev, int32_t B,
+                               int32_t N, int32_t C, float score_threshold, float iou_threshold, int32_t mp,
+                               const float *box_scaler_host, float *boxes_dev, int32_t *labels_dev, float *scores_dev,
+                               int32_t *num_boxes_dev, void *workspace_dev, size_t workspace_bytes, void *stream)
+{
+    if (!logits_dev || !codes_dev || !anchors_dev || !boxes_dev || !labels_dev || !scores_dev || !num_boxes_dev ||
+        !workspace_dev || B < 1 || N < 1 || C < 1 || mp < 1)
+        return fail(SSD_ERR_INVALID, "ssd_postprocess: bad arguments");
+    if (workspace_bytes < post_workspace_bytes(B, N, C, mp)) return fail(SSD_ERR_INVALID, "ssd_postprocess: workspace too small");
+    PostArgs p;
+    memset(&p, 0, sizeof(p));
+    p.logits = logits_dev; p.codes = codes_dev; p.anchors = anchors_dev;
+    p.B = B; p.N = N; p.C = C;
+    p.score_thr = score_threshold; p.iou_thr = iou_threshold;
+    p.logit_lo = conservative_logit_bound(score_threshold);
+    p.max_per_class = mp;
+    for (int k = 0; k < 4; ++k) p.box_scaler[k] = box_scaler_host ? box_scaler_host[k] : 1.0f;
+    p.boxes = boxes_dev; p.labels = labels_dev; p.scores = scores_dev; p.num = num_boxes_dev;
+    post_carve(p, workspace_dev);
+    HIPCHK(launch_postprocess(p, (hipStream_t)stream));
+    return SSD_OK;
+}

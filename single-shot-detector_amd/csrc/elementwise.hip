@@ -1,0 +1,252 @@
+// HBM-bound kernels of the backbone: first 3x3 convolution (uint8 in, preprocessing
+// fused), 3x3 depthwise convolution + batch norm + activation, 3x3/2 max pool, the
+// ShuffleNet concat-shuffle-split, and the logical<->physical channel permutation used
+// by the stage entry points.  NHWC, 16 B (4 channels) per lane, channels innermost so a
+// wave touches whole 128-B lines.  All fused multiply-adds are explicit fmaf chains in
+// (ky,kx[,ci]) order; everything else is separately rounded (-ffp-contract=off).
+#include "ssd_internal.h"
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_apply(float v, int act)
+{
+    if (act >= 1) v = v > 0.0f ? v : 0.0f;
+    if (act == 2) v = v < 6.0f ? v : 6.0f;
+    return v;
+}
+
+__device__ __forceinline__ v4f bn_act4(v4f v, const float *mean, const float *sf, const float *beta, int c, int act)
+{
+    if (mean) {
+        const v4f m = *(const v4f *)(mean + c), s = *(const v4f *)(sf + c), b = *(const v4f *)(beta + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = (v[i] - m[i]) * s[i];
+            v[i] = t + b[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = act_apply(v[i], act);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// K1: images uint8 [B,H,W,3] -> float(x)/255 -> 2x-1 -> conv 3x3 stride 2 'SAME'
+// (even H,W: taps at rows 2oy..2oy+2, zero beyond the bottom/right edge) -> BN -> act.
+// One thread = one output pixel x 4 output channels; weights [27][Cout] staged in LDS.
+__global__ __launch_bounds__(256) void first_conv_kernel(const uint8_t *__restrict__ img, int B, int H, int W,
+                                                          const float *__restrict__ w, int Cout,
+                                                          const float *mean, const float *sf, const float *beta,
+                                                          int act, float *__restrict__ out)
+{
+    extern __shared__ float wl[];   // 27*Cout
+    for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) wl[i] = w[i];
+    __syncthreads();
+    const int OH = H >> 1, OW = W >> 1, C4 = Cout >> 2;
+    const long long total = (long long)B * OH * OW * C4;
+    const float inv255 = (float)(1.0 / 255.0);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        long long pix = idx / C4;
+        const int ox = (int)(pix % OW);
+        pix /= OW;
+        const int oy = (int)(pix % OH);
+        const int b = (int)(pix / OH);
+        v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox + kx;
+                const bool ok = iy < H && ix < W;
+                const uint8_t *p = img + (((long long)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * 3;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    float x = (float)p[ci] * inv255;
+                    x = 2.0f * x - 1.0f;
+                    if (!ok) x = 0.0f;
+                    const v4f wv = *(const v4f *)(wl + ((ky * 3 + kx) * 3 + ci) * Cout + c4 * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(x, wv[i], acc[i]);
+                }
+            }
+        }
+        acc = bn_act4(acc, mean, sf, beta, c4 * 4, act);
+        *(v4f *)(out + idx * 4) = acc;
+    }
+}
+
+hipError_t launch_first_conv(const uint8_t *img, int B, int H, int W, const float *w, int Cout, const float *mean,
+                             const float *sf, const float *beta, int act, float *out, hipStream_t s)
+{
+    if (Cout % 4 || (H & 1) || (W & 1) || 27 * Cout * 4 > 65536) return hipErrorInvalidValue;
+    const long long total = (long long)B * (H / 2) * (W / 2) * (Cout / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(first_conv_kernel, dim3((unsigned)blocks), dim3(256), 27 * Cout * sizeof(float), s, img, B, H, W,
+                       w, Cout, mean, sf, beta, act, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// K2: depthwise 3x3, stride 1/2, zero padding `pad` on top/left (TF 'SAME': 1 for stride 1,
+// 0 for stride 2 on even sizes), + BN + act.  One thread = one output pixel x 4 channels.
+__global__ __launch_bounds__(256) void depthwise_kernel(const float *__restrict__ in, int B, int H, int W, int C,
+                                                         const float *__restrict__ w, int stride, int pad, int OH,
+                                                         int OW, const float *mean, const float *sf,
+                                                         const float *beta, int act, float *__restrict__ out)
+{
+    const int C4 = C >> 2;
+    const long long total = (long long)B * OH * OW * C4;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4) * 4;
+        long long pix = idx / C4;
+        const int ox = (int)(pix % OW);
+        pix /= OW;
+        const int oy = (int)(pix % OH);
+        const int b = (int)(pix / OH);
+        v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * stride + ky - pad;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * stride + kx - pad;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    const v4f x = *(const v4f *)(in + (((long long)b * H + iy) * W + ix) * C + c);
+                    const v4f wv = *(const v4f *)(w + (ky * 3 + kx) * C + c);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(x[i], wv[i], acc[i]);
+                }
+            }
+        }
+        acc = bn_act4(acc, mean, sf, beta, c, act);
+        *(v4f *)(out + idx * 4) = acc;
+    }
+}
+
+hipError_t launch_depthwise(const float *in, int B, int H, int W, int C, const float *w, int stride, int pad, int OH,
+                            int OW, const float *mean, const float *sf, const float *beta, int act, float *out,
+                            hipStream_t s)
+{
+    if (C % 4) return hipErrorInvalidValue;
+    const long long total = (long long)B * OH * OW * (C / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(depthwise_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, B, H, W, C, w, stride, pad, OH, OW,
+                       mean, sf, beta, act, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// K7: max pool 3x3 stride 2 'SAME' on even sizes: window rows 2oy..2oy+2, cells beyond
+// the edge do not take part.
+__global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ in, int B, int H, int W, int C,
+                                                       float *__restrict__ out)
+{
+    const int OH = H >> 1, OW = W >> 1, C4 = C >> 2;
+    const long long total = (long long)B * OH * OW * C4;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4) * 4;
+        long long pix = idx / C4;
+        const int ox = (int)(pix % OW);
+        pix /= OW;
+        const int oy = (int)(pix % OH);
+        const int b = (int)(pix / OH);
+        v4f m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox + kx;
+                if (iy < H && ix < W) {
+                    const v4f x = *(const v4f *)(in + (((long long)b * H + iy) * W + ix) * C + c);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) m[i] = x[i] > m[i] ? x[i] : m[i];
+                }
+            }
+        }
+        *(v4f *)(out + idx * 4) = m;
+    }
+}
+
+hipError_t launch_maxpool(const float *in, int B, int H, int W, int C, float *out, hipStream_t s)
+{
+    if (C % 4 || (H & 1) || (W & 1)) return hipErrorInvalidValue;
+    const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, B, H, W, C, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int phys_of_logical(int l) { const int r = l & 7; return (l & ~7) + ((r & 1) ? 4 + (r >> 1) : (r >> 1)); }
+__device__ __forceinline__ int logical_of_phys(int p) { const int r = p & 7; return (p & ~7) + (r < 4 ? 2 * r : 2 * (r - 4) + 1); }
+
+// K8: table-driven channel gather: out[r][j] = (tab[2j]==0 ? x : y)[r][tab[2j+1]], or 0 when
+// tab[2j] < 0.  Serves concat_shuffle_split (shufflenet_v2.py:94-115: z[2d+g] = (g?y:x)[d],
+// new x = z[:D], new y = z[D:]) and the stage-output concat (:89) in any channel order.
+__global__ __launch_bounds__(256) void gather_kernel(const float *__restrict__ x, int xs, const float *__restrict__ y,
+                                                      int ys, long long rows, const int *__restrict__ tab, int Cout,
+                                                      float *__restrict__ out)
+{
+    const long long total = rows * Cout;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % Cout);
+        const long long r = idx / Cout;
+        const int src = tab[2 * j], k = tab[2 * j + 1];
+        float v = 0.0f;
+        if (src == 0) v = x[r * xs + k];
+        else if (src == 1) v = y[r * ys + k];
+        out[idx] = v;
+    }
+}
+
+hipError_t launch_gather_channels(const float *x, int xs, const float *y, int ys, long long rows, const int *tab,
+                                  int Cout, float *out, hipStream_t s)
+{
+    const long long total = rows * Cout;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, xs, y, ys, rows, tab, Cout, out);
+    return hipGetLastError();
+}
+
+// to_phys = 1: in [rows][C] logical -> out [rows][Cpad] physical (pad channels zero)
+// to_phys = 0: in [rows][Cpad] physical -> out [rows][C] logical
+__global__ __launch_bounds__(256) void permute_kernel(const float *__restrict__ in, long long rows, int C, int Cpad,
+                                                       int to_phys, float *__restrict__ out)
+{
+    const int Cw = to_phys ? Cpad : C;
+    const long long total = rows * Cw;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % Cw);
+        const long long r = idx / Cw;
+        if (to_phys) {
+            const int l = logical_of_phys(j);
+            out[idx] = l < C ? in[r * C + l] : 0.0f;
+        } else {
+            out[idx] = in[r * Cpad + phys_of_logical(j)];
+        }
+    }
+}
+
+hipError_t launch_permute_channels(const float *in, long long rows, int C, int Cpad, int to_phys, float *out,
+                                   hipStream_t s)
+{
+    const long long total = rows * (to_phys ? Cpad : C);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(permute_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, rows, C, Cpad, to_phys, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,92 @@
+// Internal declarations shared by the HIP translation units of libssd_hip.so.
+// gfx950 (MI355X) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---------------------------------------------------------------------------------------
+// Physical channel order of every fp32 activation in HBM: NHWC with the channels of each
+// group of 8 stored as logical [0,2,4,6,1,3,5,7].  The MFMA kernel reads 16 B (4 physical
+// channels) per lane; lanes 0-31 take physical 0..3, lanes 32-63 physical 4..7 of an
+// octet, and v_mfma_f32_32x32x2_f32 #j multiplies physical j (k=0) then physical 4+j
+// (k=1): with this storage order the accumulation chain runs over logical channels
+// 0,1,2,...,7 -- the order the oracle (and an HWIO kernel) defines.
+// phys -> logical:  p<4 ? 2p : 2(p-4)+1 ;  logical -> phys:  l even ? l/2 : 4+(l-1)/2
+// ---------------------------------------------------------------------------------------
+static inline int ssd_phys_of_logical(int l) { int o = l & ~7, r = l & 7; return o + ((r & 1) ? 4 + (r >> 1) : (r >> 1)); }
+static inline int ssd_logical_of_phys(int p) { int o = p & ~7, r = p & 7; return o + (r < 4 ? 2 * r : 2 * (r - 4) + 1); }
+
+#define SSD_MAX_LEVELS 5
+
+struct IgemmLevel {
+    int H, W;              // input spatial size
+    int OH, OW;            // output spatial size
+    int M;                 // rows of this level = B*OH*OW
+    int tile_begin;        // first M-tile of this level
+    int param_off;         // float offset into mean/sf/beta/bias for this level
+    int out_rstride;       // floats between consecutive output positions
+    long long in_off;      // float offset of the level's input tensor [B,H,W,Cin]
+    long long out_off;     // float offset of output (image 0, position 0)
+    long long out_bstride; // floats between images in the output
+    long long res_off;     // float offset of the coarse tensor [B,OH/2,OW/2,Cout] (upsample-add)
+};
+
+struct IgemmArgs {
+    const float *in;
+    const float *wt;       // [taps][CoutPad][Cin] physical-k order (transposed weights)
+    float *out;
+    float *out2;           // optional second output = relu(raw accumulator) (fpn p6 -> p7 input)
+    const float *mean, *sf, *beta;  // batch norm (nullable as a group)
+    const float *bias;     // nullable
+    const float *res;      // nullable: coarser map added after nearest x2 upsampling
+    int B, Cin, Cout, CoutPad;
+    int taps;              // 1 or 9
+    int stride, pad;
+    int act;
+    int nlevels;
+    int n_tiles_n;
+    int dense_out;         // 1: out_bstride == OH*OW*out_rstride for every level
+    IgemmLevel lv[SSD_MAX_LEVELS];
+};
+
+// tile variants of the implicit-GEMM kernel: BM x BN
+enum IgemmTile { IGEMM_128x128 = 0, IGEMM_128x64 = 1, IGEMM_128x32 = 2 };
+int igemm_tile_bm(int tile);
+int igemm_tile_bn(int tile);
+hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s);
+
+// elementwise / memory-bound kernels -----------------------------------------------------
+hipError_t launch_first_conv(const uint8_t *img, int B, int H, int W, const float *w /*[27][Cout] phys-n*/,
+                             int Cout, const float *mean, const float *sf, const float *beta, int act,
+                             float *out, hipStream_t s);
+hipError_t launch_depthwise(const float *in, int B, int H, int W, int C, const float *w /*[9][C]*/,
+                            int stride, int pad, int OH, int OW, const float *mean, const float *sf,
+                            const float *beta, int act, float *out, hipStream_t s);
+hipError_t launch_maxpool(const float *in, int B, int H, int W, int C, float *out, hipStream_t s);
+// out[r][j] = (tab[2j]==0 ? x : y)[r][tab[2j+1]] (0 if tab[2j] < 0); tab is device memory
+hipError_t launch_gather_channels(const float *x, int xs, const float *y, int ys, long long rows, const int *tab,
+                                  int Cout, float *out, hipStream_t s);
+// channel permutation logical<->physical (+ zero padding to Cpad) for the stage entry points
+hipError_t launch_permute_channels(const float *in, long long rows, int C, int Cpad, int to_phys, float *out,
+                                   hipStream_t s);
+
+// post-processing ------------------------------------------------------------------------
+struct PostArgs {
+    const float *logits, *codes, *anchors;
+    int B, N, C;
+    float score_thr, iou_thr;
+    float logit_lo;        // conservative logit bound below which sigmoid(x) <= score_thr
+    int max_per_class;
+    float box_scaler[4];
+    float *boxes; int32_t *labels; float *scores; int32_t *num;
+    // workspace carve-up
+    unsigned long long *keys;   // [B][C][N]
+    int *counts;                // [B][C]
+    float *dec;                 // [B][N][4] decoded+clipped boxes of candidate anchors
+    float *cls_boxes;           // [B][C][max][4]
+    float *cls_scores;          // [B][C][max]
+    int *cls_counts;            // [B][C]
+};
+size_t post_workspace_bytes(int B, int N, int C, int max_per_class);
+void post_carve(PostArgs &p, void *ws);
+hipError_t launch_postprocess(const PostArgs &p, hipStream_t s);

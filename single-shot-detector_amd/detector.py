@@ -1,0 +1,80 @@
+"""Drop-in for the reference's inference/detector.py:5-60.
+
+    detector = Detector(model_path)                     # weights .npz (+ config)
+    boxes, labels, scores = detector(image_uint8_HW3, score_threshold=0.1)
+
+Same constructor keywords, same return order (boxes, labels, scores), boxes normalised
+[ymin, xmin, ymax, xmax].  `model_path` is this build's weight container (a .npz keyed by
+the reference's TF variable names, see variables.py) instead of a frozen .pb; the JSON
+config is the reference's own file (config_mobilenet.json / config_shufflenet.json).
+"""
+import json
+import os
+
+import numpy as np
+
+from .config import load_config
+from .ssd import Engine, _torch
+from .variables import load_weights
+
+
+class Detector:
+    def __init__(self, model_path, gpu_memory_fraction=0.25, visible_device_list='0',
+                 config=None):
+        """
+        Arguments:
+            model_path: path to the weight file (.npz), or a dict {variable name: ndarray}.
+            gpu_memory_fraction: accepted for compatibility and ignored (the library
+                allocates exactly the arena the network needs).
+            visible_device_list: a string like the reference's; the first entry is the HIP
+                device index.
+            config: path to the reference's JSON config or a dict; default: `config.json`
+                next to `model_path` (the reference reads 'config.json', create_pb.py:18).
+        """
+        if isinstance(model_path, dict):
+            weights = model_path
+            if config is None:
+                raise ValueError("config is required when weights are passed as a dict")
+        else:
+            if not os.path.exists(model_path):
+                raise FileNotFoundError(model_path)       # tf.gfile.GFile would raise too
+            weights = load_weights(model_path)
+            if config is None:
+                config = os.path.join(os.path.dirname(os.path.abspath(model_path)), "config.json")
+        self.params = load_config(config)
+        device = int(str(visible_device_list).split(",")[0])
+        self.engine = Engine(self.params, weights, device=device)
+        self.device = device
+
+    def detect_batch(self, images):
+        """images: uint8 ndarray [B,H,W,3] (or CUDA tensor) -> the graph outputs
+        (boxes [B,T,4], labels [B,T], scores [B,T], num_boxes [B]) as numpy arrays
+        (model.py:70-73)."""
+        torch = _torch()
+        if isinstance(images, np.ndarray):
+            if images.dtype != np.uint8 or images.ndim != 4 or images.shape[3] != 3:
+                raise ValueError("images must be a uint8 array of shape [B, height, width, 3]")
+            images = torch.from_numpy(np.ascontiguousarray(images)).to("cuda:%d" % self.device)
+        boxes, labels, scores, num = self.engine.forward(images)
+        return boxes.cpu().numpy(), labels.cpu().numpy(), scores.cpu().numpy(), num.cpu().numpy()
+
+    def __call__(self, image, score_threshold=0.1):
+        """
+        Arguments:
+            image: a numpy uint8 array with shape [height, width, 3] (RGB).
+            score_threshold: a float number.
+        Returns:
+            boxes: a float numpy array of shape [N, 4] (ymin, xmin, ymax, xmax!).
+            labels: an int numpy array of shape [N].
+            scores: a float numpy array of shape [N].
+        """
+        image = np.asarray(image)
+        if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
+            raise ValueError("image must be a uint8 array of shape [height, width, 3]")
+        boxes, labels, scores, n = self.detect_batch(np.expand_dims(image, 0))
+        n = n[0]  # inference/detector.py:54-58
+        to_keep = scores[0][:n] > score_threshold
+        boxes = boxes[0][:n][to_keep]
+        labels = labels[0][:n][to_keep]
+        scores = scores[0][:n][to_keep]
+        return boxes, labels, scores

@@ -1,0 +1,326 @@
+"""Host-side mirror of detector/ssd.py, detector/anchor_generator.py and
+detector/utils/nms.py on top of libssd_hip.so.  Tensors are torch CUDA (= HIP) tensors;
+torch only provides the memory and the stream.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import SsdConfig, check, lib
+
+ACT = {None: 0, "none": 0, "relu": 1, "relu6": 2}
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("single-shot-detector_amd needs an AMD GPU (HIP device): there is "
+                           "no CPU path")
+    return torch
+
+
+def _stream(torch):
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _fp(a):
+    """host float32 array (or None) -> ctypes float pointer (keeps `a` alive via return)."""
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _check_dev(torch, t, dtype, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise TypeError("%s must be a contiguous CUDA tensor of dtype %s" % (name, dtype))
+
+
+# ----------------------------------------------------------------------------- stage ops
+def out_size(n, k, stride, mode):
+    """'SAME' (TF) or 'EXPLICIT' (conv2d_same stride>1, layer_utils.py:26-43)."""
+    if mode == "SAME":
+        o = -(-n // stride)
+        return o, max((o - 1) * stride + k - n, 0) // 2
+    pad_beg = (k - 1) // 2
+    return (n + (k - 1) - k) // stride + 1, pad_beg
+
+
+def conv2d(x, w, stride=1, mode="SAME", bn=None, bias=None, up=None, act=None):
+    """Dense 1x1 / 3x3 convolution on the MFMA kernel (ssd_conv2d).
+    x [B,H,W,Cin] cuda f32; w HWIO numpy; bn = (mean, sf, beta) numpy; up = coarser map."""
+    torch = _torch()
+    _check_dev(torch, x, torch.float32, "x")
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    B, H, W, Cin = x.shape
+    k, k2, cin2, Cout = w.shape
+    if k != k2 or cin2 != Cin:
+        raise ValueError("kernel shape %s does not match input channels %d" % (w.shape, Cin))
+    OH, pb = out_size(H, k, stride, mode)
+    OW, _ = out_size(W, k, stride, mode)
+    out = torch.empty((B, OH, OW, Cout), dtype=torch.float32, device=x.device)
+    keep = [_fp(v) for v in (bn if bn is not None else (None, None, None))]
+    kb = _fp(bias)
+    if up is not None:
+        _check_dev(torch, up, torch.float32, "up")
+        if tuple(up.shape) != (B, OH // 2, OW // 2, Cout):
+            raise ValueError("up must have shape [B, OH/2, OW/2, Cout]")
+    check(lib().ssd_conv2d(_ptr(x), B, H, W, Cin, w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                           k, Cout, stride, pb, OH, OW, keep[0][1], keep[1][1], keep[2][1], kb[1],
+                           _ptr(up) if up is not None else None, ACT[act], _ptr(out),
+                           _stream(torch)))
+    return out
+
+
+def depthwise3x3(x, w, stride=1, bn=None, act=None):
+    torch = _torch()
+    _check_dev(torch, x, torch.float32, "x")
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    B, H, W, C = x.shape
+    if w.shape != (3, 3, C, 1):
+        raise ValueError("depthwise weights must be [3,3,C,1]")
+    OH, pb = out_size(H, 3, stride, "SAME")
+    OW, _ = out_size(W, 3, stride, "SAME")
+    out = torch.empty((B, OH, OW, C), dtype=torch.float32, device=x.device)
+    keep = [_fp(v) for v in (bn if bn is not None else (None, None, None))]
+    check(lib().ssd_depthwise3x3(_ptr(x), B, H, W, C, w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                 stride, pb, OH, OW, keep[0][1], keep[1][1], keep[2][1], ACT[act],
+                                 _ptr(out), _stream(torch)))
+    return out
+
+
+def first_conv(images, w, bn=None, act=None):
+    torch = _torch()
+    _check_dev(torch, images, torch.uint8, "images")
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    B, H, W, three = images.shape
+    if three != 3 or w.shape[:3] != (3, 3, 3):
+        raise ValueError("images must be [B,H,W,3] and weights [3,3,3,Cout]")
+    Cout = w.shape[3]
+    out = torch.empty((B, H // 2, W // 2, Cout), dtype=torch.float32, device=images.device)
+    keep = [_fp(v) for v in (bn if bn is not None else (None, None, None))]
+    check(lib().ssd_first_conv(_ptr(images), B, H, W, w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                               Cout, keep[0][1], keep[1][1], keep[2][1], ACT[act], _ptr(out),
+                               _stream(torch)))
+    return out
+
+
+def maxpool3x3s2(x):
+    torch = _torch()
+    _check_dev(torch, x, torch.float32, "x")
+    B, H, W, C = x.shape
+    out = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+    check(lib().ssd_maxpool3x3s2(_ptr(x), B, H, W, C, _ptr(out), _stream(torch)))
+    return out
+
+
+def concat_shuffle_split(x, y):
+    torch = _torch()
+    _check_dev(torch, x, torch.float32, "x")
+    _check_dev(torch, y, torch.float32, "y")
+    if x.shape != y.shape:
+        raise ValueError("x and y must have the same shape")
+    D = x.shape[-1]
+    xo, yo = torch.empty_like(x), torch.empty_like(y)
+    check(lib().ssd_concat_shuffle_split(_ptr(x), _ptr(y), x.numel() // D, D, _ptr(xo), _ptr(yo),
+                                         _stream(torch)))
+    return xo, yo
+
+
+class AnchorGenerator:
+    """detector/anchor_generator.py:12-120 with the hyper-parameters model.py:37-42 fixes
+    (the C ABI hard-codes exactly those; other values raise)."""
+
+    def __init__(self, strides=[8, 16, 32, 64, 128], scales=[32, 64, 128, 256, 512],
+                 scale_multipliers=[1.0, 1.4142], aspect_ratios=[1.0, 2.0, 0.5]):
+        if (list(strides), list(scales), list(scale_multipliers), list(aspect_ratios)) != \
+                ([8, 16, 32, 64, 128], [32, 64, 128, 256, 512], [1.0, 1.4142], [1.0, 2.0, 0.5]):
+            raise NotImplementedError("only the anchor hyper-parameters of model.py:37-42")
+        self.strides, self.scales = list(strides), list(scales)
+        self.scale_multipliers, self.aspect_ratios = list(scale_multipliers), list(aspect_ratios)
+        self.num_anchors_per_location = len(aspect_ratios) * len(scale_multipliers)
+
+    def __call__(self, image_height, image_width):
+        """-> float32 ndarray [num_anchors, 4], normalised ymin,xmin,ymax,xmax, not clipped."""
+        n = lib().ssd_num_anchors(int(image_height), int(image_width))
+        out = np.empty((n, 4), np.float32)
+        check(lib().ssd_anchors(int(image_height), int(image_width),
+                                out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        self.num_anchors_per_feature_map = [
+            -(-int(image_height) // s) * -(-int(image_width) // s) * self.num_anchors_per_location
+            for s in self.strides]
+        return out
+
+
+def batch_multiclass_non_max_suppression(encoded_boxes, anchors, logits, score_threshold,
+                                         iou_threshold, max_boxes_per_class, box_scaler=None):
+    """detector/utils/nms.py:48-102 on the GPU (ssd_postprocess).
+
+    encoded_boxes [B,N,4], anchors [N,4], logits [B,N,C] CUDA tensors.  Unlike the
+    reference, which is handed tf.sigmoid(class_predictions), this takes the LOGITS: the
+    sigmoid of ssd.py:60 is fused into the scan kernel.
+    Returns boxes [B,C*m,4], scores [B,C*m], classes [B,C*m] int32, num_detections [B] int32
+    (the reference's return order, nms.py:102)."""
+    torch = _torch()
+    for t, n in ((encoded_boxes, "encoded_boxes"), (anchors, "anchors"), (logits, "logits")):
+        _check_dev(torch, t, torch.float32, n)
+    B, N, C = logits.shape
+    if tuple(encoded_boxes.shape) != (B, N, 4) or tuple(anchors.shape) != (N, 4):
+        raise ValueError("shape mismatch between encoded_boxes, anchors and logits")
+    T = C * int(max_boxes_per_class)
+    dev = logits.device
+    boxes = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, T), dtype=torch.float32, device=dev)
+    classes = torch.empty((B, T), dtype=torch.int32, device=dev)
+    num = torch.empty((B,), dtype=torch.int32, device=dev)
+    nbytes = lib().ssd_postprocess_workspace_bytes(B, N, C, int(max_boxes_per_class))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    bs = _fp(box_scaler)
+    check(lib().ssd_postprocess(_ptr(logits), _ptr(encoded_boxes), _ptr(anchors), B, N, C,
+                                float(score_threshold), float(iou_threshold),
+                                int(max_boxes_per_class), bs[1], _ptr(boxes), _ptr(classes),
+                                _ptr(scores), _ptr(num), _ptr(ws), nbytes, _stream(torch)))
+    return boxes, scores, classes, num
+
+
+# ----------------------------------------------------------------------------- whole graph
+class Engine:
+    """Owns one ssd_handle: weights + workspace on one GPU.  `forward` is the frozen
+    graph's sess.run (inference/detector.py:51-52) for a batch."""
+
+    def __init__(self, params, weights, device=0):
+        torch = _torch()
+        self.params = dict(params)
+        self.device = int(device)
+        cfg = SsdConfig(0 if params["backbone"] == "mobilenet" else 1,
+                        float(params["depth_multiplier"]), int(params["num_classes"]),
+                        float(params["score_threshold"]), float(params["iou_threshold"]),
+                        int(params["max_boxes_per_class"]), int(params["min_dimension"]),
+                        self.device)
+        self._h = ctypes.c_void_p()
+        torch.cuda.set_device(self.device)
+        check(lib().ssd_create(ctypes.byref(cfg), ctypes.byref(self._h)))
+        try:
+            for name, arr in weights.items():
+                a = np.ascontiguousarray(arr, dtype=np.float32)
+                shape = (ctypes.c_int64 * a.ndim)(*a.shape)
+                check(lib().ssd_load_weight(self._h, name.encode(),
+                                            a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                            shape, a.ndim))
+            check(lib().ssd_finalize(self._h))
+        except Exception:
+            lib().ssd_destroy(self._h)
+            self._h = None
+            raise
+        self.T = int(params["num_classes"]) * int(params["max_boxes_per_class"])
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ssd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, images, out=None):
+        """images: uint8 CUDA tensor [B,H,W,3] -> (boxes [B,T,4], labels [B,T] i32,
+        scores [B,T], num_boxes [B] i32) CUDA tensors; asynchronous on the current stream."""
+        torch = _torch()
+        _check_dev(torch, images, torch.uint8, "images")
+        if images.dim() != 4 or images.shape[3] != 3:
+            raise ValueError("images must have shape [B,H,W,3]")
+        B, H, W, _ = images.shape
+        dev = images.device
+        if out is None:
+            out = (torch.empty((B, self.T, 4), dtype=torch.float32, device=dev),
+                   torch.empty((B, self.T), dtype=torch.int32, device=dev),
+                   torch.empty((B, self.T), dtype=torch.float32, device=dev),
+                   torch.empty((B,), dtype=torch.int32, device=dev))
+        boxes, labels, scores, num = out
+        check(lib().ssd_forward(self._h, _ptr(images), B, H, W, _ptr(boxes), _ptr(labels),
+                                _ptr(scores), _ptr(num), _stream(torch)))
+        return boxes, labels, scores, num
+
+    def get_tensor(self, name):
+        """Retained intermediate of the last forward as a numpy array [B,H,W,C]."""
+        dims = (ctypes.c_int32 * 4)()
+        cap = 1 << 20
+        while True:
+            buf = np.empty((cap,), np.float32)
+            rc = lib().ssd_get_tensor(self._h, name.encode(),
+                                      buf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), cap, dims)
+            if rc != 0 and b"too small" in (lib().ssd_last_error() or b"") and cap < (1 << 34):
+                cap *= 8
+                continue
+            check(rc)
+            n = dims[0] * dims[1] * dims[2] * dims[3]
+            return buf[:n].reshape(dims[0], dims[1], dims[2], dims[3]).copy()
+
+    def get_tensor_dev(self, name, shape):
+        torch = _torch()
+        out = torch.empty(tuple(shape), dtype=torch.float32, device="cuda:%d" % self.device)
+        dims = (ctypes.c_int32 * 4)()
+        check(lib().ssd_get_tensor_dev(self._h, name.encode(), _ptr(out), out.numel(), dims,
+                                       _stream(torch)))
+        return out
+
+    # profiling (bench.py roofline leg)
+    def profile_enable(self, on=True):
+        check(lib().ssd_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(lib().ssd_profile_reset(self._h))
+
+    def profile_read(self):
+        names = ["conv3x3_mfma", "pointwise_mfma", "depthwise", "first_conv", "postprocess", "other"]
+        out = {}
+        for i, n in enumerate(names):
+            ms, cnt = ctypes.c_double(), ctypes.c_int64()
+            fl, by = ctypes.c_double(), ctypes.c_double()
+            check(lib().ssd_profile_read(self._h, i, ctypes.byref(ms), ctypes.byref(cnt),
+                                         ctypes.byref(fl), ctypes.byref(by)))
+            out[n] = {"ms": ms.value, "launches": cnt.value, "flops": fl.value, "bytes": by.value}
+        return out
+
+
+class SSD:
+    """Mirror of detector/ssd.py:9-69 (inference part).  The reference wires TF graph
+    builders in __init__; here the network has already been assembled inside `engine`, so
+    __init__ runs it on `images` (uint8 [B,H,W,3] CUDA; the /255 of create_pb.py:47 is
+    fused into the first kernel) and exposes the same attributes:
+      .anchors            [num_anchors, 4]                       (ssd.py:31)
+      .raw_predictions    {'encoded_boxes', 'class_predictions'} (ssd.py:37-40)
+      .get_predictions(score_threshold, iou_threshold, max_boxes_per_class)  (ssd.py:42-69)
+    """
+
+    def __init__(self, images, engine, num_classes=None):
+        torch = _torch()
+        self.engine = engine
+        self.num_classes = engine.params["num_classes"] if num_classes is None else num_classes
+        if self.num_classes != engine.params["num_classes"]:
+            raise ValueError("num_classes differs from the engine's configuration")
+        B, H, W, _ = images.shape
+        self._default = engine.forward(images)
+        gen = AnchorGenerator()
+        self.anchors = torch.from_numpy(gen(H, W)).to(images.device)
+        self.num_anchors_per_feature_map = gen.num_anchors_per_feature_map
+        N = self.anchors.shape[0]
+        self.raw_predictions = {
+            "encoded_boxes": engine.get_tensor_dev("encoded_boxes", (B, N, 4)),
+            "class_predictions": engine.get_tensor_dev("class_predictions", (B, N, self.num_classes)),
+        }
+
+    def get_predictions(self, score_threshold=0.05, iou_threshold=0.5, max_boxes_per_class=20):
+        boxes, scores, classes, num = batch_multiclass_non_max_suppression(
+            self.raw_predictions["encoded_boxes"], self.anchors,
+            self.raw_predictions["class_predictions"], score_threshold=score_threshold,
+            iou_threshold=iou_threshold, max_boxes_per_class=max_boxes_per_class)
+        return {"boxes": boxes, "labels": classes, "scores": scores, "num_boxes": num}

@@ -1,0 +1,70 @@
+"""N > 1 path on CPU: world_size-2 gloo all-gather of detection records."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _records(rank, B, T):
+    g = torch.Generator().manual_seed(100 + rank)
+    boxes = torch.rand((B, T, 4), generator=g)
+    scores = torch.rand((B, T), generator=g)
+    labels = torch.randint(0, 80, (B, T), generator=g, dtype=torch.int32)
+    num = torch.randint(0, T, (B,), generator=g, dtype=torch.int32)
+    return boxes, labels, scores, num
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import ssd_amd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, T = 3, 50
+    mine = _records(rank, B, T)
+    out = ssd_amd.all_gather_detections(*mine)
+    ok = True
+    for r in range(world):
+        exp = _records(r, B, T)
+        for a, b in zip(out, exp):
+            ok &= bool(torch.equal(a[r * B:(r + 1) * B], b))
+    ok &= out[0].shape == (world * B, T, 4) and out[3].dtype == torch.int32
+    lo, hi = ssd_amd.shard_range(7, rank, world)
+    q.put((rank, ok, lo, hi))
+    dist.destroy_process_group()
+
+
+def test_all_gather_detections_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1]
+    assert (res[0][2], res[0][3]) == (0, 4) and (res[1][2], res[1][3]) == (4, 7)
+
+
+def test_pack_unpack_roundtrip_and_record_size():
+    sys.path.insert(0, ROOT)
+    import ssd_amd
+    from importlib import import_module
+    d = import_module("ssd_amd.distributed")
+    b, l, s, n = _records(0, 4, 2000)
+    rec = d.pack_detections(b, l, s, n)
+    assert rec.shape == (4, 12001) and rec.element_size() * rec.shape[1] == 48004
+    b2, l2, s2, n2 = d.unpack_detections(rec)
+    assert torch.equal(b, b2) and torch.equal(l, l2) and torch.equal(s, s2) and torch.equal(n, n2)
+    # world size 1 / uninitialised: identity
+    out = ssd_amd.all_gather_detections(b, l, s, n)
+    assert out[0] is b
+    assert [ssd_amd.shard_range(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]

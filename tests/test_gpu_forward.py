@@ -1,0 +1,164 @@
+"""-m gpu: the whole drop-in path (ssd_forward behind Detector / Engine / SSD) against the
+CPU oracle and against the committed golden fixture."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+TOL = 1e-4
+
+
+def compare_outputs(got, ref, what):
+    gb, gl, gs, gn = got
+    assert np.array_equal(gn, ref["num_boxes"]), (what, gn, ref["num_boxes"])
+    assert np.array_equal(gl, ref["labels"]), what + ": labels"
+    assert np.abs(gs - ref["scores"]).max() <= TOL and np.abs(gb - ref["boxes"]).max() <= TOL, what
+    print(what, "num", gn.tolist(), "scores bit-equal", float((gs == ref["scores"]).mean()),
+          "boxes bit-equal", float((gb == ref["boxes"]).mean()))
+
+
+def stage_check(engine, keep, names, what):
+    worst = 1.0
+    for n in names:
+        got = engine.get_tensor(n)
+        ref = keep[n]
+        if n in ("encoded_boxes", "class_predictions"):
+            ref = ref.reshape(got.shape)
+        err = np.abs(got - ref).max()
+        scale = max(1.0, float(np.abs(ref).max()))
+        eq = float((got == ref).mean())
+        worst = min(worst, eq)
+        print("%s %s: max err %.3g scale %.3g bit-equal %.6f" % (what, n, err, scale, eq))
+        assert err <= TOL * scale, (what, n)
+    return worst
+
+
+STAGES = ["c3", "c4", "c5", "p3", "p4", "p5", "p6", "p7", "encoded_boxes", "class_predictions"]
+
+
+def test_golden_tiny(cuda, ssd):
+    import make_golden as mg
+    Wt, img = mg.inputs()
+    z = np.load(os.path.join(HERE, "golden", "tiny_mobilenet_128.npz"))
+    eng = ssd.Engine(mg.TINY, Wt)
+    out = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(img).cuda())]
+    compare_outputs(out, z, "golden tiny")
+    assert np.abs(eng.get_tensor("encoded_boxes").reshape(2, -1, 4) - z["encoded_boxes"]).max() <= TOL
+    cp = eng.get_tensor("class_predictions").reshape(2, -1, 80)[:, ::8]
+    assert np.abs(cp - z["class_predictions_every8"]).max() <= TOL * 10
+    for n in ("c5", "p5", "p6", "p7"):
+        assert np.abs(eng.get_tensor(n) - z[n]).max() <= TOL * max(1.0, np.abs(z[n]).max())
+    assert np.abs(eng.get_tensor("c3")[:, :4, :4] - z["c3_corner"]).max() <= TOL * 10
+    assert np.abs(eng.get_tensor("p3")[:, :4, :4] - z["p3_corner"]).max() <= TOL * 10
+    eng.close()
+
+
+@pytest.mark.parametrize("backbone,H,W,B", [("mobilenet", 128, 256, 3), ("shufflenet", 128, 128, 2)])
+def test_forward_vs_oracle_small(cuda, ssd, oracle_graph, backbone, H, W, B):
+    params = {"backbone": backbone, "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
+              "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
+    Wt = ssd.synthetic_weights(params, seed=11, logits_bias=-4.0)
+    img = np.random.default_rng(5).integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    keep = {}
+    ref = oracle_graph.forward(img, Wt, params, keep)
+    eng = ssd.Engine(params, Wt)
+    out = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(img).cuda())]
+    worst = stage_check(eng, keep, STAGES, backbone)
+    compare_outputs(out, ref, backbone + " small")
+    assert ref["num_boxes"].min() > 0
+    assert worst == 1.0, "stages within tolerance but not bit-identical to the oracle"
+    # a second call with another batch size re-plans the arena and stays correct
+    out1 = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(img[:1].copy()).cuda())]
+    for a, b in zip(out, out1):
+        assert np.array_equal(a[:1], b)
+    eng.close()
+
+
+def test_forward_vs_oracle_full_size(cuda, ssd, oracle_graph):
+    """BASELINE config 2: MobileNet-v1 + FPN + heads at 640x896 (H x W), batch 1."""
+    params = ssd.load_config(os.path.join(HERE, "golden", "config_mobilenet.json"))
+    Wt = ssd.synthetic_weights(params, seed=0, logits_bias=-4.0)
+    img = np.random.default_rng(0).integers(0, 256, (1, 640, 896, 3), dtype=np.uint8)
+    keep = {}
+    ref = oracle_graph.forward(img, Wt, params, keep)
+    eng = ssd.Engine(params, Wt)
+    out = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(img).cuda())]
+    assert out[0].shape == (1, 2000, 4) and out[1].dtype == np.int32 and out[3].dtype == np.int32
+    stage_check(eng, keep, STAGES, "full")
+    compare_outputs(out, ref, "full size")
+    assert ref["num_boxes"][0] > 50
+    eng.close()
+
+
+def test_detector_drop_in(cuda, ssd, oracle_graph, tmp_path):
+    """inference/detector.py API: Detector(model_path)(image, score_threshold) ->
+    (boxes, labels, scores)."""
+    import json
+    params = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
+              "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128,
+              "weight_decay": 5e-5, "batch_size": 8}          # training keys are ignored
+    Wt = ssd.synthetic_weights(params, seed=3, logits_bias=-4.0)
+    ssd.save_weights(str(tmp_path / "model.npz"), Wt)
+    with open(tmp_path / "config.json", "w") as f:
+        json.dump(params, f)
+    det = ssd.Detector(str(tmp_path / "model.npz"), gpu_memory_fraction=0.25, visible_device_list="0")
+    img = np.random.default_rng(9).integers(0, 256, (128, 128, 3), dtype=np.uint8)
+    boxes, labels, scores = det(img, score_threshold=0.2)
+    ref = oracle_graph.forward(img[None], Wt, ssd.load_config(params))
+    rb, rl, rs = oracle_graph.detector_call(ref, 0.2)
+    assert boxes.shape == rb.shape and boxes.ndim == 2 and boxes.shape[1] == 4
+    assert np.array_equal(labels, rl) and np.abs(scores - rs).max() <= TOL and np.abs(boxes - rb).max() <= TOL
+    assert (scores > 0.2).all() and len(scores) > 0
+    with pytest.raises(ValueError):
+        det(img.astype(np.float32))
+    with pytest.raises(ssd.SsdError):
+        det(np.zeros((100, 128, 3), np.uint8))              # not a multiple of 128
+    with pytest.raises(FileNotFoundError):
+        ssd.Detector(str(tmp_path / "nope.npz"))
+    # SSD mirror (ssd.py:10-69): raw predictions + get_predictions with other thresholds
+    s = ssd.SSD(cuda.from_numpy(img[None].copy()).cuda(), det.engine)
+    pred = s.get_predictions(score_threshold=0.3, iou_threshold=0.5, max_boxes_per_class=10)
+    p2 = dict(params, score_threshold=0.3, iou_threshold=0.5, max_boxes_per_class=10)
+    ref2 = oracle_graph.forward(img[None], Wt, ssd.load_config(p2))
+    assert np.array_equal(pred["num_boxes"].cpu().numpy(), ref2["num_boxes"])
+    assert np.array_equal(pred["labels"].cpu().numpy(), ref2["labels"])
+    assert np.abs(pred["boxes"].cpu().numpy() - ref2["boxes"]).max() <= TOL
+
+
+def test_missing_weight_fails_loudly(cuda, ssd):
+    params = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
+              "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
+    Wt = ssd.synthetic_weights(params, seed=3)
+    del Wt["fpn/p6/kernel"]
+    with pytest.raises(ssd.SsdError, match="fpn/p6/kernel"):
+        ssd.Engine(params, Wt)
+    Wt = ssd.synthetic_weights(params, seed=3)
+    Wt["fpn/p6/kernel"] = Wt["fpn/p6/kernel"][:, :, :8]
+    with pytest.raises(ssd.SsdError, match="shape"):
+        ssd.Engine(params, Wt)
+
+
+def test_batch_independence_full_batch(cuda, ssd):
+    """BASELINE config 5 shard size (32 images / GPU) at 640x896: every image of a batch
+    gives exactly the result of its own batch-1 run, and permuting the batch permutes the
+    outputs (the path has no cross-image term)."""
+    params = ssd.load_config(os.path.join(HERE, "golden", "config_mobilenet.json"))
+    Wt = ssd.synthetic_weights(params, seed=0, logits_bias=-4.0)
+    eng = ssd.Engine(params, Wt)
+    rng = np.random.default_rng(1)
+    imgs = rng.integers(0, 256, (32, 640, 896, 3), dtype=np.uint8)
+    d = cuda.from_numpy(imgs).cuda()
+    full = [t.cpu().numpy() for t in eng.forward(d)]
+    perm = rng.permutation(32)
+    permd = [t.cpu().numpy() for t in eng.forward(d[cuda.from_numpy(perm).cuda()].contiguous())]
+    for a, b in zip(full, permd):
+        assert np.array_equal(a[perm], b)
+    one = [t.cpu().numpy() for t in eng.forward(d[17:18].contiguous())]
+    for a, b in zip(full, one):
+        assert np.array_equal(a[17:18], b)
+    assert full[3].min() > 0
+    eng.close()

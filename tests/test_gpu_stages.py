@@ -1,0 +1,238 @@
+"""-m gpu: every HIP kernel behind the C ABI against the CPU oracle on the same seeded
+inputs.  Integer / index results must be identical; fp32 values are compared with the
+tolerance BASELINE.json's north_star states (1e-4), and -- because the kernels accumulate
+in the oracle's k-order on the exact-fp32 matrix cores -- additionally reported / asserted
+bit-for-bit where noted."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def bn_params(rng, c):
+    g = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    b = rng.normal(0, 0.1, c).astype(np.float32)
+    m = rng.normal(0, 0.1, c).astype(np.float32)
+    v = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    return g, b, m, v
+
+
+def close(got, ref, what):
+    got = np.asarray(got)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = np.abs(got - ref).max() if ref.size else 0.0
+    scale = max(1.0, float(np.abs(ref).max()) if ref.size else 1.0)
+    exact = float((got == ref).mean()) if ref.size else 1.0
+    print("%s: max abs err %.3g (scale %.3g), bit-equal fraction %.6f" % (what, err, scale, exact))
+    assert err <= TOL * scale, what
+    return exact
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, mode, bn, bias, act, up
+    (1, 10, 14, 256, 256, 3, 1, "SAME", True, False, "relu", False),     # head tower / fpn p conv
+    (2, 7, 5, 256, 256, 3, 1, "SAME", True, False, "relu", False),       # tiny level, M tail
+    (1, 20, 28, 256, 480, 3, 1, "SAME", False, True, None, False),       # class_net/logits
+    (1, 20, 28, 256, 24, 3, 1, "SAME", False, True, None, False),        # box_net/encoded_boxes
+    (2, 20, 28, 64, 256, 3, 2, "EXPLICIT", True, False, "relu", False),  # fpn p6/p7 form
+    (1, 10, 14, 1024, 256, 3, 2, "EXPLICIT", False, False, None, False), # fpn p6 Cin 1024
+    (2, 40, 56, 32, 64, 1, 1, "SAME", True, False, "relu6", False),      # Conv2d_1_pointwise
+    (1, 20, 28, 512, 512, 1, 1, "SAME", True, False, "relu6", False),    # Conv2d_7..11_pointwise
+    (1, 5, 7, 1024, 1024, 1, 1, "SAME", True, False, "relu6", False),    # Conv2d_13_pointwise (tile tail)
+    (2, 20, 28, 512, 256, 1, 1, "SAME", False, False, None, True),       # fpn lateral + upsample-add
+    (1, 16, 16, 24, 58, 1, 1, "SAME", True, False, "relu", False),       # shufflenet odd channels
+    (1, 16, 16, 116, 116, 1, 1, "SAME", True, False, "relu", False),
+    (3, 33, 17, 40, 72, 3, 1, "SAME", False, False, None, False),        # ragged everything
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
+def test_conv2d(cuda, ssd, oracle_ops, case):
+    B, H, W, Cin, Cout, k, stride, mode, use_bn, use_bias, act, use_up = case
+    rng = np.random.default_rng(100 + CONV_CASES.index(case))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) * np.sqrt(2.0 / (k * k * Cin))).astype(np.float32)
+    ref = oracle_ops.conv2d(x, w, stride, mode)
+    bn = None
+    if use_bn:
+        g, b, m, v = bn_params(rng, Cout)
+        ref = oracle_ops.bn_act(ref, g, b, m, v, None)
+        bn = (m, oracle_ops.bn_scale(g, v), b)
+    bias = None
+    if use_bias:
+        bias = rng.standard_normal(Cout).astype(np.float32)
+        ref = oracle_ops.bias_add(ref, bias)
+    up = None
+    if use_up:
+        coarse = rng.standard_normal((B, ref.shape[1] // 2, ref.shape[2] // 2, Cout)).astype(np.float32)
+        ref = oracle_ops.upsample2_add(coarse, ref)
+        up = dev(cuda, coarse)
+    if act == "relu":
+        ref = np.maximum(ref, 0)
+    elif act == "relu6":
+        ref = np.clip(ref, 0, 6)
+    got = ssd.ssd.conv2d(dev(cuda, x), w, stride, mode, bn=bn, bias=bias, up=up, act=act).cpu().numpy()
+    exact = close(got, ref, "conv2d %s" % (case,))
+    # same accumulation order on the exact-fp32 MFMA as the oracle's fmaf chain
+    assert exact == 1.0, "conv2d result is within tolerance but not bit-identical to the oracle"
+
+
+def test_conv2d_empty_and_errors(cuda, ssd):
+    x = cuda.zeros((1, 4, 4, 8), dtype=cuda.float32, device="cuda")
+    with pytest.raises(ValueError):
+        ssd.ssd.conv2d(x, np.zeros((3, 3, 16, 8), np.float32))
+    with pytest.raises(ssd.SsdError):
+        ssd.ssd.conv2d(x, np.zeros((5, 5, 8, 8), np.float32))         # only k = 1 or 3
+    with pytest.raises(TypeError):
+        ssd.ssd.conv2d(x.cpu(), np.zeros((3, 3, 8, 8), np.float32))   # no CPU path
+
+
+@pytest.mark.parametrize("B,H,W,C,stride,act", [(2, 20, 28, 32, 1, "relu6"), (1, 40, 56, 64, 2, "relu6"),
+                                                (2, 16, 16, 24, 2, None), (1, 10, 10, 58, 1, None),
+                                                (1, 6, 8, 1024, 1, "relu6")])
+def test_depthwise(cuda, ssd, oracle_ops, B, H, W, C, stride, act):
+    rng = np.random.default_rng(C * 7 + stride)
+    x = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    w = rng.standard_normal((3, 3, C, 1)).astype(np.float32)
+    g, b, m, v = bn_params(rng, C)
+    ref = oracle_ops.bn_act(oracle_ops.depthwise3x3(x, w, stride), g, b, m, v, act)
+    got = ssd.ssd.depthwise3x3(dev(cuda, x), w, stride, bn=(m, oracle_ops.bn_scale(g, v), b), act=act).cpu().numpy()
+    assert close(got, ref, "depthwise C=%d s=%d" % (C, stride)) == 1.0
+
+
+@pytest.mark.parametrize("B,H,W,Cout,act", [(2, 128, 128, 32, "relu6"), (1, 64, 96, 24, "relu")])
+def test_first_conv(cuda, ssd, oracle_ops, B, H, W, Cout, act):
+    rng = np.random.default_rng(Cout)
+    img = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    w = (rng.standard_normal((3, 3, 3, Cout)) * 0.3).astype(np.float32)
+    g, b, m, v = bn_params(rng, Cout)
+    ref = oracle_ops.bn_act(oracle_ops.conv2d(oracle_ops.preprocess(img), w, 2, "SAME"), g, b, m, v, act)
+    got = ssd.ssd.first_conv(dev(cuda, img), w, bn=(m, oracle_ops.bn_scale(g, v), b), act=act).cpu().numpy()
+    assert close(got, ref, "first conv") == 1.0
+
+
+def test_maxpool_and_shuffle(cuda, ssd, oracle_ops):
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, 16, 24, 24)).astype(np.float32)
+    assert np.array_equal(ssd.ssd.maxpool3x3s2(dev(cuda, x)).cpu().numpy(), oracle_ops.maxpool3x3s2(x))
+    a = rng.standard_normal((3, 5, 7, 58)).astype(np.float32)
+    b = rng.standard_normal((3, 5, 7, 58)).astype(np.float32)
+    xo, yo = ssd.ssd.concat_shuffle_split(dev(cuda, a), dev(cuda, b))
+    rx, ry = oracle_ops.concat_shuffle_split(a, b)
+    assert np.array_equal(xo.cpu().numpy(), rx) and np.array_equal(yo.cpu().numpy(), ry)
+
+
+# --------------------------------------------------------------------------- post-processing
+def synth_heads(rng, B, N, C, frac=0.002, base=-4.6):
+    """codes ~ N(0,1); logits = base + sparse positives U[-1.5, 3]."""
+    codes = rng.standard_normal((B, N, 4)).astype(np.float32)
+    logits = np.full((B, N, C), base, np.float32)
+    npos = max(1, int(frac * N))
+    for b in range(B):
+        rows = rng.choice(N, npos, replace=False)
+        cls = rng.integers(0, C, npos)
+        logits[b, rows, cls] = rng.uniform(-1.5, 3.0, npos).astype(np.float32)
+    return codes, logits
+
+
+def run_post(cuda, ssd, oracle_ops, codes, logits, anc, thr=0.15, iou=0.6, m=25, scaler=None):
+    ref = oracle_ops.postprocess(logits, codes, anc, thr, iou, m, scaler)
+    boxes, scores, classes, num = ssd.batch_multiclass_non_max_suppression(
+        dev(cuda, codes), dev(cuda, anc), dev(cuda, logits), thr, iou, m, box_scaler=scaler)
+    got = (boxes.cpu().numpy(), classes.cpu().numpy(), scores.cpu().numpy(), num.cpu().numpy())
+    rb, rl, rs, rn = ref
+    assert np.array_equal(got[3], rn), ("num_boxes", got[3], rn)
+    assert np.array_equal(got[1], rl), "labels differ"
+    assert np.abs(got[2] - rs).max() <= TOL and np.abs(got[0] - rb).max() <= TOL
+    print("postprocess: num", rn.tolist()[:8], "scores bit-equal", float((got[2] == rs).mean()),
+          "boxes bit-equal", float((got[0] == rb).mean()))
+    assert np.array_equal(got[2], rs) and np.array_equal(got[0], rb)
+    return got
+
+
+def test_postprocess_config3(cuda, ssd, oracle_ops):
+    rng = np.random.default_rng(0)
+    anc = oracle_ops.anchors(640, 896)
+    codes, logits = synth_heads(rng, 4, anc.shape[0], 80)
+    got = run_post(cuda, ssd, oracle_ops, codes, logits, anc)
+    assert got[3].min() > 20
+
+
+def test_postprocess_edge_cases(cuda, ssd, oracle_ops):
+    rng = np.random.default_rng(1)
+    anc = oracle_ops.anchors(128, 128)
+    N = anc.shape[0]
+    # (a) nothing above threshold -> all zero outputs
+    codes, logits = synth_heads(rng, 2, N, 80)
+    logits[:] = -4.6
+    got = run_post(cuda, ssd, oracle_ops, codes, logits, anc)
+    assert not got[3].any() and not got[0].any()
+    # (b) one class with > 512 candidates (global-memory path of the NMS kernel) and
+    #     heavy overlap (many suppressions), other classes sparse
+    codes, logits = synth_heads(rng, 2, N, 80, frac=0.01)
+    logits[0, :, 7] = rng.uniform(-1.0, 4.0, N).astype(np.float32)
+    codes[0] *= 0.1
+    run_post(cuda, ssd, oracle_ops, codes, logits, anc)
+    # (c) exact ties in score: lower anchor index first
+    codes, logits = synth_heads(rng, 1, N, 80)
+    logits[0, 100:140, 3] = 2.0
+    run_post(cuda, ssd, oracle_ops, codes, logits, anc)
+    # (d) score exactly at the threshold (0.5 = sigmoid(0)) is not selected; just above is
+    codes, logits = synth_heads(rng, 1, N, 80)
+    logits[:] = -9.0
+    logits[0, 10, 0] = 0.0
+    logits[0, 900, 1] = np.float32(1e-6)
+    got = run_post(cuda, ssd, oracle_ops, codes, logits, anc, thr=0.5)
+    assert got[3][0] == 1 and got[1][0][0] == 1
+    # (e) fully clipped (zero-area) boxes never suppress each other: cap at max_per_class
+    codes = np.zeros((1, N, 4), np.float32)
+    codes[..., 0] = 200.0                      # cy far below the image -> clipped to y = 1
+    logits = np.full((1, N, 80), -9.0, np.float32)
+    logits[0, :60, 5] = rng.uniform(0, 3, 60).astype(np.float32)
+    got = run_post(cuda, ssd, oracle_ops, codes, logits, anc, m=25)
+    assert got[3][0] == 25
+    # (f) box_scaler division (model.py:67-68) and other thresholds / caps
+    codes, logits = synth_heads(rng, 3, N, 80, frac=0.02)
+    run_post(cuda, ssd, oracle_ops, codes, logits, anc, thr=0.3, iou=0.4, m=7,
+             scaler=np.array([0.8, 1.0, 0.8, 1.0], np.float32))
+    # (g) non-multiple-of-4 class count takes the scalar scan path
+    codes, logits = synth_heads(rng, 2, N, 3, frac=0.05)
+    run_post(cuda, ssd, oracle_ops, codes, logits, anc, m=5)
+
+
+def test_postprocess_batch_properties(cuda, ssd, oracle_ops):
+    """Full BASELINE size (config 3: B=32, N=71610): images are independent, so a
+    permutation of the batch permutes the outputs and every image equals its B=1 run."""
+    rng = np.random.default_rng(2)
+    anc = oracle_ops.anchors(640, 896)
+    codes, logits = synth_heads(rng, 32, anc.shape[0], 80)
+    d_anc, d_codes, d_logits = dev(cuda, anc), dev(cuda, codes), dev(cuda, logits)
+    full = [t.cpu().numpy() for t in ssd.batch_multiclass_non_max_suppression(d_codes, d_anc, d_logits, 0.15, 0.6, 25)]
+    perm = rng.permutation(32)
+    pl, pc = dev(cuda, logits[perm]), dev(cuda, codes[perm])
+    permd = [t.cpu().numpy() for t in ssd.batch_multiclass_non_max_suppression(pc, d_anc, pl, 0.15, 0.6, 25)]
+    for a, b in zip(full, permd):
+        assert np.array_equal(a[perm], b)
+    one = [t.cpu().numpy() for t in ssd.batch_multiclass_non_max_suppression(
+        d_codes[5:6].contiguous(), d_anc, d_logits[5:6].contiguous(), 0.15, 0.6, 25)]
+    for a, b in zip(full, one):
+        assert np.array_equal(a[5:6], b)
+    # oracle on a bounded sample of the batch
+    ref = oracle_ops.postprocess(logits[:2], codes[:2], anc, 0.15, 0.6, 25)
+    assert np.array_equal(full[3][:2], ref[3]) and np.array_equal(full[2][:2], ref[1])
+    assert np.array_equal(full[0][:2], ref[0]) and np.array_equal(full[1][:2], ref[2])
+    # structure: class-major, scores descending inside a class, zero padding
+    boxes, scores, classes, num = full
+    for b in range(32):
+        n = num[b]
+        assert (np.diff(classes[b][:n]) >= 0).all()
+        same = np.diff(classes[b][:n]) == 0
+        assert (np.diff(scores[b][:n])[same] <= 0).all()
+        assert not scores[b][n:].any() and not boxes[b][n:].any()
+        assert np.bincount(classes[b][:n], minlength=80).max() <= 25

@@ -1,0 +1,97 @@
+"""CPU-side host logic: config surface, weight container, C ABI symbols, anchors."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def test_config_surface(ssd):
+    p = ssd.load_config(os.path.join(HERE, "golden", "config_mobilenet.json"))
+    assert p == {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80,
+                 "score_threshold": 0.15, "iou_threshold": 0.6, "max_boxes_per_class": 25,
+                 "min_dimension": 640}
+    assert ssd.load_config(os.path.join(HERE, "golden", "config_shufflenet.json"))["backbone"] == "shufflenet"
+    with pytest.raises(KeyError):
+        ssd.load_config({"backbone": "mobilenet"})
+    with pytest.raises(ValueError):
+        ssd.load_config(dict(p, backbone="resnet"))
+
+
+def test_variable_catalogue(ssd):
+    p = ssd.load_config(os.path.join(HERE, "golden", "config_mobilenet.json"))
+    shapes = ssd.variable_shapes(p)
+    assert shapes["MobilenetV1/Conv2d_0/weights"] == (3, 3, 3, 32)
+    assert shapes["MobilenetV1/Conv2d_13_pointwise/weights"] == (1, 1, 1024, 1024)
+    assert shapes["fpn/p6/kernel"] == (3, 3, 1024, 256)
+    assert shapes["class_net/logits/kernel"] == (3, 3, 256, 480)
+    assert shapes["box_net/batch_norm_3_for_level_7/moving_variance"] == (256,)
+    conv = sum(int(np.prod(s)) for n, s in shapes.items() if n.endswith(("weights", "kernel")))
+    assert abs(conv / 1e6 - 14.24) < 0.01                       # 14.24 M conv params
+    ps = ssd.load_config(os.path.join(HERE, "golden", "config_shufflenet.json"))
+    ss = ssd.variable_shapes(ps)
+    assert ss["ShuffleNetV2/Stage2/unit_1/conv1x1_after/weights"] == (1, 1, 24, 58)
+    assert ss["ShuffleNetV2/Stage3/unit_8/depthwise/depthwise_weights"] == (3, 3, 116, 1)
+    assert ss["ShuffleNetV2/Conv5/weights"] == (1, 1, 464, 1024)
+    assert ss["fpn/lateral3/kernel"] == (1, 1, 116, 256)
+    conv = sum(int(np.prod(s)) for n, s in ss.items() if n.endswith(("weights", "kernel")))
+    assert abs(conv / 1e6 - 12.18) < 0.01                       # 12.18 M
+
+
+def test_weights_roundtrip(ssd, tmp_path):
+    p = {"backbone": "mobilenet", "depth_multiplier": 0.25, "num_classes": 3, "score_threshold": 0.1,
+         "iou_threshold": 0.5, "max_boxes_per_class": 5, "min_dimension": 128}
+    W = ssd.synthetic_weights(p, seed=1)
+    W2 = ssd.synthetic_weights(p, seed=1)
+    assert all(np.array_equal(W[k], W2[k]) for k in W)
+    ssd.save_weights(str(tmp_path / "w.npz"), W)
+    L = ssd.load_weights(str(tmp_path / "w.npz"))
+    assert set(L) == set(W) and all(np.array_equal(W[k], L[k]) for k in W)
+    assert abs(float(W["class_net/logits/bias"][0]) + np.log(99.0)) < 1e-6   # box_predictor.py:121-127
+
+
+def test_abi_exports_every_declared_symbol(ssd):
+    """The C-ABI library loads and exports every function include/ssd_hip.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "ssd_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ssd_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 19
+    lib = ctypes.CDLL(ssd.build())
+    for name in declared:
+        assert hasattr(lib, name), name
+    from importlib import import_module
+    sigs = import_module("ssd_amd._lib").SIGNATURES
+    assert declared == set(sigs)
+
+
+def test_anchors_host_side(ssd, oracle_ops):
+    """ssd_anchors is host arithmetic (no GPU needed): identical to the oracle's table."""
+    for H, W in [(640, 896), (640, 640), (128, 128), (256, 384)]:
+        a = ssd.AnchorGenerator()(H, W)
+        assert np.array_equal(a, oracle_ops.anchors(H, W))
+    with pytest.raises(NotImplementedError):
+        ssd.AnchorGenerator(scales=[16, 32, 64, 128, 256])
+
+
+def test_no_cpu_fallback(ssd):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p = ssd.load_config(os.path.join(HERE, "golden", "config_mobilenet.json"))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ssd.Engine(p, {})
+    with pytest.raises(RuntimeError):
+        ssd.ssd.conv2d(torch.zeros(1, 4, 4, 8), np.zeros((1, 1, 8, 8), np.float32))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "single-shot-detector_amd")
+    for dirpath, _d, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "libssd_oracle" not in src, f
