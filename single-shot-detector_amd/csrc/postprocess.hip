@@ -20,6 +20,7 @@
 //   K9d pack     per image: prefix over class counts, class-major copy, / box_scaler,
 //                zero padding, num_boxes.
 #include "ssd_internal.h"
+#include <cstdlib>
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
@@ -62,7 +63,9 @@ __device__ __forceinline__ bool iou_greater(const v4f bi, const v4f bj, float th
     const float ymax_j = fmaxf(bj[0], bj[2]), xmax_j = fmaxf(bj[1], bj[3]);
     const float area_i = (ymax_i - ymin_i) * (xmax_i - xmin_i);
     const float area_j = (ymax_j - ymin_j) * (xmax_j - xmin_j);
-    if (area_i <= 0.0f || area_j <= 0.0f) return false;
+    // branch-free form of `if (area_i <= 0 || area_j <= 0) return false;` -- with both areas
+    // positive the union is positive, otherwise the (possibly NaN) quotient is masked.
+    const bool valid = (area_i > 0.0f) & (area_j > 0.0f);
     const float iy0 = fmaxf(ymin_i, ymin_j), ix0 = fmaxf(xmin_i, xmin_j);
     const float iy1 = fminf(ymax_i, ymax_j), ix1 = fminf(xmax_i, xmax_j);
     const float ih = fmaxf(iy1 - iy0, 0.0f), iw = fmaxf(ix1 - ix0, 0.0f);
@@ -70,7 +73,7 @@ __device__ __forceinline__ bool iou_greater(const v4f bi, const v4f bj, float th
     float uni = area_i + area_j;
     uni = uni - inter;
     const float iou = inter / uni;
-    return iou > thr;
+    return valid & (iou > thr);
 }
 
 __device__ __forceinline__ void emit_candidate(const PostArgs &p, int b, int i, int c, float logit)
@@ -143,23 +146,29 @@ __global__ __launch_bounds__(64) void post_nms_kernel(const PostArgs p)
     float *ob = p.cls_boxes + (long long)bc * p.max_per_class * 4;
     float *os = p.cls_scores + (long long)bc * p.max_per_class;
     int kept = 0;
-    if (n > 0 && n <= 64 * NMS_R) {
+    if (n > 0 && n <= p.fast_max) {
+        // keys and boxes are immutable; liveness is one bit per register slot.  (A version
+        // that zeroed key[r] under `key == best || iou > thr` was miscompiled by hipcc
+        // 7.2: the kill of the IoU branch was dropped -- keep this form branch-free.)
         u64 key[NMS_R];
         v4f box[NMS_R];
+        unsigned alive = 0;
 #pragma unroll
         for (int r = 0; r < NMS_R; ++r) {
             const int i = lane + 64 * r;
-            key[r] = 0;
-            box[r] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-            if (i < n) {
-                key[r] = keys[i];
-                box[r] = *(const v4f *)(dec + (long long)(0xFFFFFFFFu - (unsigned)(key[r] & 0xFFFFFFFFu)) * 4);
-            }
+            const bool ok = i < n;
+            key[r] = ok ? keys[ok ? i : 0] : 0ull;
+            const unsigned anchor = 0xFFFFFFFFu - (unsigned)(key[r] & 0xFFFFFFFFu);
+            box[r] = *(const v4f *)(dec + (long long)(ok ? anchor : 0u) * 4);
+            alive |= ok ? (1u << r) : 0u;
         }
         while (kept < p.max_per_class) {
             u64 best = 0;
 #pragma unroll
-            for (int r = 0; r < NMS_R; ++r) best = key[r] > best ? key[r] : best;
+            for (int r = 0; r < NMS_R; ++r) {
+                const u64 k = ((alive >> r) & 1u) ? key[r] : 0ull;
+                best = k > best ? k : best;
+            }
             best = wave_max_u64(best);
             if (best == 0) break;
             const v4f wb = *(const v4f *)(dec + (long long)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFu)) * 4);
@@ -168,9 +177,13 @@ __global__ __launch_bounds__(64) void post_nms_kernel(const PostArgs p)
                 os[kept] = __uint_as_float((unsigned)(best >> 32));
             }
             ++kept;
+            unsigned kill = 0;
 #pragma unroll
-            for (int r = 0; r < NMS_R; ++r)
-                if (key[r] != 0 && (key[r] == best || iou_greater(box[r], wb, p.iou_thr))) key[r] = 0;
+            for (int r = 0; r < NMS_R; ++r) {
+                const bool k = (key[r] == best) | iou_greater(box[r], wb, p.iou_thr);
+                kill |= k ? (1u << r) : 0u;
+            }
+            alive &= ~kill;
         }
     } else if (n > 0) {
         // any candidate count: keys stay in global memory, dead candidates are zeroed
@@ -259,8 +272,11 @@ void post_carve(PostArgs &p, void *ws)
     p.cls_counts = (int *)q;
 }
 
-hipError_t launch_postprocess(const PostArgs &p, hipStream_t s)
+hipError_t launch_postprocess(const PostArgs &pin, hipStream_t s)
 {
+    PostArgs p = pin;
+    p.fast_max = 64 * NMS_R;
+    if (const char *e = getenv("SSD_NMS_FAST_MAX")) { int v = atoi(e); if (v >= 0 && v < p.fast_max) p.fast_max = v; }
     if (p.B < 1 || p.N < 1 || p.C < 1 || p.max_per_class < 1) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(p.counts, 0, (size_t)p.B * p.C * sizeof(int), s);
     if (e != hipSuccess) return e;

@@ -77,6 +77,7 @@ struct PostArgs {
     float score_thr, iou_thr;
     float logit_lo;        // conservative logit bound below which sigmoid(x) <= score_thr
     int max_per_class;
+    int fast_max;          // candidate lists up to this length are processed in registers
     float box_scaler[4];
     float *boxes; int32_t *labels; float *scores; int32_t *num;
     // workspace carve-up

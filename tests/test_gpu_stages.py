@@ -201,6 +201,13 @@ def test_postprocess_edge_cases(cuda, ssd, oracle_ops):
     codes, logits = synth_heads(rng, 3, N, 80, frac=0.02)
     run_post(cuda, ssd, oracle_ops, codes, logits, anc, thr=0.3, iou=0.4, m=7,
              scaler=np.array([0.8, 1.0, 0.8, 1.0], np.float32))
+    # (h) register path of the NMS kernel (<= 512 candidates) with heavy suppression
+    codes, logits = synth_heads(rng, 2, N, 80, frac=0.005)
+    codes *= 0.1
+    logits[0, 200:500, 9] = rng.uniform(-1.0, 4.0, 300).astype(np.float32)
+    logits[1, 0:480, 79] = rng.uniform(-1.0, 4.0, 480).astype(np.float32)
+    got = run_post(cuda, ssd, oracle_ops, codes, logits, anc)
+    assert 0 < np.bincount(got[1][0][:got[3][0]], minlength=80)[9] < 300
     # (g) non-multiple-of-4 class count takes the scalar scan path
     codes, logits = synth_heads(rng, 2, N, 3, frac=0.05)
     run_post(cuda, ssd, oracle_ops, codes, logits, anc, m=5)
