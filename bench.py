@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric: images/sec at 896x640 (W x H), MobileNet-v1 RetinaNet,
+on N MI355X of one node (weak scaling: a fixed shard of images per GPU), plus the p50
+per-image latency of the reference's own batch-1 protocol.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the whole hot path (uint8 frames already resident in HBM -> backbone
+-> FPN -> heads -> decode -> per-class NMS -> padded detections; for N > 1 followed by the
+RCCL all-gather of the detection records) over one batch of synthetic frames per GPU.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import ssd_amd  # noqa: E402
+
+H, W = 640, 896                       # inference/just_try_detector.ipynb:111 resize((896, 640))
+PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PARAMS = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80,
+          "score_threshold": 0.15, "iou_threshold": 0.6, "max_boxes_per_class": 25,
+          "min_dimension": 640}       # config_mobilenet.json:7-12,21
+LOGITS_BIAS = -4.0                    # random heads at the reference's -log(99) emit nothing; see DESIGN.md
+
+
+def cpu_baseline(budget_s=12.0):
+    """The CPU oracle (a port of the reference graph, oracle/) on this host's cores, one
+    640x896 frame at a time (the reference graph is batch 1), bounded to ~budget_s."""
+    from oracle import graph, ops
+    ops.build()
+    Wt = ssd_amd.synthetic_weights(PARAMS, seed=0, logits_bias=LOGITS_BIAS)
+    img = np.random.default_rng(0).integers(0, 256, (1, H, W, 3), dtype=np.uint8)
+    graph.forward(img, Wt, PARAMS)                      # warm-up (threads, page faults)
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 20 and (len(times) < 2 or time.perf_counter() < t_end):
+        t0 = time.perf_counter()
+        graph.forward(img, Wt, PARAMS)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d frames of 640x896, batch 1, C oracle (OpenMP, AVX2 fmaf chains), median %.3f s/frame"
+                      % (len(times), med)}
+
+
+def latency_batch1(engine, dev):
+    """inference/just_try_detector.ipynb:149-155: 110 calls of the batch-1 detector on one
+    host uint8 image (H2D + graph + D2H + score filter), first 10 dropped."""
+    img = np.random.default_rng(0).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    times = []
+    for _ in range(110):
+        t0 = time.perf_counter()
+        d = torch.from_numpy(img[None]).to(dev)
+        boxes, labels, scores, num = engine.forward(d)
+        n = int(num.cpu()[0])
+        s = scores[0, :n].cpu().numpy()
+        keep = s > 0.5
+        _ = boxes[0, :n].cpu().numpy()[keep], labels[0, :n].cpu().numpy()[keep], s[keep]
+        times.append(time.perf_counter() - t0)
+    t = np.array(times[10:]) * 1e3
+    return {"p50_ms": float(np.percentile(t, 50)), "mean_ms": float(t.mean()), "std_ms": float(t.std())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step (BASELINE config 5: 256/8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
+                             "--nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B = args.batch
+    Wt = ssd_amd.synthetic_weights(PARAMS, seed=0, logits_bias=LOGITS_BIAS)
+    engine = ssd_amd.Engine(PARAMS, Wt, device=local)
+    # this rank's shard of the global batch, resident in HBM before the timed region
+    lo, hi = ssd_amd.shard_range(B * world, rank, world)
+    g = torch.Generator().manual_seed(1234 + rank)
+    frames = torch.randint(0, 256, (hi - lo, H, W, 3), dtype=torch.uint8, generator=g).to(dev)
+
+    def step():
+        return ssd_amd.detect_sharded(engine, frames)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    engine.profile_reset()
+    engine.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    engine.profile_enable(False)
+    prof = engine.profile_read()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out[0].shape[0] == B * world
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        c3 = prof["conv3x3_mfma"]
+        avg_ms = c3["ms"] / max(c3["launches"], 1)
+        flops_per_launch = c3["flops"] / max(c3["launches"], 1)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        res = {
+            "metric": "images/sec at 896x640, MobileNet-v1 RetinaNet (whole hot path incl. decode + per-class NMS)",
+            "value": B * world * args.steps / dt, "unit": "img/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "MobileNet-v1 + FPN + RetinaNet heads + decode + per-class NMS, 640x896 (HxW) "
+                                   "uint8 frames, %d per GPU (BASELINE config 5 shard; config 2 = same graph at batch 1, "
+                                   "see latency_batch1)" % B,
+                       "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W,
+                       "parallelism": "dp%d" % world, "weights": "random-init (seed 0), logits bias %.1f" % LOGITS_BIAS},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "igemm_kernel (3x3 convs: FPN outputs + head towers + class/box heads)",
+                         "launches_per_step": c3["launches"] / args.steps, "avg_launch_ms": avg_ms,
+                         "algorithmic_gflop_per_launch": flops_per_launch / 1e9},
+            "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
+            "whole_net_roofline_frac": (1.113 * B) / ms_step,       # 1.113 ms/img at the per-layer roofline
+        }
+        if not args.no_latency:
+            res["latency_batch1"] = latency_batch1(engine, dev)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -166,6 +166,14 @@ int ssd_postprocess(const float *logits_dev, const float *codes_dev, const float
                     int32_t *num_boxes_dev, void *workspace_dev, size_t workspace_bytes,
                     void *stream);
 
+/* Diagnostics (scripts/bench_conv.py): average milliseconds of `reps` launches of one dense
+ * convolution with BN + ReLU on random data, with an explicit implicit-GEMM tile variant
+ * (0: 128x128, 1: 128x64, 2: 128x32, 3: 128x256, 4: 256x128; -1: the library's choice).
+ * pyramid != 0 runs the five-level head-tower launch shape (H,W halved per level). */
+int ssd_bench_conv(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t k,
+                   int32_t stride, int32_t tile, int32_t reps, int32_t pyramid, double *avg_ms,
+                   double *gflop);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,13 +107,15 @@ struct ConvW {
 static int pick_tile(int CoutP) { return CoutP <= 32 ? IGEMM_128x32 : (CoutP <= 64 ? IGEMM_128x64 : IGEMM_128x128); }
 
 // w: HWIO [k,k,Cin_l,Cout_l] -> wt [taps][CoutPad][CinP]
+static int g_force_tile = -1;   // diagnostics only (ssd_bench_conv)
+
 static int pack_conv(DevPool &pool, const float *w, int k, int Cin_l, int Cout_l, const std::vector<int> &inmap,
                      const std::vector<int> &outmap, ConvW &cw)
 {
     cw.taps = k * k;
     cw.CinP = (int)inmap.size();
     cw.CoutP = (int)outmap.size();
-    cw.tile = pick_tile(cw.CoutP);
+    cw.tile = g_force_tile >= 0 ? g_force_tile : pick_tile(cw.CoutP);
     cw.CoutPad = round_up(cw.CoutP, igemm_tile_bn(cw.tile));
     cw.Cin_l = Cin_l;
     cw.Cout_l = Cout_l;
@@ -1212,4 +1214,75 @@ extern "C" int ssd_postprocess(const float *logits_dev, const float *codes_dev, 
     post_carve(p, workspace_dev);
     HIPCHK(launch_postprocess(p, (hipStream_t)stream));
     return SSD_OK;
+}
+
+// ----------------------------------------------------------------------------- diagnostics
+// Times `reps` launches of one dense convolution (random data, BN + ReLU epilogue) on the
+// implicit-GEMM kernel with an explicit tile variant; used by scripts/bench_conv.py to A/B
+// kernel variants in one process.  nlev > 1 replicates the level `nlev` times in one launch
+// (the head-tower launch shape).  Returns the average milliseconds per launch.
+extern "C" int ssd_bench_conv(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t k, int32_t stride,
+                              int32_t tile, int32_t reps, int32_t pyramid, double *avg_ms, double *gflop)
+{
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (k != 1 && k != 3) || reps < 1 || !avg_ms)
+        return fail(SSD_ERR_INVALID, "ssd_bench_conv: bad arguments");
+    DevPool pool;
+    auto body = [&]() -> int {
+        const int CinP = round_up(Cin, 32), CoutP = round_up(Cout, 8);
+        std::vector<float> w((size_t)k * k * Cin * Cout);
+        unsigned st = 12345u;
+        auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 65536.0f - 0.5f; };
+        for (auto &v : w) v = rnd() * 0.1f;
+        ConvW cw;
+        g_force_tile = tile;
+        int rc = pack_conv(pool, w.data(), k, Cin, Cout, phys_map(Cin, CinP), phys_map(Cout, CoutP), cw);
+        g_force_tile = -1;
+        SSDCHK(rc);
+        BnHost b;
+        const int nl = pyramid ? 5 : 1;
+        for (int l = 0; l < nl; ++l)
+            for (int c = 0; c < CoutP; ++c) { b.mean.push_back(0.01f * (c % 7)); b.sf.push_back(1.0f + 0.001f * (c % 5)); b.beta.push_back(0.02f); }
+        SSDCHK(upload_bn(pool, b, cw));
+        std::vector<LevelDesc> lv;
+        long long in_total = 0, out_total = 0;
+        const int pad = k == 3 ? 1 : 0;
+        int h = H, wd = W;
+        double fl = 0;
+        for (int l = 0; l < nl; ++l) {
+            const int oh = (h + 2 * pad - k) / stride + 1, ow = (wd + 2 * pad - k) / stride + 1;
+            lv.push_back(dense_level(h, wd, oh, ow, CoutP, in_total, out_total, l * CoutP));
+            in_total += (long long)B * h * wd * CinP;
+            out_total += (long long)B * oh * ow * CoutP;
+            fl += 2.0 * B * oh * ow * (double)k * k * Cin * Cout;
+            h = (h + 1) / 2; wd = (wd + 1) / 2;
+        }
+        float *in, *out;
+        SSDCHK(pool.alloc((void **)&in, (size_t)in_total * 4));
+        SSDCHK(pool.alloc((void **)&out, (size_t)out_total * 4));
+        {
+            std::vector<float> hin((size_t)in_total);
+            for (auto &v : hin) v = rnd();
+            HIPCHK(hipMemcpy(in, hin.data(), hin.size() * 4, hipMemcpyHostToDevice));
+        }
+        Op op = make_conv_op(cw, in, out, nullptr, nullptr, B, stride, pad, SSD_ACT_RELU, lv, true);
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        for (int i = 0; i < 2; ++i) HIPCHK(op.run(nullptr));
+        HIPCHK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < reps; ++i) HIPCHK(op.run(nullptr));
+        HIPCHK(hipEventRecord(e1, nullptr));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        *avg_ms = ms / reps;
+        if (gflop) *gflop = fl / 1e9;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return SSD_OK;
+    };
+    int rc = body();
+    (void)hipDeviceSynchronize();
+    pool.free_all();
+    return rc;
 }

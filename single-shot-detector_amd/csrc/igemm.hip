@@ -22,13 +22,18 @@
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
+// DBG (timing experiments only, results are wrong): 1 = no global loads / LDS writes in the
+// K loop, 2 = additionally no LDS fragment reads, 3 = additionally no barrier.
+template <int WAVES_M, int WAVES_N, int WM, int WN, int DBG = 0>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const IgemmArgs a)
 {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;   // threads per block (256 or 512)
+    constexpr int RPP = NT / 8;                  // tile rows covered by one pass of the block
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
-    constexpr int NA = BM / 32;          // 16-B loads per thread per K-step, A tile
-    constexpr int NB = BN / 32;          // same, B tile
+    constexpr int NA = BM / RPP;         // 16-B loads per thread per K-step, A tile
+    constexpr int NB = BN / RPP;         // same, B tile
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && RPP % 16 == 0, "tile/thread mismatch");
     constexpr int A_BYTES = BM * 128;
     constexpr int STAGE = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -56,27 +61,40 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
     const int Cin = a.Cin;
     const int m0 = (tile_m - L.tile_begin) * BM;
 
-    // ---- per-thread load bookkeeping: thread owns chunk (tid&7) of rows (tid>>3)+32u
-    const float *arow[NA];
-    int aiy0[NA], aix0[NA];
+    // ---- per-thread load bookkeeping: thread owns chunk (tid&7) of rows (tid>>3)+RPP*u.
+    // Loads go through buffer resources (SGPR base + 32-bit byte offset per lane): an
+    // offset >= num_records is answered with zeros by the range check, which IS the zero
+    // padding of the convolution (and of rows beyond M) -- no select, no branch.
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.in + L.in_off), 0, (int)((long long)a.B * H * W * Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)a.wt, 0, (int)((long long)a.taps * a.CoutPad * Cin * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    int abase[NA], aiy0[NA], aix0[NA];      // byte offset of the row's image, top-left tap coordinate
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
-        const int m = m0 + (tid >> 3) + 32 * u;
-        if (m < M) {
-            const int b = m / P, p = m - b * P;
-            const int oy = p / OW, ox = p - oy * OW;
-            arow[u] = a.in + L.in_off + (long long)b * H * W * Cin + (tid & 7) * 4;
-            aiy0[u] = oy * a.stride - a.pad;
-            aix0[u] = ox * a.stride - a.pad;
-        } else {
-            arow[u] = a.in;
-            aiy0[u] = -(1 << 20);
-            aix0[u] = 0;
-        }
+        const int m = m0 + (tid >> 3) + RPP * u;
+        const bool rowok = m < M;
+        const int mm = rowok ? m : 0;
+        const int b = mm / P, p = mm - b * P;
+        const int oy = p / OW, ox = p - oy * OW;
+        abase[u] = (b * H * W * Cin + (tid & 7) * 4) * 4;
+        aiy0[u] = rowok ? oy * a.stride - a.pad : -(1 << 20);
+        aix0[u] = ox * a.stride - a.pad;
     }
-    const float *brow = a.wt + (long long)(tile_n * BN + (tid >> 3)) * Cin + (tid & 7) * 4;
-    const long long b_ustride = 32LL * Cin;
-    const long long b_tapstride = (long long)a.CoutPad * Cin;
+    // byte offsets of this thread's A chunks for filter tap `t` (OOB when the tap is padding)
+    auto tap_offsets = [&](int t, unsigned (&off)[NA]) {
+        const int tky = a.taps == 9 ? t / 3 : 0, tkx = a.taps == 9 ? t - 3 * tky : 0;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int iy = aiy0[u] + tky, ix = aix0[u] + tkx;
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && t < a.taps;
+            off[u] = ok ? (unsigned)(abase[u] + (iy * W + ix) * Cin * 4) : OOB;
+        }
+    };
+    const int bvoff = ((tile_n * BN + (tid >> 3)) * Cin + (tid & 7) * 4) * 4;
+    const int b_ustride = RPP * Cin * 4;
+    const int b_tapstride = a.CoutPad * Cin * 4;
     const int woff = (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
 
     // ---- per-lane fragment read offsets (4 octets of the 32-channel K-step)
@@ -96,66 +114,125 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
     const int KC = Cin >> 5;
     const int KS = a.taps * KC;
     v4f ra[NA], rb[NB];
-    int ky = 0, kx = 0, kc = 0, tap = 0;   // coordinates of the NEXT K-step to load
-
+    unsigned offc[NA], offn[NA];       // A offsets of the load stream's tap and of the next tap
+    int ltap = 0, lkc = 0, kload = 0;  // coordinates of the NEXT K-step to load
+    tap_offsets(0, offc);
+    tap_offsets(1, offn);
     auto gload = [&]() {
+        const int so = lkc * 128;      // scalar offset: 32 channels per K-step
 #pragma unroll
-        for (int u = 0; u < NA; ++u) {
-            const int iy = aiy0[u] + ky, ix = aix0[u] + kx;
-            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (ok) v = *(const v4f *)(arow[u] + (long long)(iy * W + ix) * Cin + kc * 32);
-            ra[u] = v;
-        }
+        for (int u = 0; u < NA; ++u)
+            ra[u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)offc[u], so, 0));
 #pragma unroll
         for (int u = 0; u < NB; ++u)
-            rb[u] = *(const v4f *)(brow + tap * b_tapstride + u * b_ustride + kc * 32);
-        if (++kc == KC) {
-            kc = 0;
-            ++tap;
-            if (++kx == 3) { kx = 0; ++ky; }
+            rb[u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(brsrc, bvoff + u * b_ustride, ltap * b_tapstride + so, 0));
+    };
+    // advance the load stream by one K-step (uniform branch once per tap; kept out of the
+    // MFMA phases).  Past the last step the counters stay put: the software pipeline's
+    // surplus prefetch re-reads valid memory.
+    auto gadvance = [&]() {
+        if (++kload < KS) {
+            if (++lkc == KC) {
+                lkc = 0;
+                ++ltap;
+#pragma unroll
+                for (int u = 0; u < NA; ++u) offc[u] = offn[u];
+                tap_offsets(ltap + 1, offn);
+            }
         }
     };
     auto lstore = [&](int stage) {
         unsigned char *base = lds + stage * STAGE;
 #pragma unroll
-        for (int u = 0; u < NA; ++u) *(v4f *)(base + woff + u * 4096) = ra[u];
+        for (int u = 0; u < NA; ++u) *(v4f *)(base + woff + u * (RPP * 128)) = ra[u];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) *(v4f *)(base + A_BYTES + woff + u * 4096) = rb[u];
+        for (int u = 0; u < NB; ++u) *(v4f *)(base + A_BYTES + woff + u * (RPP * 128)) = rb[u];
     };
-    auto compute = [&](int stage) {
+    // ---- fragment reads / MFMA phases -------------------------------------------------
+    // A K-step is four phases (one 8-channel octet each, 4*WM*WN MFMAs = 4*WM*WN*64 pipe
+    // cycles).  Phase g issues the LDS reads of octet g+1 FIRST and then its MFMAs, so a
+    // fragment has a whole phase to arrive (v_mfma issue is in order: a wave that waits
+    // for an LDS read right before an MFMA leaves the matrix pipe idle, and the partner
+    // wave on the SIMD runs the same program in lockstep and does not cover it).  The
+    // barrier sits between phases 2 and 3; right after it the wave reads octet 0 of the
+    // NEXT stage, which then has phase 3's MFMAs to arrive.
+    auto rdfrag = [&](int stage, int g, v4f (&af)[WM], v4f (&bf)[WN]) {
         const unsigned char *abase = lds + stage * STAGE + wave_m * WM * 4096;
         const unsigned char *bbase = lds + stage * STAGE + A_BYTES + wave_n * WN * 4096;
-        // all 16 fragment reads of the K-step are issued up front; the MFMAs of octet g
-        // only wait for their own operands (counted lgkmcnt), later reads stay in flight.
-        v4f af[4][WM], bf[4][WN];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int i = 0; i < WM; ++i) af[i] = *(const v4f *)(abase + i * 4096 + roff[g]);
 #pragma unroll
-            for (int i = 0; i < WM; ++i) af[g][i] = *(const v4f *)(abase + i * 4096 + roff[g]);
+        for (int j = 0; j < WN; ++j) bf[j] = *(const v4f *)(bbase + j * 4096 + roff[g]);
+    };
+    auto mfma16 = [&](const v4f (&af)[WM], const v4f (&bf)[WN]) {
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bf[g][j] = *(const v4f *)(bbase + j * 4096 + roff[g]);
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+    };
+    constexpr int PM = 4 * WM * WN;          // MFMAs per phase
+    constexpr int NFR = WM + WN;             // LDS reads per fragment set
+    // scheduling request for one phase: `nrd` LDS reads first, then every MFMA followed by
+    // a few scalar/vector ALU ops and, while they last, one LDS write / one global load.
+    auto phase_sched = [&](int nrd, int nwr, int nld) {
+        if (nrd) __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);
+#pragma unroll
+        for (int i = 0; i < PM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < nwr) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if (i < nld) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i][t], bf[g][j][t], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
+    v4f fa0[WM], fb0[WN], fa1[WM], fb1[WN];
     gload();
+    gadvance();
     lstore(0);
+    gload();
+    gadvance();
     __syncthreads();
-    for (int ks = 0; ks < KS; ++ks) {
-        const bool more = ks + 1 < KS;
-        if (more) gload();
-        compute(ks & 1);
-        if (more) lstore((ks + 1) & 1);
-        __syncthreads();
+    rdfrag(0, 0, fa0, fb0);
+    if (KS > 1) {
+      int ks = 0;
+      do {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        // phase 0: registers (step ks+1) -> LDS stage nxt
+        if (DBG < 2) rdfrag(cur, 1, fa1, fb1);
+        if (DBG < 1) lstore(nxt);
+        mfma16(fa0, fb0);
+        phase_sched(1, NA + NB, 0);
+        // phase 1: global loads of step ks+2 -> registers
+        if (DBG < 2) rdfrag(cur, 2, fa0, fb0);
+        if (DBG < 1) gload();
+        mfma16(fa1, fb1);
+        phase_sched(1, 0, NA + NB);
+        // phase 2
+        if (DBG < 2) rdfrag(cur, 3, fa1, fb1);
+        mfma16(fa0, fb0);
+        phase_sched(1, 0, 0);
+        // every wave has read stage cur and written stage nxt
+        if (DBG < 3) __syncthreads();
+        // phase 3: first fragment of the next K-step, last MFMAs of this one
+        if (DBG < 2) rdfrag(nxt, 0, fa0, fb0);
+        mfma16(fa1, fb1);
+        phase_sched(1, 0, 0);
+        gadvance();
+      } while (++ks < KS - 1);
+    }
+    {   // last K-step: nothing left to stage
+        const int cur = (KS - 1) & 1;
+        rdfrag(cur, 1, fa1, fb1);
+        mfma16(fa0, fb0);
+        rdfrag(cur, 2, fa0, fb0);
+        mfma16(fa1, fb1);
+        rdfrag(cur, 3, fa1, fb1);
+        mfma16(fa0, fb0);
+        mfma16(fa1, fb1);
     }
 
     // ---- epilogue: batch norm / bias / upsample-add / activation, straight from the
@@ -208,16 +285,25 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
     }
 }
 
-int igemm_tile_bm(int) { return 128; }
-int igemm_tile_bn(int tile) { return tile == IGEMM_128x128 ? 128 : (tile == IGEMM_128x64 ? 64 : 32); }
+int igemm_tile_bm(int tile) { return tile == IGEMM_256x128 ? 256 : 128; }
+int igemm_tile_bn(int tile)
+{
+    switch (tile) {
+    case IGEMM_128x256: return 256;
+    case IGEMM_128x128: case IGEMM_256x128: return 128;
+    case IGEMM_128x64: return 64;
+    case IGEMM_128x32: return 32;
+    default: return 128;   // diagnostic variants of 128x128
+    }
+}
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int DBG = 0>
 static hipError_t launch_t(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
     constexpr int lds_bytes = 2 * (BM + BN) * 128;
     static bool attr_set = false;
-    auto k = igemm_kernel<WAVES_M, WAVES_N, WM, WN>;
+    auto k = igemm_kernel<WAVES_M, WAVES_N, WM, WN, DBG>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -225,19 +311,24 @@ static hipError_t launch_t(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
     }
     const long long nblk = (long long)total_tiles_m * a.n_tiles_n;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), lds_bytes, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 {
     // host-side shape checks: the kernel assumes them
-    if (a.Cin % 32 != 0 || a.CoutPad % igemm_tile_bn(tile) != 0 || (a.taps != 1 && a.taps != 9)) return hipErrorInvalidValue;
-    if (a.n_tiles_n * igemm_tile_bn(tile) != a.CoutPad || a.nlevels < 1 || a.nlevels > SSD_MAX_LEVELS) return hipErrorInvalidValue;
+    if (a.Cin % 32 != 0 || a.CoutPad % igemm_tile_bn(tile >= 10 ? 0 : tile) != 0 || (a.taps != 1 && a.taps != 9)) return hipErrorInvalidValue;
+    if (a.n_tiles_n * igemm_tile_bn(tile >= 10 ? 0 : tile) != a.CoutPad || a.nlevels < 1 || a.nlevels > SSD_MAX_LEVELS) return hipErrorInvalidValue;
     switch (tile) {
     case IGEMM_128x128: return launch_t<2, 2, 2, 2>(a, total_tiles_m, s);
     case IGEMM_128x64: return launch_t<4, 1, 1, 2>(a, total_tiles_m, s);
     case IGEMM_128x32: return launch_t<4, 1, 1, 1>(a, total_tiles_m, s);
+    case IGEMM_128x256: return launch_t<2, 4, 2, 2>(a, total_tiles_m, s);
+    case IGEMM_256x128: return launch_t<4, 2, 2, 2>(a, total_tiles_m, s);
+    case 10: return launch_t<2, 2, 2, 2, 1>(a, total_tiles_m, s);
+    case 11: return launch_t<2, 2, 2, 2, 2>(a, total_tiles_m, s);
+    case 12: return launch_t<2, 2, 2, 2, 3>(a, total_tiles_m, s);
     }
     return hipErrorInvalidValue;
 }
