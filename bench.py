@@ -29,27 +29,49 @@ PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_
 PARAMS = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80,
           "score_threshold": 0.15, "iou_threshold": 0.6, "max_boxes_per_class": 25,
           "min_dimension": 640}       # config_mobilenet.json:7-12,21
-LOGITS_BIAS = -4.0                    # random heads at the reference's -log(99) emit nothing; see DESIGN.md
+# Random-init heads have no trained sparsity: with the tower activations of the seeded weights the
+# logits are ~N(bias, 1.6).  -7.5 puts ~6.5k (anchor, class) scores above score_threshold per
+# image and ~190 detections after NMS -- a busy-scene RetinaNet output.  (The reference's own
+# init, -log(99), would leave 250k candidates / 1600 detections per image: tests/ use such
+# dense settings as an NMS stress, the benchmark does not.)  See DESIGN.md section 6.
+LOGITS_BIAS = -7.5
 
 
 def cpu_baseline(budget_s=12.0):
     """The CPU oracle (a port of the reference graph, oracle/) on this host's cores, one
-    640x896 frame at a time (the reference graph is batch 1), bounded to ~budget_s."""
+    640x896 frame at a time (the reference graph is batch 1), bounded to ~budget_s.  The
+    OpenMP thread count is calibrated first (one frame each): on a many-core, multi-socket
+    host the batch-1 graph runs fastest well below the full core count."""
     from oracle import graph, ops
     ops.build()
     Wt = ssd_amd.synthetic_weights(PARAMS, seed=0, logits_bias=LOGITS_BIAS)
     img = np.random.default_rng(0).integers(0, 256, (1, H, W, 3), dtype=np.uint8)
-    graph.forward(img, Wt, PARAMS)                      # warm-up (threads, page faults)
-    times = []
-    t_end = time.perf_counter() + budget_s
-    while len(times) < 20 and (len(times) < 2 or time.perf_counter() < t_end):
+
+    def frame():
         t0 = time.perf_counter()
         graph.forward(img, Wt, PARAMS)
-        times.append(time.perf_counter() - t0)
+        return time.perf_counter() - t0
+
+    ncpu = os.cpu_count() or 1
+    cands = sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu} or {ncpu})
+    best_t, best = cands[0], None
+    for t in cands:
+        ops.set_num_threads(t)
+        frame()                                          # warm-up (threads, page faults)
+        dt = frame()
+        if best is None or dt < best:
+            best_t, best = t, dt
+        if dt > 3.0:
+            break
+    ops.set_num_threads(best_t)
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 30 and (len(times) < 3 or time.perf_counter() < t_end):
+        times.append(frame())
     med = float(np.median(times))
-    return {"value": 1.0 / med, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d frames of 640x896, batch 1, C oracle (OpenMP, AVX2 fmaf chains), median %.3f s/frame"
-                      % (len(times), med)}
+    return {"value": 1.0 / med, "unit": "img/s", "cores": best_t, "kind": "port",
+            "sample": "%d frames of 640x896, batch 1, C oracle (OpenMP %d threads of %d logical CPUs, AVX2 fmaf "
+                      "chains), median %.3f s/frame" % (len(times), best_t, ncpu, med)}
 
 
 def latency_batch1(engine, dev):
@@ -131,6 +153,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert out[0].shape[0] == B * world
+    det_per_image = float(out[3].float().mean().item())
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -138,6 +161,10 @@ def main():
         avg_ms = c3["ms"] / max(c3["launches"], 1)
         flops_per_launch = c3["flops"] / max(c3["launches"], 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # from scripts/collect_profiles.sh (separate PMC passes)
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         res = {
             "metric": "images/sec at 896x640, MobileNet-v1 RetinaNet (whole hot path incl. decode + per-class NMS)",
             "value": B * world * args.steps / dt, "unit": "img/s", "n_gpus": world,
@@ -148,9 +175,10 @@ def main():
                                    "uint8 frames, %d per GPU (BASELINE config 5 shard; config 2 = same graph at batch 1, "
                                    "see latency_batch1)" % B,
                        "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W,
-                       "parallelism": "dp%d" % world, "weights": "random-init (seed 0), logits bias %.1f" % LOGITS_BIAS},
+                       "parallelism": "dp%d" % world, "weights": "random-init (seed 0), logits bias %.1f" % LOGITS_BIAS,
+                       "detections_per_image": det_per_image},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel": "igemm_kernel (3x3 convs: FPN outputs + head towers + class/box heads)",
                          "launches_per_step": c3["launches"] / args.steps, "avg_launch_ms": avg_ms,
                          "algorithmic_gflop_per_launch": flops_per_launch / 1e9},

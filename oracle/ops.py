@@ -39,6 +39,14 @@ def lib():
     return _lib
 
 
+def set_num_threads(n):
+    lib().orc_set_num_threads(_i(int(n)))
+
+
+def get_max_threads():
+    return int(lib().orc_get_max_threads())
+
+
 def _p(a, ty=ctypes.c_float):
     return a.ctypes.data_as(ctypes.POINTER(ty))
 

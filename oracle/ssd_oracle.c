@@ -38,6 +38,15 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+#ifdef _OPENMP
+#include <omp.h>
+ORC_API void orc_set_num_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+ORC_API int orc_get_max_threads(void) { return omp_get_max_threads(); }
+#else
+ORC_API void orc_set_num_threads(int n) { (void)n; }
+ORC_API int orc_get_max_threads(void) { return 1; }
+#endif
+
 /* ------------------------------------------------------------------------- */
 /* create_pb.py:42-47 + mobilenet_v1.py:34 / shufflenet_v2.py:37             */
 /* uint8 -> float, *(1/255), then 2*x - 1 (two separately rounded ops).      */
@@ -117,10 +126,12 @@ ORC_API void orc_conv2d(const float *in, int B, int H, int W, int Cin, const flo
 #ifdef __AVX2__
     if (Cout % 16 == 0) {
         float *zeros = (float *)calloc((size_t)Cin, sizeof(float));
-#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+        const int nxb = (OW + PB - 1) / PB;
+#pragma omp parallel for collapse(3) schedule(dynamic, 4)
         for (int b = 0; b < B; ++b)
             for (int oy = 0; oy < OH; ++oy) {
-                for (int ox0 = 0; ox0 < OW; ox0 += PB) {
+                for (int xb = 0; xb < nxb; ++xb) {
+                    const int ox0 = xb * PB;
                     int np = OW - ox0 < PB ? OW - ox0 : PB;
                     for (int n0 = 0; n0 < Cout; n0 += 16) {
                         __m256 acc[PB][2];

@@ -1,0 +1,51 @@
+"""Condenses a scripts/collect_profiles.sh output directory into the files committed under
+profiles/: kernel_stats.csv (rocprofv3 --stats), pmc_summary.txt (per-kernel means of the
+PMC passes, with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md applied)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+out = sys.argv[1]
+stats = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
+if stats:
+    shutil.copy(stats[0], out + "/kernel_stats.csv")
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+dur = collections.defaultdict(list)
+for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][:56]
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][:56]
+        dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+with open(out + "/pmc_summary.txt", "w") as fo:
+    fo.write("# per-dispatch means; FETCH/WRITE in KB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024\n")
+    fo.write("# (gfx950: FETCH_SIZE reports half of a wide coalesced read stream, MI355X_MICROARCH.md section HBM)\n")
+    for k in sorted(agg, key=lambda k: -sum(dur.get(k, [0]))):
+        d = agg[k]
+        m = {c: sum(v) / len(v) for c, v in d.items()}
+        line = "%s  launches(traced)=%d avg_ms=%.4f\n" % (k, len(dur.get(k, [])), (sum(dur[k]) / len(dur[k])) if dur.get(k) else float("nan"))
+        fo.write(line)
+        if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+            fo.write("    hbm_bytes_per_launch=%.4g (fetch_kb=%.4g write_kb=%.4g)\n" % ((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024, m["FETCH_SIZE"], m["WRITE_SIZE"]))
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m and m["GRBM_GUI_ACTIVE"] > 0:
+            fo.write("    mfma_util=%.3f (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs))\n" % (m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8 * 1024)))
+        for c in sorted(m):
+            fo.write("    %-28s %.6g\n" % (c, m[c]))
+# traffic of the dominant kernel (3x3 implicit GEMM) for bench.py's roofline.traffic
+dom = [k for k in agg if "igemm_kernel<2, 2, 2, 2, 9" in k]
+if dom and "FETCH_SIZE" in agg[dom[0]] and "WRITE_SIZE" in agg[dom[0]]:
+    f = agg[dom[0]]["FETCH_SIZE"]; w = agg[dom[0]]["WRITE_SIZE"]
+    t = {"kernel": dom[0], "hbm_bytes_per_launch": (2 * sum(f) / len(f) + sum(w) / len(w)) * 1024,
+         "launches_averaged": len(f), "correction": "FETCH_SIZE x2 (gfx950), KB -> bytes",
+         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py"}
+    json.dump(t, open(out + "/traffic.json", "w"), indent=1)
+    print(t)
+print(open(out + "/pmc_summary.txt").read()[:3000])
+if os.path.exists(out + "/bench.json"):
+    print(open(out + "/bench.json").read())

@@ -24,7 +24,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 // DBG (timing experiments only, results are wrong): 1 = no global loads / LDS writes in the
 // K loop, 2 = additionally no LDS fragment reads, 3 = additionally no barrier.
-template <int WAVES_M, int WAVES_N, int WM, int WN, int DBG = 0>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int DBG = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const IgemmArgs a)
 {
     constexpr int NT = 64 * WAVES_M * WAVES_N;   // threads per block (256 or 512)
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(a.in + L.in_off), 0, (int)((long long)a.B * H * W * Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)a.wt, 0, (int)((long long)a.taps * a.CoutPad * Cin * 4), 0x00020000);
+        (void *)a.wt, 0, (int)((long long)TAPS * a.CoutPad * Cin * 4), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     int abase[NA], aiy0[NA], aix0[NA];      // byte offset of the row's image, top-left tap coordinate
 #pragma unroll
@@ -84,11 +84,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     }
     // byte offsets of this thread's A chunks for filter tap `t` (OOB when the tap is padding)
     auto tap_offsets = [&](int t, unsigned (&off)[NA]) {
-        const int tky = a.taps == 9 ? t / 3 : 0, tkx = a.taps == 9 ? t - 3 * tky : 0;
+        const int tky = TAPS == 9 ? t / 3 : 0, tkx = TAPS == 9 ? t - 3 * tky : 0;
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int iy = aiy0[u] + tky, ix = aix0[u] + tkx;
-            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && t < a.taps;
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && t < TAPS;
             off[u] = ok ? (unsigned)(abase[u] + (iy * W + ix) * Cin * 4) : OOB;
         }
     };
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int KC = Cin >> 5;
-    const int KS = a.taps * KC;
+    const int KS = TAPS * KC;
     v4f ra[NA], rb[NB];
     unsigned offc[NA], offn[NA];       // A offsets of the load stream's tap and of the next tap
     int ltap = 0, lkc = 0, kload = 0;  // coordinates of the NEXT K-step to load
@@ -297,13 +297,13 @@ int igemm_tile_bn(int tile)
     }
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int DBG = 0>
-static hipError_t launch_t(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int DBG = 0>
+static hipError_t launch_tt(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
     constexpr int lds_bytes = 2 * (BM + BN) * 128;
     static bool attr_set = false;
-    auto k = igemm_kernel<WAVES_M, WAVES_N, WM, WN, DBG>;
+    auto k = igemm_kernel<WAVES_M, WAVES_N, WM, WN, TAPS, DBG>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -315,10 +315,21 @@ static hipError_t launch_t(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
     return hipGetLastError();
 }
 
+template <int WAVES_M, int WAVES_N, int WM, int WN, int DBG = 0>
+static hipError_t launch_t(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
+{
+    return a.taps == 9 ? launch_tt<WAVES_M, WAVES_N, WM, WN, 9, DBG>(a, total_tiles_m, s)
+                       : launch_tt<WAVES_M, WAVES_N, WM, WN, 1, DBG>(a, total_tiles_m, s);
+}
+
 hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 {
     // host-side shape checks: the kernel assumes them
     if (a.Cin % 32 != 0 || a.CoutPad % igemm_tile_bn(tile >= 10 ? 0 : tile) != 0 || (a.taps != 1 && a.taps != 9)) return hipErrorInvalidValue;
+    // 32-bit byte offsets inside buffer resources: every tensor of a launch stays < 2 GiB
+    if ((long long)a.taps * a.CoutPad * a.Cin * 4 >= (1LL << 31)) return hipErrorInvalidValue;
+    for (int i = 0; i < a.nlevels; ++i)
+        if ((long long)a.B * a.lv[i].H * a.lv[i].W * a.Cin * 4 >= (1LL << 31)) return hipErrorInvalidValue;
     if (a.n_tiles_n * igemm_tile_bn(tile >= 10 ? 0 : tile) != a.CoutPad || a.nlevels < 1 || a.nlevels > SSD_MAX_LEVELS) return hipErrorInvalidValue;
     switch (tile) {
     case IGEMM_128x128: return launch_t<2, 2, 2, 2>(a, total_tiles_m, s);

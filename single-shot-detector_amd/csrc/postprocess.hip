@@ -76,10 +76,15 @@ __device__ __forceinline__ bool iou_greater(const v4f bi, const v4f bj, float th
     return valid & (iou > thr);
 }
 
-__device__ __forceinline__ void emit_candidate(const PostArgs &p, int b, int i, int c, float logit)
+// One candidate (logit above the conservative bound): exact score, strict threshold,
+// append to its (image, class) list, decode the anchor's box.
+__device__ __forceinline__ void emit_candidate(const PostArgs &p, unsigned elem, float logit)
 {
     const float s = sigmoid_cr(logit);
     if (!(s > p.score_thr)) return;
+    const int c = (int)(elem % (unsigned)p.C);
+    const unsigned row = elem / (unsigned)p.C;
+    const int i = (int)(row % (unsigned)p.N), b = (int)(row / (unsigned)p.N);
     const int slot = atomicAdd(&p.counts[b * p.C + c], 1);
     p.keys[((long long)b * p.C + c) * p.N + slot] = ((u64)__float_as_uint(s) << 32) | (u64)(0xFFFFFFFFu - (unsigned)i);
     const v4f code = *(const v4f *)(p.codes + ((long long)b * p.N + i) * 4);
@@ -87,37 +92,67 @@ __device__ __forceinline__ void emit_candidate(const PostArgs &p, int b, int i, 
     *(v4f *)(p.dec + ((long long)b * p.N + i) * 4) = decode_clip(code, anc);
 }
 
+// K9a.  The scan itself is a pure HBM stream; the rare logits above the bound are pushed
+// into a per-block LDS queue and the queue is drained DENSELY by all 256 threads (the
+// double-precision sigmoid / exp and the atomics would otherwise run with one active lane
+// per wave).  The element index fits 32 bits (host check: B*N*C < 2^32).
+#define SCAN_U 4                       // 16-B loads in flight per thread
+#define SCAN_Q (2048 + 256 * SCAN_U * 4)
 __global__ __launch_bounds__(256) void post_scan_kernel(const PostArgs p)
 {
+    __shared__ unsigned q_elem[SCAN_Q];
+    __shared__ float q_val[SCAN_Q];
+    __shared__ int q_n;
     const int C = p.C;
-    if ((C & 3) == 0) {
-        const int C4 = C >> 2;
-        const long long total = (long long)p.B * p.N * C4;
-        for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-             idx += (long long)gridDim.x * blockDim.x) {
-            const v4f x = *(const v4f *)(p.logits + idx * 4);
-            const float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
-            if (mx >= p.logit_lo) {
-                const int q = (int)(idx % C4);
-                const long long row = idx / C4;
-                const int i = (int)(row % p.N), b = (int)(row / p.N);
+    const bool vec = (C & 3) == 0;
+    const long long total = vec ? (long long)p.B * p.N * (C >> 2) : (long long)p.B * p.N * C;
+    if (threadIdx.x == 0) q_n = 0;
+    __syncthreads();
+    auto drain = [&]() {
+        const int n = q_n;
+        for (int t = threadIdx.x; t < n; t += 256) emit_candidate(p, q_elem[t], q_val[t]);
+        __syncthreads();
+        if (threadIdx.x == 0) q_n = 0;
+        __syncthreads();
+    };
+    auto push = [&](unsigned elem, float v) {
+        const int slot = atomicAdd(&q_n, 1);
+        q_elem[slot] = elem;
+        q_val[slot] = v;
+    };
+    const long long stride = (long long)gridDim.x * 256 * SCAN_U;
+    for (long long base = (long long)blockIdx.x * 256 * SCAN_U; base < total; base += stride) {
+        if (vec) {
+            v4f x[SCAN_U];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (x[k] >= p.logit_lo) emit_candidate(p, b, i, q * 4 + k, x[k]);
+            for (int u = 0; u < SCAN_U; ++u) {
+                const long long idx = base + u * 256 + threadIdx.x;
+                x[u] = idx < total ? *(const v4f *)(p.logits + idx * 4) : (v4f){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+#pragma unroll
+            for (int u = 0; u < SCAN_U; ++u) {
+                const long long idx = base + u * 256 + threadIdx.x;
+                const float mx = fmaxf(fmaxf(x[u][0], x[u][1]), fmaxf(x[u][2], x[u][3]));
+                if (mx >= p.logit_lo) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (x[u][k] >= p.logit_lo) push((unsigned)(idx * 4 + k), x[u][k]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < SCAN_U; ++u) {
+                const long long idx = base + u * 256 + threadIdx.x;
+                if (idx < total) {
+                    const float x = p.logits[idx];
+                    if (x >= p.logit_lo) push((unsigned)idx, x);
+                }
             }
         }
-    } else {
-        const long long total = (long long)p.B * p.N * C;
-        for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-             idx += (long long)gridDim.x * blockDim.x) {
-            const float x = p.logits[idx];
-            if (x >= p.logit_lo) {
-                const int c = (int)(idx % C);
-                const long long row = idx / C;
-                emit_candidate(p, (int)(row / p.N), (int)(row % p.N), c, x);
-            }
-        }
+        __syncthreads();
+        if (q_n > 2048) drain();               // uniform: q_n is stable between the barriers
     }
+    drain();
 }
 
 __device__ __forceinline__ u64 wave_max_u64(u64 v)
@@ -132,24 +167,27 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v)
     return v;
 }
 
-#define NMS_R 8   // candidates per lane kept in registers (fast path: n <= 64*NMS_R)
+#define NMS_R 8      // candidates per thread kept in registers
+#define NMS_BIG 1024 // threads of the large-list kernel
 
-__global__ __launch_bounds__(64) void post_nms_kernel(const PostArgs p)
+// K9c, lists of up to 64*NMS_R candidates: one wavefront, everything in registers.
+// keys and boxes are immutable; liveness is one bit per register slot.  (A version that
+// zeroed key[r] under `key == best || iou > thr` was miscompiled by hipcc 7.2: the kill of
+// the IoU branch was dropped -- keep this form branch-free.)
+__global__ __launch_bounds__(64) void post_nms_small_kernel(const PostArgs p)
 {
     const int bc = blockIdx.x;              // b*C + c
     const int b = bc / p.C;
     const int lane = threadIdx.x;
     int n = p.counts[bc];
     if (n > p.N) n = p.N;
-    u64 *keys = p.keys + (long long)bc * p.N;
+    if (n > p.fast_max) return;             // handled by post_nms_big_kernel
+    const u64 *keys = p.keys + (long long)bc * p.N;
     const float *dec = p.dec + (long long)b * p.N * 4;
     float *ob = p.cls_boxes + (long long)bc * p.max_per_class * 4;
     float *os = p.cls_scores + (long long)bc * p.max_per_class;
     int kept = 0;
-    if (n > 0 && n <= p.fast_max) {
-        // keys and boxes are immutable; liveness is one bit per register slot.  (A version
-        // that zeroed key[r] under `key == best || iou > thr` was miscompiled by hipcc
-        // 7.2: the kill of the IoU branch was dropped -- keep this form branch-free.)
+    if (n > 0) {
         u64 key[NMS_R];
         v4f box[NMS_R];
         unsigned alive = 0;
@@ -185,31 +223,141 @@ __global__ __launch_bounds__(64) void post_nms_kernel(const PostArgs p)
             }
             alive &= ~kill;
         }
-    } else if (n > 0) {
-        // any candidate count: keys stay in global memory, dead candidates are zeroed
-        while (kept < p.max_per_class) {
-            u64 best = 0;
-            for (int i = lane; i < n; i += 64) {
+    }
+    if (lane == 0) p.cls_counts[bc] = kept;
+}
+
+// K9c, longer lists: 1024 threads per (image, class).  Up to 1024*NMS_R candidates live in
+// registers (same scheme, block-wide arg-max through LDS); beyond that the keys stay in
+// global memory and dead candidates are zeroed there.
+__global__ __launch_bounds__(NMS_BIG) void post_nms_big_kernel(const PostArgs p)
+{
+    __shared__ u64 wbest[2][NMS_BIG / 64];
+    const int bc = blockIdx.x;
+    const int b = bc / p.C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int n = p.counts[bc];
+    if (n > p.N) n = p.N;
+    if (n <= p.fast_max) return;            // whole block leaves: handled by the small kernel
+    u64 *keys = p.keys + (long long)bc * p.N;
+    const float *dec = p.dec + (long long)b * p.N * 4;
+    float *ob = p.cls_boxes + (long long)bc * p.max_per_class * 4;
+    float *os = p.cls_scores + (long long)bc * p.max_per_class;
+    // Lists longer than the register capacity: greedy NMS only consumes candidates in
+    // descending score order until max_per_class boxes are kept, so first try the top
+    // scores alone -- a score histogram picks the largest score cut that leaves at most
+    // CAP candidates, those are compacted into LDS and processed in registers.  If that
+    // keeps max_per_class boxes the result is exact; otherwise (rare: massive ties or
+    // massive suppression) everything is redone by the global-memory path below.
+    constexpr int CAP = NMS_BIG * NMS_R;
+    constexpr int NBIN = 4096;
+    __shared__ unsigned hist[NBIN];
+    __shared__ u64 chunk[CAP];
+    __shared__ int chunk_n, cut_bin;
+    const unsigned lo_bits = __float_as_uint(p.score_thr > 0.0f ? p.score_thr : 0.0f);
+    int shift = 0;
+    while (((0x3F800000u - lo_bits) >> shift) >= (unsigned)NBIN) ++shift;
+    bool in_regs = n <= CAP, trial = false;
+    int nn = n;                              // candidates resident in registers
+    if (!in_regs) {
+        for (int i = tid; i < NBIN; i += NMS_BIG) hist[i] = 0;
+        if (tid == 0) chunk_n = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += NMS_BIG) {
+            const unsigned sb = (unsigned)(keys[i] >> 32);
+            atomicAdd(&hist[(sb - lo_bits) >> shift], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned cum = 0;
+            int bin = NBIN;                  // keep bins >= cut_bin
+            while (bin > 0 && cum + hist[bin - 1] <= (unsigned)CAP) { cum += hist[bin - 1]; --bin; }
+            cut_bin = bin;
+        }
+        __syncthreads();
+        const int cb = cut_bin;
+        for (int i = tid; i < n; i += NMS_BIG) {
+            const u64 k = keys[i];
+            if ((int)(((unsigned)(k >> 32) - lo_bits) >> shift) >= cb) chunk[atomicAdd(&chunk_n, 1)] = k;
+        }
+        __syncthreads();
+        nn = chunk_n;
+        trial = nn >= p.max_per_class;       // fewer than the cap can never fill it: skip the trial
+        in_regs = trial;
+    }
+    int kept = 0;
+    u64 key[NMS_R];
+    v4f box[NMS_R];
+    unsigned alive = 0;
+restart:
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < NMS_R; ++r) {
+            const int i = tid + NMS_BIG * r;
+            const bool ok = i < nn;
+            key[r] = ok ? (trial ? chunk[ok ? i : 0] : keys[ok ? i : 0]) : 0ull;
+            const unsigned anchor = 0xFFFFFFFFu - (unsigned)(key[r] & 0xFFFFFFFFu);
+            box[r] = *(const v4f *)(dec + (long long)(ok ? anchor : 0u) * 4);
+            alive |= ok ? (1u << r) : 0u;
+        }
+    }
+    while (kept < p.max_per_class) {        // uniform trip count: `best` is block-uniform
+        u64 best = 0;
+        if (in_regs) {
+#pragma unroll
+            for (int r = 0; r < NMS_R; ++r) {
+                const u64 k = ((alive >> r) & 1u) ? key[r] : 0ull;
+                best = k > best ? k : best;
+            }
+        } else {
+            for (int i = tid; i < n; i += NMS_BIG) {
                 const u64 k = keys[i];
                 best = k > best ? k : best;
             }
-            best = wave_max_u64(best);
-            if (best == 0) break;
-            const v4f wb = *(const v4f *)(dec + (long long)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFu)) * 4);
-            if (lane == 0) {
-                *(v4f *)(ob + kept * 4) = wb;
-                os[kept] = __uint_as_float((unsigned)(best >> 32));
+        }
+        best = wave_max_u64(best);
+        const int buf = kept & 1;
+        if (lane == 0) wbest[buf][wave] = best;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NMS_BIG / 64; ++w) {
+            const u64 o = wbest[buf][w];
+            best = o > best ? o : best;
+        }
+        if (best == 0) break;
+        const v4f wb = *(const v4f *)(dec + (long long)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFu)) * 4);
+        if (tid == 0) {
+            *(v4f *)(ob + kept * 4) = wb;
+            os[kept] = __uint_as_float((unsigned)(best >> 32));
+        }
+        ++kept;
+        if (in_regs) {
+            unsigned kill = 0;
+#pragma unroll
+            for (int r = 0; r < NMS_R; ++r) {
+                const bool k = (key[r] == best) | iou_greater(box[r], wb, p.iou_thr);
+                kill |= k ? (1u << r) : 0u;
             }
-            ++kept;
-            for (int i = lane; i < n; i += 64) {
+            alive &= ~kill;
+        } else {
+            for (int i = tid; i < n; i += NMS_BIG) {
                 const u64 k = keys[i];
-                if (k == 0) continue;
-                const v4f bx = *(const v4f *)(dec + (long long)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu)) * 4);
-                if (k == best || iou_greater(bx, wb, p.iou_thr)) keys[i] = 0;
+                const unsigned anchor = k ? 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu) : 0u;   // dead: any mapped box
+                const v4f bx = *(const v4f *)(dec + (long long)anchor * 4);
+                const bool kill = (k == best) | iou_greater(bx, wb, p.iou_thr);
+                if (k != 0 && kill) keys[i] = 0;
             }
         }
     }
-    if (lane == 0) p.cls_counts[bc] = kept;
+    if (trial && kept < p.max_per_class) {   // block-uniform: the cut did not suffice -> exact redo
+        __syncthreads();
+        trial = false;
+        in_regs = false;
+        kept = 0;
+        alive = 0;
+        goto restart;
+    }
+    if (tid == 0) p.cls_counts[bc] = kept;
 }
 
 __global__ __launch_bounds__(256) void post_pack_kernel(const PostArgs p)
@@ -278,13 +426,15 @@ hipError_t launch_postprocess(const PostArgs &pin, hipStream_t s)
     p.fast_max = 64 * NMS_R;
     if (const char *e = getenv("SSD_NMS_FAST_MAX")) { int v = atoi(e); if (v >= 0 && v < p.fast_max) p.fast_max = v; }
     if (p.B < 1 || p.N < 1 || p.C < 1 || p.max_per_class < 1) return hipErrorInvalidValue;
+    if ((long long)p.B * p.N * p.C >= (1LL << 32)) return hipErrorInvalidValue;   // 32-bit element index in the scan queue
     hipError_t e = hipMemsetAsync(p.counts, 0, (size_t)p.B * p.C * sizeof(int), s);
     if (e != hipSuccess) return e;
     const long long units = (long long)p.B * p.N * ((p.C & 3) ? p.C : p.C / 4);
-    long long blocks = (units + 255) / 256;
+    long long blocks = (units + 256 * SCAN_U - 1) / (256 * SCAN_U);
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(post_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(post_nms_kernel, dim3((unsigned)(p.B * p.C)), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(post_nms_small_kernel, dim3((unsigned)(p.B * p.C)), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(post_nms_big_kernel, dim3((unsigned)(p.B * p.C)), dim3(NMS_BIG), 0, s, p);
     hipLaunchKernelGGL(post_pack_kernel, dim3((unsigned)p.B), dim3(256), (p.C + 1) * sizeof(int), s, p);
     return hipGetLastError();
 }
