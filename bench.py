@@ -155,6 +155,18 @@ def main():
     assert out[0].shape[0] == B * world
     det_per_image = float(out[3].float().mean().item())
 
+    # the same step with the boundary's host buffers in the loop (pinned host frames -> HBM,
+    # detections -> host); reported beside `value`, never as `value`
+    host_frames = frames.cpu().pin_memory()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(max(2, args.steps // 2)):
+        d = host_frames.to(dev, non_blocking=True)
+        o = engine.forward(d)
+        _ = [t.cpu() for t in o]
+    torch.cuda.synchronize()
+    pcie_img_s = (hi - lo) * max(2, args.steps // 2) / (time.perf_counter() - t1)
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         c3 = prof["conv3x3_mfma"]
@@ -181,8 +193,10 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel": "igemm_kernel (3x3 convs: FPN outputs + head towers + class/box heads)",
                          "launches_per_step": c3["launches"] / args.steps, "avg_launch_ms": avg_ms,
-                         "algorithmic_gflop_per_launch": flops_per_launch / 1e9},
+                         "algorithmic_gflop_per_launch": flops_per_launch / 1e9,
+                         "algorithmic_gbyte_per_launch": c3["bytes"] / max(c3["launches"], 1) / 1e9},
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
+            "pcie_inclusive_img_s_per_gpu": pcie_img_s,
             "whole_net_roofline_frac": (1.113 * B) / ms_step,       # 1.113 ms/img at the per-layer roofline
         }
         if not args.no_latency:
