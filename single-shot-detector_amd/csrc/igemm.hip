@@ -235,50 +235,84 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         mfma16(fa1, fb1);
     }
 
-    // ---- epilogue: batch norm / bias / upsample-add / activation, straight from the
-    // accumulators (lane = column, 16 registers = 16 rows of the 32x32 tile).
+    // ---- epilogue: batch norm / bias / upsample-add / activation.
+    // The accumulators (lane = column, 16 registers = 16 rows of a 32x32 tile) go through a
+    // per-wave LDS transpose so that every lane ends up with 4 consecutive channels of one
+    // row: 16-B global stores (256 contiguous bytes per row and instruction) and vector loads
+    // of the BN parameters, a quarter of the store instructions of the direct form.
     const bool has_bn = a.mean != nullptr;
+    constexpr int RW = WN * 32;                  // floats per row of the wave's sub-tile
+    constexpr int C4N = RW / 4;                  // 16-B chunks per row
+    constexpr int WAVE_REGION = WM * 32 * RW * 4;
+    static_assert(WAVE_REGION * WAVES_M * WAVES_N <= 2 * STAGE, "epilogue transpose does not fit the staging LDS");
+    __syncthreads();                             // every wave is done with the staging buffers
+    {
+        float *reg = (float *)(lds + wave * WAVE_REGION);
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int col = tile_n * BN + (wave_n * WN + j) * 32 + (lane & 31);
-        const bool colok = col < a.Cout;
-        float mean = 0.0f, sf = 1.0f, beta = 0.0f, bias = 0.0f;
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int col = j * 32 + (lane & 31);
+                    reg[row * RW + (((col >> 2) ^ (row & (C4N - 1))) << 2) + (col & 3)] = acc[i][j][r];
+                }
+        __syncthreads();
+        const int c4 = lane % C4N;
+        const int col = tile_n * BN + wave_n * RW + c4 * 4;
+        const bool colok = col < a.Cout;         // Cout is a multiple of 4 (host check)
+        v4f mean = {0.f, 0.f, 0.f, 0.f}, sf = {1.f, 1.f, 1.f, 1.f}, beta = {0.f, 0.f, 0.f, 0.f}, bias = {0.f, 0.f, 0.f, 0.f};
         if (colok && has_bn) {
-            mean = a.mean[L.param_off + col];
-            sf = a.sf[L.param_off + col];
-            beta = a.beta[L.param_off + col];
+            mean = *(const v4f *)(a.mean + L.param_off + col);
+            sf = *(const v4f *)(a.sf + L.param_off + col);
+            beta = *(const v4f *)(a.beta + L.param_off + col);
         }
-        if (colok && a.bias) bias = a.bias[L.param_off + col];
+        if (colok && a.bias) bias = *(const v4f *)(a.bias + L.param_off + col);
+        constexpr int ROWS_PER_IT = 64 / C4N;
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
+        for (int it = 0; it < WM * 32 / ROWS_PER_IT; ++it) {
+            const int row = it * ROWS_PER_IT + lane / C4N;
+            const int m = m0 + wave_m * WM * 32 + row;
+            const v4f raw = *(const v4f *)(reg + row * RW + ((c4 ^ (row & (C4N - 1))) << 2));
+            if (m < M && colok) {
+                v4f v = raw;
+                if (has_bn) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wave_m * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int m = m0 + row;
-                if (m < M && colok) {
-                    const float raw = acc[i][j][r];
-                    float v = raw;
-                    if (has_bn) {
-                        v = (v - mean) * sf;
-                        v = v + beta;
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = (v[e] - mean[e]) * sf[e];
+                        v[e] = t + beta[e];
                     }
-                    if (a.bias) v = v + bias;
-                    long long off;
-                    if (a.dense_out && !a.res) {
-                        off = L.out_off + (long long)m * L.out_rstride + col;
-                    } else {
-                        const int b = m / P, p = m - b * P;
-                        off = L.out_off + b * L.out_bstride + (long long)p * L.out_rstride + col;
-                        if (a.res) {
-                            const int oy = p / OW, ox = p - oy * OW;
-                            const int ch = L.OH >> 1, cw = OW >> 1;
-                            v = a.res[L.res_off + (((long long)b * ch + (oy >> 1)) * cw + (ox >> 1)) * a.Cout + col] + v;
-                        }
+                }
+                if (a.bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] + bias[e];
+                }
+                long long off;
+                if (a.dense_out && !a.res) {
+                    off = L.out_off + (long long)m * L.out_rstride + col;
+                } else {
+                    const int b = m / P, p = m - b * P;
+                    off = L.out_off + b * L.out_bstride + (long long)p * L.out_rstride + col;
+                    if (a.res) {
+                        const int oy = p / OW, ox = p - oy * OW;
+                        const int ch = L.OH >> 1, cw = OW >> 1;
+                        const v4f rv = *(const v4f *)(a.res + L.res_off + (((long long)b * ch + (oy >> 1)) * cw + (ox >> 1)) * a.Cout + col);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = rv[e] + v[e];
                     }
-                    if (a.act >= 1) v = v > 0.0f ? v : 0.0f;
-                    if (a.act == 2) v = v < 6.0f ? v : 6.0f;
-                    a.out[off] = v;
-                    if (a.out2) a.out2[off] = raw > 0.0f ? raw : 0.0f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (a.act >= 1) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                    if (a.act == 2) v[e] = v[e] < 6.0f ? v[e] : 6.0f;
+                }
+                *(v4f *)(a.out + off) = v;
+                if (a.out2) {
+                    v4f q;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q[e] = raw[e] > 0.0f ? raw[e] : 0.0f;
+                    *(v4f *)(a.out2 + off) = q;
                 }
             }
         }
@@ -325,6 +359,7 @@ static hipError_t launch_t(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 {
     // host-side shape checks: the kernel assumes them
+    if (a.Cout % 4 != 0) return hipErrorInvalidValue;   // 16-B epilogue stores
     if (a.Cin % 32 != 0 || a.CoutPad % igemm_tile_bn(tile >= 10 ? 0 : tile) != 0 || (a.taps != 1 && a.taps != 9)) return hipErrorInvalidValue;
     // 32-bit byte offsets inside buffer resources: every tensor of a launch stays < 2 GiB
     if ((long long)a.taps * a.CoutPad * a.Cin * 4 >= (1LL << 31)) return hipErrorInvalidValue;
@@ -335,8 +370,6 @@ hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStre
     case IGEMM_128x128: return launch_t<2, 2, 2, 2>(a, total_tiles_m, s);
     case IGEMM_128x64: return launch_t<4, 1, 1, 2>(a, total_tiles_m, s);
     case IGEMM_128x32: return launch_t<4, 1, 1, 1>(a, total_tiles_m, s);
-    case IGEMM_128x256: return launch_t<2, 4, 2, 2>(a, total_tiles_m, s);
-    case IGEMM_256x128: return launch_t<4, 2, 2, 2>(a, total_tiles_m, s);
     case 10: return launch_t<2, 2, 2, 2, 1>(a, total_tiles_m, s);
     case 11: return launch_t<2, 2, 2, 2, 2>(a, total_tiles_m, s);
     case 12: return launch_t<2, 2, 2, 2, 3>(a, total_tiles_m, s);
