@@ -9,7 +9,7 @@ from ssd_amd._lib import check
 assert torch.cuda.is_available()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 L = ssd_amd.lib()
-TILES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "128x256", 4: "256x128"}
+TILES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "128x256", 4: "256x128", 5: "64x64"}
 
 
 def run(name, H, W, Cin, Cout, k, stride, tiles, pyramid=0, reps=10):

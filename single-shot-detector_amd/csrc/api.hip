@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -142,6 +143,7 @@ struct DwW { float *w = nullptr, *mean = nullptr, *sf = nullptr, *beta = nullptr
 // ----------------------------------------------------------------------------- ops
 struct Op {
     int cls;            // profile class
+    int stream = 0;     // 0: the caller's stream, 1: the handle's second stream (class tower)
     double flops, bytes;
     std::function<hipError_t(hipStream_t)> run;
 };
@@ -163,11 +165,19 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
     a.B = B; a.Cin = cw.CinP; a.Cout = cw.CoutP; a.CoutPad = cw.CoutPad; a.taps = cw.taps;
     a.stride = stride; a.pad = pad; a.act = act;
     a.nlevels = (int)lv.size();
-    a.n_tiles_n = cw.CoutPad / igemm_tile_bn(cw.tile);
+    // Small problems (batch 1, coarse pyramid levels): 128x128 tiles would leave most of the
+    // 256 CUs with one wave per SIMD or idle; 64x64 tiles give 4x the blocks.
+    int tile = cw.tile;
+    if (tile == IGEMM_128x128 && g_force_tile < 0) {
+        long long t128 = 0;
+        for (size_t i = 0; i < lv.size(); ++i) t128 += ((long long)B * lv[i].OH * lv[i].OW + 127) / 128;
+        if (t128 * (cw.CoutPad / 128) < 2 * 256) tile = IGEMM_64x64;
+    }
+    a.n_tiles_n = cw.CoutPad / igemm_tile_bn(tile);
     a.dense_out = dense ? 1 : 0;
     int tiles = 0;
     double rows = 0, inb = 0;
-    const int BM = igemm_tile_bm(cw.tile);
+    const int BM = igemm_tile_bm(tile);
     for (size_t i = 0; i < lv.size(); ++i) {
         IgemmLevel &L = a.lv[i];
         L.H = lv[i].H; L.W = lv[i].W; L.OH = lv[i].OH; L.OW = lv[i].OW;
@@ -185,7 +195,6 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
     op.cls = cw.taps == 9 ? 0 : 1;
     op.flops = 2.0 * rows * cw.taps * cw.Cin_l * cw.Cout_l;
     op.bytes = inb + rows * cw.Cout_l * 4.0 + (double)cw.taps * cw.Cin_l * cw.Cout_l * 4.0;
-    const int tile = cw.tile;
     op.run = [a, tile, tiles](hipStream_t s) { return launch_igemm(tile, a, tiles, s); };
     return op;
 }
@@ -193,7 +202,7 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
 // ----------------------------------------------------------------------------- handle
 struct Retained { const float *dev; int B, H, W, C, Cp; bool permuted; };
 
-struct EvPair { hipEvent_t a, b; int cls; };
+struct EvPair { hipEvent_t a, b; int cls; int fwd; };
 
 struct ssd_handle {
     ssd_config cfg;
@@ -218,9 +227,14 @@ struct ssd_handle {
     PostArgs post;
     std::map<std::string, Retained> retained;
     int N = 0;
+    // second stream: the class tower runs beside the box tower (independent chains,
+    // box_predictor.py:47-59), so one launch's tail / launch gap is filled by the other
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // profiling
     bool profiling = false;
     std::vector<EvPair> evs;
+    std::vector<hipEvent_t> ref_evs;     // one reference event per profiled forward
     double acc_ms[6] = {0}, acc_flops[6] = {0}, acc_bytes[6] = {0};
     long long acc_n[6] = {0};
 };
@@ -524,6 +538,12 @@ extern "C" int ssd_create(const ssd_config *cfg, ssd_handle **out)
     HIPCHK(hipSetDevice(cfg->device));
     ssd_handle *h = new ssd_handle();
     h->cfg = *cfg;
+    if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        delete h;
+        return fail(SSD_ERR_HIP, "ssd_create: cannot create the second stream / events");
+    }
     *out = h;
     return SSD_OK;
 }
@@ -534,6 +554,10 @@ extern "C" void ssd_destroy(ssd_handle *h)
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
     for (auto &e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto r : h->ref_evs) (void)hipEventDestroy(r);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->aux) (void)hipStreamDestroy(h->aux);
     h->apool.free_all();
     h->wpool.free_all();
     delete h;
@@ -831,6 +855,7 @@ static int build_plan(ssd_handle *h, int B, int H, int W)
     float *logits, *codes;
     SSDCHK(falloc(&logits, (long long)B * N * C));
     SSDCHK(falloc(&codes, (long long)B * N * 4));
+    std::vector<Op> tower_ops[2];
     for (int t = 0; t < 2; ++t) {
         float *TA, *TB;
         SSDCHK(falloc(&TA, py.total));
@@ -840,7 +865,7 @@ static int build_plan(ssd_handle *h, int B, int H, int W)
         for (int i = 0; i < 4; ++i) {
             std::vector<LevelDesc> lv;
             for (int l = 0; l < 5; ++l) lv.push_back(dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, py.off[l], py.off[l], l * 256));
-            h->ops.push_back(make_conv_op(h->tower[t][i], in, out, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true));
+            tower_ops[t].push_back(make_conv_op(h->tower[t][i], in, out, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true));
             in = out;
             out = (out == TA) ? TB : TA;
         }
@@ -854,8 +879,16 @@ static int build_plan(ssd_handle *h, int B, int H, int W)
             d.param_off = 0;
             lv.push_back(d);
         }
-        h->ops.push_back(make_conv_op(h->final_[t], in, t == 0 ? codes : logits, nullptr, nullptr, B, 1, 1, SSD_ACT_NONE, lv, false));
+        tower_ops[t].push_back(make_conv_op(h->final_[t], in, t == 0 ? codes : logits, nullptr, nullptr, B, 1, 1, SSD_ACT_NONE, lv, false));
     }
+    // enqueue order interleaved so both hardware queues stay fed; class tower (t = 1) on the
+    // second stream
+    for (size_t i = 0; i < tower_ops[0].size(); ++i)
+        for (int t = 1; t >= 0; --t) {
+            Op op = tower_ops[t][i];
+            op.stream = t;
+            h->ops.push_back(op);
+        }
     h->retained["encoded_boxes"] = Retained{codes, B, 1, (int)N, 4, 4, false};
     h->retained["class_predictions"] = Retained{logits, B, 1, (int)N, C, C, false};
 
@@ -890,9 +923,11 @@ static float conservative_logit_bound(float thr)
 
 static hipError_t run_op(ssd_handle *h, const Op &op, hipStream_t s)
 {
+    if (op.stream == 1) s = h->aux;
     if (!h->profiling) return op.run(s);
     EvPair e;
     e.cls = op.cls;
+    e.fwd = (int)h->ref_evs.size() - 1;
     hipError_t r = hipEventCreate(&e.a);
     if (r != hipSuccess) return r;
     r = hipEventCreate(&e.b);
@@ -925,7 +960,25 @@ extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, 
     }
     hipStream_t s = (hipStream_t)stream;
     h->cur_images = images_dev;
-    for (const Op &op : h->ops) HIPCHK(run_op(h, op, s));
+    if (h->profiling) {
+        hipEvent_t ref;
+        HIPCHK(hipEventCreate(&ref));
+        HIPCHK(hipEventRecord(ref, s));
+        h->ref_evs.push_back(ref);
+    }
+    bool forked = false;
+    for (const Op &op : h->ops) {
+        if (op.stream == 1 && !forked) {        // fork: the second stream starts after the FPN
+            HIPCHK(hipEventRecord(h->ev_fork, s));
+            HIPCHK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+            forked = true;
+        }
+        HIPCHK(run_op(h, op, s));
+    }
+    if (forked) {                               // join before the post-processing reads the logits
+        HIPCHK(hipEventRecord(h->ev_join, h->aux));
+        HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
+    }
     PostArgs p = h->post;
     p.boxes = boxes_dev; p.labels = labels_dev; p.scores = scores_dev; p.num = num_boxes_dev;
     p.logit_lo = conservative_logit_bound(p.score_thr);
@@ -982,17 +1035,45 @@ extern "C" int ssd_profile_enable(ssd_handle *h, int32_t on)
     return SSD_OK;
 }
 
+// Per class, the time is the UNION of its kernels' [start, end] intervals inside each forward
+// (the two head towers run concurrently on two streams: their kernels overlap, and a sum of
+// durations would count the shared GPU twice).
 static int drain_events(ssd_handle *h)
 {
+    std::vector<std::vector<std::pair<float, float>>> iv(6);
+    int cur_fwd = -1;
+    auto flush = [&]() {
+        for (int c = 0; c < 6; ++c) {
+            auto &v = iv[c];
+            std::sort(v.begin(), v.end());
+            float lo = 0, hi = -1;
+            for (auto &p : v) {
+                if (hi < 0) { lo = p.first; hi = p.second; }
+                else if (p.first <= hi) { if (p.second > hi) hi = p.second; }
+                else { h->acc_ms[c] += hi - lo; lo = p.first; hi = p.second; }
+            }
+            if (hi >= 0) h->acc_ms[c] += hi - lo;
+            v.clear();
+        }
+    };
     for (auto &e : h->evs) {
         HIPCHK(hipEventSynchronize(e.b));
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
-        h->acc_ms[e.cls] += ms;
+        if (e.fwd != cur_fwd) { flush(); cur_fwd = e.fwd; }
+        float t0 = 0, t1 = 0;
+        if (e.fwd >= 0 && e.fwd < (int)h->ref_evs.size()) {
+            HIPCHK(hipEventElapsedTime(&t0, h->ref_evs[e.fwd], e.a));
+            HIPCHK(hipEventElapsedTime(&t1, h->ref_evs[e.fwd], e.b));
+        } else {
+            HIPCHK(hipEventElapsedTime(&t1, e.a, e.b));
+        }
+        iv[e.cls].push_back({t0, t1});
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
+    flush();
     h->evs.clear();
+    for (auto r : h->ref_evs) (void)hipEventDestroy(r);
+    h->ref_evs.clear();
     return SSD_OK;
 }
 

@@ -319,13 +319,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     }
 }
 
-int igemm_tile_bm(int tile) { return tile == IGEMM_256x128 ? 256 : 128; }
+int igemm_tile_bm(int tile) { return tile == IGEMM_256x128 ? 256 : (tile == IGEMM_64x64 ? 64 : 128); }
 int igemm_tile_bn(int tile)
 {
     switch (tile) {
     case IGEMM_128x256: return 256;
     case IGEMM_128x128: case IGEMM_256x128: return 128;
-    case IGEMM_128x64: return 64;
+    case IGEMM_128x64: case IGEMM_64x64: return 64;
     case IGEMM_128x32: return 32;
     default: return 128;   // diagnostic variants of 128x128
     }
@@ -370,6 +370,7 @@ hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStre
     case IGEMM_128x128: return launch_t<2, 2, 2, 2>(a, total_tiles_m, s);
     case IGEMM_128x64: return launch_t<4, 1, 1, 2>(a, total_tiles_m, s);
     case IGEMM_128x32: return launch_t<4, 1, 1, 1>(a, total_tiles_m, s);
+    case IGEMM_64x64: return launch_t<2, 2, 1, 1>(a, total_tiles_m, s);
     case 10: return launch_t<2, 2, 2, 2, 1>(a, total_tiles_m, s);
     case 11: return launch_t<2, 2, 2, 2, 2>(a, total_tiles_m, s);
     case 12: return launch_t<2, 2, 2, 2, 3>(a, total_tiles_m, s);
