@@ -204,12 +204,25 @@ struct Retained { const float *dev; int B, H, W, C, Cp; bool permuted; };
 
 struct EvPair { hipEvent_t a, b; int cls; int fwd; };
 
+// The layer plan of one SUB-BATCH: ssd_forward splits a large batch into a few sub-batches and
+// staggers them over streams, so the HBM-bound backbone of sub-batch k+1 runs underneath the
+// MFMA-bound heads of sub-batch k (images are independent end to end).
+struct Plan {
+    int B = 0, img0 = 0, N = 0;
+    DevPool pool;                       // activations / workspace
+    std::vector<Op> ops;
+    PostArgs post;
+    std::map<std::string, Retained> retained;
+    hipStream_t s_main = nullptr;       // null: the caller's stream (sub-batch 0)
+    hipStream_t s_aux = nullptr;        // class tower beside the box tower (box_predictor.py:47-59)
+    hipEvent_t ev_fpn = nullptr, ev_join = nullptr, ev_done = nullptr;
+};
+
 struct ssd_handle {
     ssd_config cfg;
     std::map<std::string, Tensor> vars;
     bool finalized = false;
     DevPool wpool;      // weights
-    DevPool apool;      // activations / workspace of the current plan
     // packed weights
     DwW first;                          // first conv (w = [27][CoutP])
     int firstCp = 0, firstAct = SSD_ACT_RELU6;
@@ -219,18 +232,11 @@ struct ssd_handle {
     ConvW tower[2][4], final_[2];       // [box, class]
     std::vector<int *> tabs;            // shufflenet gather tables (device)
     int c_ch[3] = {0, 0, 0};            // logical channels of c3, c4, c5
-    // plan
+    // plans
     int pB = 0, pH = 0, pW = 0;
-    std::vector<Op> ops;
+    std::vector<Plan *> plans;
+    hipEvent_t ev_start = nullptr;
     const uint8_t *cur_images = nullptr;
-    float *o_boxes = nullptr, *o_scores = nullptr; int32_t *o_labels = nullptr, *o_num = nullptr;
-    PostArgs post;
-    std::map<std::string, Retained> retained;
-    int N = 0;
-    // second stream: the class tower runs beside the box tower (independent chains,
-    // box_predictor.py:47-59), so one launch's tail / launch gap is filled by the other
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // profiling
     bool profiling = false;
     std::vector<EvPair> evs;
@@ -238,6 +244,21 @@ struct ssd_handle {
     double acc_ms[6] = {0}, acc_flops[6] = {0}, acc_bytes[6] = {0};
     long long acc_n[6] = {0};
 };
+
+static void free_plans(ssd_handle *h)
+{
+    for (Plan *pl : h->plans) {
+        pl->pool.free_all();
+        if (pl->s_main) (void)hipStreamDestroy(pl->s_main);
+        if (pl->s_aux) (void)hipStreamDestroy(pl->s_aux);
+        if (pl->ev_fpn) (void)hipEventDestroy(pl->ev_fpn);
+        if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
+        if (pl->ev_done) (void)hipEventDestroy(pl->ev_done);
+        delete pl;
+    }
+    h->plans.clear();
+    h->pB = h->pH = h->pW = 0;
+}
 
 static const Tensor *getvar(ssd_handle *h, const std::string &n, std::initializer_list<int64_t> shape)
 {
@@ -538,11 +559,9 @@ extern "C" int ssd_create(const ssd_config *cfg, ssd_handle **out)
     HIPCHK(hipSetDevice(cfg->device));
     ssd_handle *h = new ssd_handle();
     h->cfg = *cfg;
-    if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess) {
         delete h;
-        return fail(SSD_ERR_HIP, "ssd_create: cannot create the second stream / events");
+        return fail(SSD_ERR_HIP, "ssd_create: cannot create events");
     }
     *out = h;
     return SSD_OK;
@@ -555,10 +574,8 @@ extern "C" void ssd_destroy(ssd_handle *h)
     (void)hipDeviceSynchronize();
     for (auto &e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto r : h->ref_evs) (void)hipEventDestroy(r);
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->aux) (void)hipStreamDestroy(h->aux);
-    h->apool.free_all();
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    free_plans(h);
     h->wpool.free_all();
     delete h;
 }
@@ -640,13 +657,12 @@ static LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long 
     return d;
 }
 
-static int build_plan(ssd_handle *h, int B, int H, int W)
+static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, int img0)
 {
-    h->apool.free_all();
-    h->ops.clear();
-    h->retained.clear();
-    h->pB = h->pH = h->pW = 0;
-    DevPool &ap = h->apool;
+    pl.B = B;
+    pl.img0 = img0;
+    const size_t img_off = (size_t)img0 * H * W * 3;
+    DevPool &ap = pl.pool;
     auto falloc = [&](float **p, long long nfloats) { return ap.alloc((void **)p, (size_t)nfloats * sizeof(float)); };
 
     // ---------------- backbone
@@ -677,16 +693,16 @@ static int build_plan(ssd_handle *h, int B, int H, int W)
             const DwW f = h->first;
             const int act = h->firstAct;
             op.run = [=](hipStream_t s) {
-                return launch_first_conv(hh->cur_images, B, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, X, s);
+                return launch_first_conv(hh->cur_images + img_off, B, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, X, s);
             };
-            h->ops.push_back(op);
+            pl.ops.push_back(op);
         }
         float *cur = X;
         int ch = h2, cwid = w2;
         for (int i = 0; i < 13; ++i) {
             const int s = MB_STRIDE[i];
             float *dwo = (cur == X) ? Y : X;
-            h->ops.push_back(make_dw_op(h->dw[i], cur, B, ch, cwid, s, SSD_ACT_RELU6, dwo, h->pw[i].Cin_l));
+            pl.ops.push_back(make_dw_op(h->dw[i], cur, B, ch, cwid, s, SSD_ACT_RELU6, dwo, h->pw[i].Cin_l));
             ch /= s; cwid /= s;
             const ConvW &cw = h->pw[i];
             float *pwo;
@@ -694,11 +710,11 @@ static int build_plan(ssd_handle *h, int B, int H, int W)
                 SSDCHK(falloc(&pwo, (long long)B * ch * cwid * cw.CoutP));
                 if (i == 4) C3 = pwo; else if (i == 10) C4 = pwo; else C5 = pwo;
                 const char *nm = i == 4 ? "c3" : (i == 10 ? "c4" : "c5");
-                h->retained[nm] = Retained{pwo, B, ch, cwid, cw.Cout_l, cw.CoutP, true};
+                pl.retained[nm] = Retained{pwo, B, ch, cwid, cw.Cout_l, cw.CoutP, true};
             } else {
                 pwo = (dwo == X) ? Y : X;
             }
-            h->ops.push_back(make_conv_op(cw, dwo, pwo, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU6,
+            pl.ops.push_back(make_conv_op(cw, dwo, pwo, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU6,
                                           {dense_level(ch, cwid, ch, cwid, cw.CoutP)}, true));
             cur = pwo;
         }
@@ -719,14 +735,14 @@ static int build_plan(ssd_handle *h, int B, int H, int W)
             const DwW f = h->first;
             const int act = h->firstAct;
             op.run = [=](hipStream_t s) {
-                return launch_first_conv(hh->cur_images, B, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s);
+                return launch_first_conv(hh->cur_images + img_off, B, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s);
             };
-            h->ops.push_back(op);
+            pl.ops.push_back(op);
             Op mp;
             mp.cls = 5; mp.flops = 0;
             mp.bytes = ((double)B * h2 * w2 + (double)B * h4 * w4) * 24 * 4.0;
             mp.run = [=](hipStream_t s) { return launch_maxpool(F, B, h2, w2, fc, MP, s); };
-            h->ops.push_back(mp);
+            pl.ops.push_back(mp);
         }
         const float *cur = MP;
         int ch = h4, cwid = w4, ipw = 0, idw = 0;
@@ -745,13 +761,13 @@ static int build_plan(ssd_handle *h, int B, int H, int W)
             SSDCHK(falloc(&Xa, rows * Dp)); SSDCHK(falloc(&Xb, rows * Dp));
             SSDCHK(falloc(&Ya, rows * Dp)); SSDCHK(falloc(&Yb, rows * Dp));
             SSDCHK(falloc(&U, rows * Dp)); SSDCHK(falloc(&V, rows * Dp));
-            h->ops.push_back(make_conv_op(before, cur, t1, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+            pl.ops.push_back(make_conv_op(before, cur, t1, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
                                           {dense_level(ch, cwid, ch, cwid, before.CoutP)}, true));
-            h->ops.push_back(make_dw_op(d1, t1, B, ch, cwid, 2, SSD_ACT_NONE, t2, before.Cout_l));
-            h->ops.push_back(make_conv_op(after, t2, Ya, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+            pl.ops.push_back(make_dw_op(d1, t1, B, ch, cwid, 2, SSD_ACT_NONE, t2, before.Cout_l));
+            pl.ops.push_back(make_conv_op(after, t2, Ya, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
                                           {dense_level(oh, ow, oh, ow, Dp)}, true));
-            h->ops.push_back(make_dw_op(d2, cur, B, ch, cwid, 2, SSD_ACT_NONE, t3, before.Cin_l));
-            h->ops.push_back(make_conv_op(after2, t3, Xa, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+            pl.ops.push_back(make_dw_op(d2, cur, B, ch, cwid, 2, SSD_ACT_NONE, t3, before.Cin_l));
+            pl.ops.push_back(make_conv_op(after2, t3, Xa, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
                                           {dense_level(oh, ow, oh, ow, Dp)}, true));
             float *x = Xa, *y = Ya, *xs = Xb, *ys = Yb;
             const int *tabx = h->tabs[st * 3], *taby = h->tabs[st * 3 + 1], *tabc = h->tabs[st * 3 + 2];
@@ -765,16 +781,16 @@ static int build_plan(ssd_handle *h, int B, int H, int W)
                         if (e != hipSuccess) return e;
                         return launch_gather_channels(cx, Dp, cy, Dp, rows, taby, Dp, oy, s);
                     };
-                    h->ops.push_back(g);
+                    pl.ops.push_back(g);
                 }
                 const ConvW &b2 = h->pw[ipw], &a2 = h->pw[ipw + 1];
                 const DwW &dd = h->dw[idw];
                 ipw += 2; idw += 1;
-                h->ops.push_back(make_conv_op(b2, xs, U, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+                pl.ops.push_back(make_conv_op(b2, xs, U, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
                                               {dense_level(oh, ow, oh, ow, Dp)}, true));
-                h->ops.push_back(make_dw_op(dd, U, B, oh, ow, 1, SSD_ACT_NONE, V, D));
+                pl.ops.push_back(make_dw_op(dd, U, B, oh, ow, 1, SSD_ACT_NONE, V, D));
                 // new x overwrites the old x buffer (dead after the shuffle); y' = ys
-                h->ops.push_back(make_conv_op(a2, V, x, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+                pl.ops.push_back(make_conv_op(a2, V, x, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
                                               {dense_level(oh, ow, oh, ow, Dp)}, true));
                 // now (x, ys) is the live pair; old y and xs are free
                 float *oldy = y;
@@ -789,18 +805,18 @@ static int build_plan(ssd_handle *h, int B, int H, int W)
                 g.cls = 5; g.flops = 0; g.bytes = 4.0 * rows * D * 4.0;
                 const float *cx = x, *cy = y;
                 g.run = [=](hipStream_t s) { return launch_gather_channels(cx, Dp, cy, Dp, rows, tabc, Cc, S, s); };
-                h->ops.push_back(g);
+                pl.ops.push_back(g);
             }
-            if (st == 0) { C3 = S; h->retained["c3"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
-            if (st == 1) { C4 = S; h->retained["c4"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
+            if (st == 0) { C3 = S; pl.retained["c3"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
+            if (st == 1) { C4 = S; pl.retained["c4"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
             cur = S;
             ch = oh; cwid = ow;
         }
         const ConvW &c5 = h->pw[ipw];
         SSDCHK(falloc(&C5, (long long)B * ch * cwid * c5.CoutP));
-        h->ops.push_back(make_conv_op(c5, cur, C5, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+        pl.ops.push_back(make_conv_op(c5, cur, C5, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
                                       {dense_level(ch, cwid, ch, cwid, c5.CoutP)}, true));
-        h->retained["c5"] = Retained{C5, B, ch, cwid, c5.Cout_l, c5.CoutP, true};
+        pl.retained["c5"] = Retained{C5, B, ch, cwid, c5.Cout_l, c5.CoutP, true};
     }
 
     // ---------------- FPN (feature_extractor.py:40-76)
@@ -813,45 +829,45 @@ static int build_plan(ssd_handle *h, int B, int H, int W)
     SSDCHK(falloc(&T6, (long long)B * py.h[3] * py.w[3] * 256));
     auto lvl = [&](int l, int CoutP) { return dense_level(py.h[l], py.w[l], py.h[l], py.w[l], CoutP); };
     // x5 = lateral5(c5); p5 = conv(x5)
-    h->ops.push_back(make_conv_op(h->lat[2], C5, X5, nullptr, nullptr, B, 1, 0, SSD_ACT_NONE, {lvl(2, 256)}, true));
+    pl.ops.push_back(make_conv_op(h->lat[2], C5, X5, nullptr, nullptr, B, 1, 0, SSD_ACT_NONE, {lvl(2, 256)}, true));
     {
         LevelDesc d = lvl(2, 256);
         d.out_off = py.off[2];
-        h->ops.push_back(make_conv_op(h->pconv[2], X5, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true));
+        pl.ops.push_back(make_conv_op(h->pconv[2], X5, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true));
     }
     {   // p6 = conv s2 (c5): BN+ReLU -> P6, ReLU(raw) -> T6 (input of p7, :60)
         LevelDesc d = dense_level(py.h[2], py.w[2], py.h[3], py.w[3], 256);
         d.out_off = py.off[3];
         Op op = make_conv_op(h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true);
-        h->ops.push_back(op);
+        pl.ops.push_back(op);
         LevelDesc d7 = dense_level(py.h[3], py.w[3], py.h[4], py.w[4], 256);
         d7.out_off = py.off[4];
-        h->ops.push_back(make_conv_op(h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true));
+        pl.ops.push_back(make_conv_op(h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true));
     }
     // x4 = up(x5) + lateral4(c4); p4;  x3 = up(x4) + lateral3(c3); p3
-    h->ops.push_back(make_conv_op(h->lat[1], C4, X4, nullptr, X5, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true));
+    pl.ops.push_back(make_conv_op(h->lat[1], C4, X4, nullptr, X5, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true));
     {
         LevelDesc d = lvl(1, 256);
         d.out_off = py.off[1];
-        h->ops.push_back(make_conv_op(h->pconv[1], X4, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true));
+        pl.ops.push_back(make_conv_op(h->pconv[1], X4, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true));
     }
-    h->ops.push_back(make_conv_op(h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true));
+    pl.ops.push_back(make_conv_op(h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true));
     {
         LevelDesc d = lvl(0, 256);
         d.out_off = py.off[0];
-        h->ops.push_back(make_conv_op(h->pconv[0], X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true));
+        pl.ops.push_back(make_conv_op(h->pconv[0], X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true));
     }
     for (int l = 0; l < 5; ++l) {
         char nm[8];
         snprintf(nm, sizeof nm, "p%d", l + 3);
-        h->retained[nm] = Retained{P + py.off[l], B, py.h[l], py.w[l], 256, 256, true};
+        pl.retained[nm] = Retained{P + py.off[l], B, py.h[l], py.w[l], 256, 256, true};
     }
 
     // ---------------- heads (box_predictor.py:36-155), all levels per launch
     const int C = h->cfg.num_classes, A = 6;
     long long N = 0, aoff[5];
     for (int l = 0; l < 5; ++l) { aoff[l] = N; N += (long long)py.h[l] * py.w[l] * A; }
-    h->N = (int)N;
+    pl.N = (int)N;
     float *logits, *codes;
     SSDCHK(falloc(&logits, (long long)B * N * C));
     SSDCHK(falloc(&codes, (long long)B * N * 4));
@@ -887,10 +903,10 @@ static int build_plan(ssd_handle *h, int B, int H, int W)
         for (int t = 1; t >= 0; --t) {
             Op op = tower_ops[t][i];
             op.stream = t;
-            h->ops.push_back(op);
+            pl.ops.push_back(op);
         }
-    h->retained["encoded_boxes"] = Retained{codes, B, 1, (int)N, 4, 4, false};
-    h->retained["class_predictions"] = Retained{logits, B, 1, (int)N, C, C, false};
+    pl.retained["encoded_boxes"] = Retained{codes, B, 1, (int)N, 4, 4, false};
+    pl.retained["class_predictions"] = Retained{logits, B, 1, (int)N, C, C, false};
 
     // ---------------- anchors + post-processing
     std::vector<float> anc((size_t)N * 4);
@@ -900,7 +916,7 @@ static int build_plan(ssd_handle *h, int B, int H, int W)
     void *ws;
     const size_t wsb = post_workspace_bytes(B, (int)N, C, h->cfg.max_boxes_per_class);
     SSDCHK(ap.alloc(&ws, wsb));
-    PostArgs &p = h->post;
+    PostArgs &p = pl.post;
     memset(&p, 0, sizeof(p));
     p.logits = logits; p.codes = codes; p.anchors = anc_dev;
     p.B = B; p.N = (int)N; p.C = C;
@@ -909,7 +925,6 @@ static int build_plan(ssd_handle *h, int B, int H, int W)
     // resize_keeping_aspect_ratio is the identity for the accepted sizes: box_scaler = 1
     for (int k = 0; k < 4; ++k) p.box_scaler[k] = 1.0f;
     post_carve(p, ws);
-    h->pB = B; h->pH = H; h->pW = W;
     return SSD_OK;
 }
 
@@ -923,7 +938,6 @@ static float conservative_logit_bound(float thr)
 
 static hipError_t run_op(ssd_handle *h, const Op &op, hipStream_t s)
 {
-    if (op.stream == 1) s = h->aux;
     if (!h->profiling) return op.run(s);
     EvPair e;
     e.cls = op.cls;
@@ -942,6 +956,32 @@ static hipError_t run_op(ssd_handle *h, const Op &op, hipStream_t s)
     return r;
 }
 
+static int make_plans(ssd_handle *h, int B, int H, int W)
+{
+    free_plans(h);
+    // Measured on MI355X (B = 32, 640x896): 1 / 2 / 4 / 8 sub-batches -> 730 / 696 / 647 / 587 img/s.
+    // Backbone kernels running beside head kernels take CU slots from them and stretch far more
+    // than the overlap returns, so the default is ONE plan; SSD_NSUB keeps the experiment alive.
+    int nsub = 1;
+    if (const char *e = getenv("SSD_NSUB")) { const int v = atoi(e); if (v >= 1 && v <= 8) nsub = v; }
+    if (nsub > B) nsub = B;
+    int img0 = 0;
+    for (int k = 0; k < nsub; ++k) {
+        const int bk = B / nsub + (k < B % nsub ? 1 : 0);
+        Plan *pl = new Plan();
+        h->plans.push_back(pl);
+        if (k > 0) HIPCHK(hipStreamCreateWithFlags(&pl->s_main, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&pl->s_aux, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&pl->ev_fpn, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&pl->ev_done, hipEventDisableTiming));
+        SSDCHK(build_plan(h, *pl, bk, H, W, img0));
+        img0 += bk;
+    }
+    h->pB = B; h->pH = H; h->pW = W;
+    return SSD_OK;
+}
+
 extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
                            int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, void *stream)
 {
@@ -956,7 +996,8 @@ extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, 
     HIPCHK(hipSetDevice(h->cfg.device));
     if (B != h->pB || H != h->pH || W != h->pW) {
         HIPCHK(hipDeviceSynchronize());
-        SSDCHK(build_plan(h, B, H, W));
+        int rc = make_plans(h, B, H, W);
+        if (rc != SSD_OK) { free_plans(h); return rc; }
     }
     hipStream_t s = (hipStream_t)stream;
     h->cur_images = images_dev;
@@ -966,47 +1007,73 @@ extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, 
         HIPCHK(hipEventRecord(ref, s));
         h->ref_evs.push_back(ref);
     }
-    bool forked = false;
-    for (const Op &op : h->ops) {
-        if (op.stream == 1 && !forked) {        // fork: the second stream starts after the FPN
-            HIPCHK(hipEventRecord(h->ev_fork, s));
-            HIPCHK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-            forked = true;
+    const int T = h->cfg.num_classes * h->cfg.max_boxes_per_class;
+    HIPCHK(hipEventRecord(h->ev_start, s));
+    for (size_t k = 0; k < h->plans.size(); ++k) {
+        Plan &pl = *h->plans[k];
+        hipStream_t sm = pl.s_main ? pl.s_main : s;
+        if (k > 0) {
+            // staggered start: after the caller's prior work, and once the previous sub-batch
+            // has left its backbone + FPN (so this backbone runs beneath that one's heads)
+            HIPCHK(hipStreamWaitEvent(sm, h->ev_start, 0));
+            HIPCHK(hipStreamWaitEvent(sm, h->plans[k - 1]->ev_fpn, 0));
         }
-        HIPCHK(run_op(h, op, s));
+        bool forked = false;
+        for (const Op &op : pl.ops) {
+            if (op.stream == 1 && !forked) {        // fork: the second stream starts after the FPN
+                HIPCHK(hipEventRecord(pl.ev_fpn, sm));
+                HIPCHK(hipStreamWaitEvent(pl.s_aux, pl.ev_fpn, 0));
+                forked = true;
+            }
+            HIPCHK(run_op(h, op, op.stream == 1 ? pl.s_aux : sm));
+        }
+        if (!forked) HIPCHK(hipEventRecord(pl.ev_fpn, sm));
+        if (forked) {                               // join before the post-processing reads the logits
+            HIPCHK(hipEventRecord(pl.ev_join, pl.s_aux));
+            HIPCHK(hipStreamWaitEvent(sm, pl.ev_join, 0));
+        }
+        PostArgs p = pl.post;
+        p.boxes = boxes_dev + (size_t)pl.img0 * T * 4;
+        p.labels = labels_dev + (size_t)pl.img0 * T;
+        p.scores = scores_dev + (size_t)pl.img0 * T;
+        p.num = num_boxes_dev + pl.img0;
+        p.logit_lo = conservative_logit_bound(p.score_thr);
+        Op pop;
+        pop.cls = 4;
+        pop.flops = 0;
+        pop.bytes = (double)pl.B * p.N * (p.C + 8) * 4.0;
+        pop.run = [p](hipStream_t st) { return launch_postprocess(p, st); };
+        HIPCHK(run_op(h, pop, sm));
+        if (k > 0) HIPCHK(hipEventRecord(pl.ev_done, sm));
     }
-    if (forked) {                               // join before the post-processing reads the logits
-        HIPCHK(hipEventRecord(h->ev_join, h->aux));
-        HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
-    }
-    PostArgs p = h->post;
-    p.boxes = boxes_dev; p.labels = labels_dev; p.scores = scores_dev; p.num = num_boxes_dev;
-    p.logit_lo = conservative_logit_bound(p.score_thr);
-    Op pop;
-    pop.cls = 4;
-    pop.flops = 0;
-    pop.bytes = (double)B * p.N * (p.C + 8) * 4.0;
-    pop.run = [p](hipStream_t st) { return launch_postprocess(p, st); };
-    HIPCHK(run_op(h, pop, s));
+    for (size_t k = 1; k < h->plans.size(); ++k) HIPCHK(hipStreamWaitEvent(s, h->plans[k]->ev_done, 0));
     return SSD_OK;
 }
 
 extern "C" int ssd_get_tensor(ssd_handle *h, const char *name, float *dst, int64_t cap, int32_t *dims)
 {
     if (!h || !name || !dst || !dims) return fail(SSD_ERR_INVALID, "ssd_get_tensor: null argument");
-    auto it = h->retained.find(name);
-    if (it == h->retained.end()) return fail(SSD_ERR_INVALID, std::string("ssd_get_tensor: unknown tensor ") + name);
-    const Retained &r = it->second;
-    const long long rows = (long long)r.B * r.H * r.W;
-    if (cap < rows * r.C) return fail(SSD_ERR_INVALID, "ssd_get_tensor: destination too small");
+    if (h->plans.empty()) return fail(SSD_ERR_STATE, "ssd_get_tensor before ssd_forward");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipDeviceSynchronize());
-    std::vector<float> tmp((size_t)rows * r.Cp);
-    HIPCHK(hipMemcpy(tmp.data(), r.dev, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
-    for (long long q = 0; q < rows; ++q)
-        for (int c = 0; c < r.C; ++c)
-            dst[q * r.C + c] = tmp[q * r.Cp + (r.permuted ? ssd_phys_of_logical(c) : c)];
-    dims[0] = r.B; dims[1] = r.H; dims[2] = r.W; dims[3] = r.C;
+    long long done = 0;
+    int Btot = 0;
+    for (Plan *pl : h->plans) {                  // sub-batches are consecutive images
+        auto it = pl->retained.find(name);
+        if (it == pl->retained.end()) return fail(SSD_ERR_INVALID, std::string("ssd_get_tensor: unknown tensor ") + name);
+        const Retained &r = it->second;
+        const long long rows = (long long)r.B * r.H * r.W;
+        if (cap < done + rows * r.C) return fail(SSD_ERR_INVALID, "ssd_get_tensor: destination too small");
+        std::vector<float> tmp((size_t)rows * r.Cp);
+        HIPCHK(hipMemcpy(tmp.data(), r.dev, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (long long q = 0; q < rows; ++q)
+            for (int c = 0; c < r.C; ++c)
+                dst[done + q * r.C + c] = tmp[q * r.Cp + (r.permuted ? ssd_phys_of_logical(c) : c)];
+        done += rows * r.C;
+        Btot += r.B;
+        dims[1] = r.H; dims[2] = r.W; dims[3] = r.C;
+    }
+    dims[0] = Btot;
     return SSD_OK;
 }
 
@@ -1015,15 +1082,23 @@ extern "C" int ssd_get_tensor(ssd_handle *h, const char *name, float *dst, int64
 extern "C" int ssd_get_tensor_dev(ssd_handle *h, const char *name, float *dst_dev, int64_t cap, int32_t *dims, void *stream)
 {
     if (!h || !name || !dst_dev || !dims) return fail(SSD_ERR_INVALID, "ssd_get_tensor_dev: null argument");
-    auto it = h->retained.find(name);
-    if (it == h->retained.end()) return fail(SSD_ERR_INVALID, std::string("ssd_get_tensor_dev: unknown tensor ") + name);
-    const Retained &r = it->second;
-    const long long rows = (long long)r.B * r.H * r.W;
-    if (cap < rows * r.C) return fail(SSD_ERR_INVALID, "ssd_get_tensor_dev: destination too small");
+    if (h->plans.empty()) return fail(SSD_ERR_STATE, "ssd_get_tensor_dev before ssd_forward");
     HIPCHK(hipSetDevice(h->cfg.device));
-    if (r.permuted) HIPCHK(launch_permute_channels(r.dev, rows, r.C, r.Cp, 0, dst_dev, (hipStream_t)stream));
-    else HIPCHK(hipMemcpyAsync(dst_dev, r.dev, (size_t)rows * r.C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    dims[0] = r.B; dims[1] = r.H; dims[2] = r.W; dims[3] = r.C;
+    long long done = 0;
+    int Btot = 0;
+    for (Plan *pl : h->plans) {
+        auto it = pl->retained.find(name);
+        if (it == pl->retained.end()) return fail(SSD_ERR_INVALID, std::string("ssd_get_tensor_dev: unknown tensor ") + name);
+        const Retained &r = it->second;
+        const long long rows = (long long)r.B * r.H * r.W;
+        if (cap < done + rows * r.C) return fail(SSD_ERR_INVALID, "ssd_get_tensor_dev: destination too small");
+        if (r.permuted) HIPCHK(launch_permute_channels(r.dev, rows, r.C, r.Cp, 0, dst_dev + done, (hipStream_t)stream));
+        else HIPCHK(hipMemcpyAsync(dst_dev + done, r.dev, (size_t)rows * r.C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        done += rows * r.C;
+        Btot += r.B;
+        dims[1] = r.H; dims[2] = r.W; dims[3] = r.C;
+    }
+    dims[0] = Btot;
     return SSD_OK;
 }
 

@@ -57,7 +57,7 @@ def test_golden_tiny(cuda, ssd):
     eng.close()
 
 
-@pytest.mark.parametrize("backbone,H,W,B", [("mobilenet", 128, 256, 3), ("shufflenet", 128, 128, 2)])
+@pytest.mark.parametrize("backbone,H,W,B", [("mobilenet", 128, 256, 9), ("shufflenet", 128, 128, 2)])
 def test_forward_vs_oracle_small(cuda, ssd, oracle_graph, backbone, H, W, B):
     params = {"backbone": backbone, "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
               "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
@@ -75,6 +75,23 @@ def test_forward_vs_oracle_small(cuda, ssd, oracle_graph, backbone, H, W, B):
     out1 = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(img[:1].copy()).cuda())]
     for a, b in zip(out, out1):
         assert np.array_equal(a[:1], b)
+    eng.close()
+
+
+def test_sub_batch_plans(cuda, ssd, oracle_graph, monkeypatch):
+    """SSD_NSUB splits a batch into staggered sub-batch plans (uneven split 5 = 2+2+1): same
+    results, same retained tensors."""
+    monkeypatch.setenv("SSD_NSUB", "3")
+    params = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
+              "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
+    Wt = ssd.synthetic_weights(params, seed=12, logits_bias=-4.0)
+    img = np.random.default_rng(6).integers(0, 256, (5, 128, 128, 3), dtype=np.uint8)
+    keep = {}
+    ref = oracle_graph.forward(img, Wt, params, keep)
+    eng = ssd.Engine(params, Wt)
+    out = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(img).cuda())]
+    assert stage_check(eng, keep, STAGES, "nsub3") == 1.0
+    compare_outputs(out, ref, "sub-batch plans")
     eng.close()
 
 
