@@ -80,8 +80,11 @@ int ssd_finalize(ssd_handle *h);
 
 /* ---- the hot path: replaces sess.run(output_ops, {images: ...})
  *      (inference/detector.py:51-52) = create_pb.py:42-47 + model.py:13-77 ------------ */
-/* images_dev uint8 [B,H,W,3]; H, W multiples of 128 with min(H,W) == min_dimension
- * (resize_keeping_aspect_ratio, pipeline.py:138-194, is then the identity).
+/* images_dev uint8 [B,H,W,3], any H and W: the serving graph's preprocessing
+ * (create_pb.py:42-47 -> resize_keeping_aspect_ratio(min_dimension, 128), pipeline.py:138-194:
+ * nearest-neighbour resize so that the short side is min_dimension, zero pad bottom/right to
+ * multiples of 128, box_scaler) is fused into the first kernel; for H, W multiples of 128 with
+ * min(H,W) == min_dimension it is the identity.
  * Outputs, T = num_classes*max_boxes_per_class (2000): boxes_dev f32 [B,T,4]
  * (ymin,xmin,ymax,xmax, normalised, already divided by box_scaler, model.py:67-68),
  * labels_dev i32 [B,T], scores_dev f32 [B,T], num_boxes_dev i32 [B]; zero padded. */

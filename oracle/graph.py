@@ -140,13 +140,17 @@ def box_predictor(ps, W, num_classes, towers=None):
 
 # ---------------------------------------------------------------- create_pb.py + model.py PREDICT
 def forward(images_u8, W, params, keep=None):
-    """images_u8 [B,H,W,3] uint8 with H, W multiples of 128 and min(H, W) == min_dimension
-    (then resize_keeping_aspect_ratio, pipeline.py:138-194, is the identity and
-    box_scaler == 1).  Returns the graph outputs dict (model.py:70-73) plus, when `keep` is a
-    dict, every intermediate needed by the stage parity tests."""
-    B, H, Wd, _ = images_u8.shape
+    """images_u8 [B,H,W,3] uint8, any size.  create_pb.py:42-47: to_float ->
+    resize_keeping_aspect_ratio(min_dimension, 128) (pipeline.py:138-194; identity when H, W
+    are multiples of 128 with min(H, W) == min_dimension) -> *1/255; then model_fn PREDICT.
+    Returns the graph outputs dict (model.py:70-73) plus, when `keep` is a dict, every
+    intermediate needed by the stage parity tests."""
+    B, H0, W0, _ = images_u8.shape
+    dims, box_scaler = ops.resize_dims(H0, W0, params["min_dimension"], 128)
+    xf = ops.resize_pad(images_u8.astype(np.float32), dims)
+    H, Wd = xf.shape[1], xf.shape[2]
     assert H % 128 == 0 and Wd % 128 == 0
-    x = ops.preprocess(images_u8)
+    x = ops.preprocess_f(xf)
     inter = {} if keep is None else keep
     if params["backbone"] == "mobilenet":
         feats = mobilenet_v1(x, W, inter)
@@ -161,7 +165,7 @@ def forward(images_u8, W, params, keep=None):
     anc = ops.anchors(H, Wd)
     boxes, labels, scores, num = ops.postprocess(
         logits, codes, anc, params["score_threshold"], params["iou_threshold"],
-        params["max_boxes_per_class"])
+        params["max_boxes_per_class"], box_scaler)
     return {"boxes": boxes, "labels": labels, "scores": scores, "num_boxes": num}
 
 

@@ -62,6 +62,31 @@ def preprocess(img_u8):
     return out
 
 
+def resize_dims(height, width, min_dimension=640, divisor=128):
+    """pipeline.py:138-194 size arithmetic -> (new_h, new_w, pad_h, pad_w), box_scaler[4]."""
+    dims = (ctypes.c_int * 4)()
+    bs = np.empty(4, np.float32)
+    lib().orc_resize_dims(_i(height), _i(width), _i(min_dimension), _i(divisor), dims, _p(bs))
+    return tuple(dims), bs
+
+
+def resize_pad(img_f, dims):
+    """NN resize of a float image batch [B,H,W,C] to (new_h,new_w) + zero pad bottom/right."""
+    img_f = _c(img_f)
+    B, H, W, C = img_f.shape
+    nh, nw, ph, pw = dims
+    out = np.empty((B, nh + ph, nw + pw, C), np.float32)
+    lib().orc_resize_pad(_p(img_f), _i(B), _i(H), _i(W), _i(C), _i(nh), _i(nw), _i(ph), _i(pw), _p(out))
+    return out
+
+
+def preprocess_f(img_f):
+    img_f = _c(img_f)
+    out = np.empty_like(img_f)
+    lib().orc_preprocess_f(_p(img_f), _i64(img_f.size), _p(out))
+    return out
+
+
 def out_size(n, k, stride, mode):
     """mode 'SAME' (TF) or 'EXPLICIT' (layer_utils.py:26-43: pad (k-1)//2 both sides, VALID)."""
     if mode == "SAME":

@@ -50,6 +50,15 @@ ORC_API int orc_get_max_threads(void) { return 1; }
 /* ------------------------------------------------------------------------- */
 /* create_pb.py:42-47 + mobilenet_v1.py:34 / shufflenet_v2.py:37             */
 /* uint8 -> float, *(1/255), then 2*x - 1 (two separately rounded ops).      */
+ORC_API void orc_preprocess_f(const float *img, int64_t n, float *out)
+{
+    const float inv255 = (float)(1.0 / 255.0);
+    for (int64_t i = 0; i < n; ++i) {
+        float x = img[i] * inv255;
+        out[i] = 2.0f * x - 1.0f;
+    }
+}
+
 ORC_API void orc_preprocess(const uint8_t *img, int64_t n, float *out)
 {
     const float inv255 = (float)(1.0 / 255.0);
@@ -57,6 +66,58 @@ ORC_API void orc_preprocess(const uint8_t *img, int64_t n, float *out)
         float x = (float)img[i] * inv255;
         out[i] = 2.0f * x - 1.0f;
     }
+}
+
+/* ------------------------------------------------------------------------- */
+/* resize_keeping_aspect_ratio (pipeline.py:138-194) -- the size arithmetic.  */
+/* scale_factor = to_float(min_dimension / original_min_dim) (int/int true    */
+/* division -> float64 -> float32); the longer side becomes                   */
+/* to_int32(round(to_float(x) * scale_factor)) (tf.round: half to even) and   */
+/* is padded up to a multiple of `divisor`; the shorter side is min_dimension.*/
+/* dims: [new_h, new_w, pad_h, pad_w]; box_scaler: float32 of the float64     */
+/* quotients new/(new+pad) (:187-192).                                        */
+ORC_API void orc_resize_dims(int height, int width, int min_dimension, int divisor, int *dims,
+                             float *box_scaler)
+{
+    const int omin = height < width ? height : width;
+    const float scale_factor = (float)((double)min_dimension / (double)omin);
+    int nh, nw, ph = 0, pw = 0;
+    if (height >= width) {
+        const int unp = (int)rintf((float)height * scale_factor);
+        const int x = (int)ceil((double)unp / (double)divisor);
+        nh = unp; ph = divisor * x - unp; nw = min_dimension;
+    } else {
+        const int unp = (int)rintf((float)width * scale_factor);
+        const int x = (int)ceil((double)unp / (double)divisor);
+        nw = unp; pw = divisor * x - unp; nh = min_dimension;
+    }
+    dims[0] = nh; dims[1] = nw; dims[2] = ph; dims[3] = pw;
+    box_scaler[0] = box_scaler[2] = (float)((double)nh / (double)(nh + ph));
+    box_scaler[1] = box_scaler[3] = (float)((double)nw / (double)(nw + pw));
+}
+
+/* tf.image.resize_images(method=NEAREST_NEIGHBOR) (pipeline.py:177, constants.py:22) ==  */
+/* ResizeNearestNeighbor of TF r1.12, align_corners=False (third-party, published kernel  */
+/* resize_nearest_neighbor_op.cc): scale = in / (float)out;                               */
+/* in_y = min((int)floorf(y * scale), in - 1).  Then pad_to_bounding_box(0, 0, ...) with   */
+/* zeros at the bottom / right (:179-183).  Input/outputs are the FLOAT image (0..255),    */
+/* i.e. before the 1/255 of create_pb.py:47.                                               */
+ORC_API void orc_resize_pad(const float *img, int B, int H, int W, int C, int nh, int nw, int ph, int pw,
+                            float *out)
+{
+    const int OH = nh + ph, OW = nw + pw;
+    const float hs = (float)H / (float)nh, ws = (float)W / (float)nw;
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < OH; ++y)
+            for (int x = 0; x < OW; ++x) {
+                float *o = out + (((int64_t)b * OH + y) * OW + x) * C;
+                if (y >= nh || x >= nw) { for (int c = 0; c < C; ++c) o[c] = 0.0f; continue; }
+                int sy = (int)floorf((float)y * hs), sx = (int)floorf((float)x * ws);
+                sy = sy < H - 1 ? sy : H - 1;
+                sx = sx < W - 1 ? sx : W - 1;
+                const float *ip = img + (((int64_t)b * H + sy) * W + sx) * C;
+                for (int c = 0; c < C; ++c) o[c] = ip[c];
+            }
 }
 
 /* ------------------------------------------------------------------------- */

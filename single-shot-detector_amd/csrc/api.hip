@@ -545,6 +545,30 @@ extern "C" int ssd_anchors(int32_t H, int32_t W, float *out)
     return SSD_OK;
 }
 
+// resize_keeping_aspect_ratio (pipeline.py:138-194), the size arithmetic of the TF graph:
+// scale_factor = to_float(min_dimension / min(h, w)); the longer side is
+// to_int32(round(to_float(x) * scale_factor)) (half to even), padded up to a multiple of 128.
+struct ResizeDims { int nh, nw, ph, pw; float box_scaler[4]; };
+static ResizeDims resize_dims(int height, int width, int min_dimension, int divisor)
+{
+    ResizeDims r;
+    const int omin = height < width ? height : width;
+    const float scale_factor = (float)((double)min_dimension / (double)omin);
+    r.ph = r.pw = 0;
+    if (height >= width) {
+        const int unp = (int)nearbyintf((float)height * scale_factor);
+        const int x = (int)ceil((double)unp / (double)divisor);
+        r.nh = unp; r.ph = divisor * x - unp; r.nw = min_dimension;
+    } else {
+        const int unp = (int)nearbyintf((float)width * scale_factor);
+        const int x = (int)ceil((double)unp / (double)divisor);
+        r.nw = unp; r.pw = divisor * x - unp; r.nh = min_dimension;
+    }
+    r.box_scaler[0] = r.box_scaler[2] = (float)((double)r.nh / (double)(r.nh + r.ph));
+    r.box_scaler[1] = r.box_scaler[3] = (float)((double)r.nw / (double)(r.nw + r.pw));
+    return r;
+}
+
 // ----------------------------------------------------------------------------- lifetime
 extern "C" int ssd_create(const ssd_config *cfg, ssd_handle **out)
 {
@@ -657,11 +681,14 @@ static LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long 
     return d;
 }
 
-static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, int img0)
+static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int img0)
 {
     pl.B = B;
     pl.img0 = img0;
-    const size_t img_off = (size_t)img0 * H * W * 3;
+    const size_t img_off = (size_t)img0 * srcH * srcW * 3;
+    const ResizeDims rd = resize_dims(srcH, srcW, h->cfg.min_dimension, 128);
+    const int H = rd.nh + rd.ph, W = rd.nw + rd.pw;     // network input size (multiples of 128)
+    const int rnh = rd.nh, rnw = rd.nw;
     DevPool &ap = pl.pool;
     auto falloc = [&](float **p, long long nfloats) { return ap.alloc((void **)p, (size_t)nfloats * sizeof(float)); };
 
@@ -693,7 +720,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, int img0)
             const DwW f = h->first;
             const int act = h->firstAct;
             op.run = [=](hipStream_t s) {
-                return launch_first_conv(hh->cur_images + img_off, B, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, X, s);
+                return launch_first_conv(hh->cur_images + img_off, B, srcH, srcW, rnh, rnw, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, X, s);
             };
             pl.ops.push_back(op);
         }
@@ -735,7 +762,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, int img0)
             const DwW f = h->first;
             const int act = h->firstAct;
             op.run = [=](hipStream_t s) {
-                return launch_first_conv(hh->cur_images + img_off, B, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s);
+                return launch_first_conv(hh->cur_images + img_off, B, srcH, srcW, rnh, rnw, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s);
             };
             pl.ops.push_back(op);
             Op mp;
@@ -922,8 +949,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, int img0)
     p.B = B; p.N = (int)N; p.C = C;
     p.score_thr = h->cfg.score_threshold; p.iou_thr = h->cfg.iou_threshold;
     p.max_per_class = h->cfg.max_boxes_per_class;
-    // resize_keeping_aspect_ratio is the identity for the accepted sizes: box_scaler = 1
-    for (int k = 0; k < 4; ++k) p.box_scaler[k] = 1.0f;
+    for (int k = 0; k < 4; ++k) p.box_scaler[k] = rd.box_scaler[k];    // model.py:67-68
     post_carve(p, ws);
     return SSD_OK;
 }
@@ -988,11 +1014,13 @@ extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, 
     if (!h || !images_dev || !boxes_dev || !labels_dev || !scores_dev || !num_boxes_dev)
         return fail(SSD_ERR_INVALID, "ssd_forward: null argument");
     if (!h->finalized) return fail(SSD_ERR_STATE, "ssd_forward before ssd_finalize");
-    if (B < 1 || H < 128 || W < 128 || H % 128 || W % 128)
-        return fail(SSD_ERR_INVALID, "ssd_forward: H and W must be positive multiples of 128 (pipeline.py:152; anchor_generator.py:6-10)");
-    const int mn = H < W ? H : W;
-    if (mn != h->cfg.min_dimension)
-        return fail(SSD_ERR_INVALID, "ssd_forward: min(H,W) must equal min_dimension (resize path of pipeline.py:138-194 is not part of this build yet)");
+    if (B < 1 || H < 1 || W < 1 || h->cfg.min_dimension < 128 || h->cfg.min_dimension % 128)
+        return fail(SSD_ERR_INVALID, "ssd_forward: B, H, W must be positive and min_dimension a multiple of 128 (pipeline.py:152)");
+    {
+        const ResizeDims rd = resize_dims(H, W, h->cfg.min_dimension, 128);
+        if ((long long)(rd.nh + rd.ph) * (rd.nw + rd.pw) > (1LL << 26))
+            return fail(SSD_ERR_INVALID, "ssd_forward: aspect ratio too extreme (resized image exceeds 64 Mpixel)");
+    }
     HIPCHK(hipSetDevice(h->cfg.device));
     if (B != h->pB || H != h->pH || W != h->pW) {
         HIPCHK(hipDeviceSynchronize());
@@ -1298,7 +1326,7 @@ extern "C" int ssd_first_conv(const uint8_t *images_dev, int32_t B, int32_t H, i
         }
         const long long rout = (long long)B * (H / 2) * (W / 2);
         SSDCHK(pool.alloc((void **)&tout, (size_t)rout * Cp * 4));
-        HIPCHK(launch_first_conv(images_dev, B, H, W, dw_, Cp, dm, ds, db, act, tout, s));
+        HIPCHK(launch_first_conv(images_dev, B, H, W, H, W, H, W, dw_, Cp, dm, ds, db, act, tout, s));
         HIPCHK(launch_permute_channels(tout, rout, Cout, Cp, 0, out_dev, s));
         HIPCHK(hipStreamSynchronize(s));
         return SSD_OK;

@@ -31,10 +31,15 @@ __device__ __forceinline__ v4f bn_act4(v4f v, const float *mean, const float *sf
 }
 
 // ---------------------------------------------------------------------------------------
-// K1: images uint8 [B,H,W,3] -> float(x)/255 -> 2x-1 -> conv 3x3 stride 2 'SAME'
-// (even H,W: taps at rows 2oy..2oy+2, zero beyond the bottom/right edge) -> BN -> act.
+// K1: images uint8 [B,srcH,srcW,3] -> float -> nearest-neighbour resize to [nh,nw] + zero pad to
+// [H,W] (resize_keeping_aspect_ratio, pipeline.py:138-194; TF r1.12 ResizeNearestNeighbor:
+// src = min(floorf(dst * in/out), in-1)) -> /255 -> 2x-1 -> conv 3x3 stride 2 'SAME' (even H,W:
+// taps at rows 2oy..2oy+2, zero beyond the bottom/right edge) -> BN -> act, all fused: the
+// resized / padded / normalised image never exists in memory.  Pixels of the pad band are
+// 0 before normalisation, i.e. 2*0-1 = -1 after it; taps beyond [H,W] contribute 0.
 // One thread = one output pixel x 4 output channels; weights [27][Cout] staged in LDS.
-__global__ __launch_bounds__(256) void first_conv_kernel(const uint8_t *__restrict__ img, int B, int H, int W,
+__global__ __launch_bounds__(256) void first_conv_kernel(const uint8_t *__restrict__ img, int B, int srcH, int srcW,
+                                                          int nh, int nw, int H, int W, float hs, float ws,
                                                           const float *__restrict__ w, int Cout,
                                                           const float *mean, const float *sf, const float *beta,
                                                           int act, float *__restrict__ out)
@@ -57,16 +62,22 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const uint8_t *__restri
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = 2 * oy + ky;
+            int sy = (int)floorf((float)iy * hs);
+            sy = sy < srcH - 1 ? sy : srcH - 1;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = 2 * ox + kx;
-                const bool ok = iy < H && ix < W;
-                const uint8_t *p = img + (((long long)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * 3;
+                int sx = (int)floorf((float)ix * ws);
+                sx = sx < srcW - 1 ? sx : srcW - 1;
+                const bool inside = iy < H && ix < W;      // else: zero padding of the convolution
+                const bool inimg = iy < nh && ix < nw;     // else (but inside): the resize's zero pad band
+                const uint8_t *p = img + (((long long)b * srcH + sy) * srcW + sx) * 3;
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci) {
-                    float x = (float)p[ci] * inv255;
+                    float x = inimg ? (float)p[ci] : 0.0f;
+                    x = x * inv255;
                     x = 2.0f * x - 1.0f;
-                    if (!ok) x = 0.0f;
+                    if (!inside) x = 0.0f;
                     const v4f wv = *(const v4f *)(wl + ((ky * 3 + kx) * 3 + ci) * Cout + c4 * 4);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i] = fmaf(x, wv[i], acc[i]);
@@ -78,15 +89,18 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const uint8_t *__restri
     }
 }
 
-hipError_t launch_first_conv(const uint8_t *img, int B, int H, int W, const float *w, int Cout, const float *mean,
-                             const float *sf, const float *beta, int act, float *out, hipStream_t s)
+hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int nh, int nw, int H, int W,
+                             const float *w, int Cout, const float *mean, const float *sf, const float *beta, int act,
+                             float *out, hipStream_t s)
 {
-    if (Cout % 4 || (H & 1) || (W & 1) || 27 * Cout * 4 > 65536) return hipErrorInvalidValue;
+    if (Cout % 4 || (H & 1) || (W & 1) || 27 * Cout * 4 > 65536 || nh < 1 || nw < 1 || nh > H || nw > W || srcH < 1 || srcW < 1)
+        return hipErrorInvalidValue;
+    const float hs = (float)srcH / (float)nh, ws = (float)srcW / (float)nw;
     const long long total = (long long)B * (H / 2) * (W / 2) * (Cout / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(first_conv_kernel, dim3((unsigned)blocks), dim3(256), 27 * Cout * sizeof(float), s, img, B, H, W,
-                       w, Cout, mean, sf, beta, act, out);
+    hipLaunchKernelGGL(first_conv_kernel, dim3((unsigned)blocks), dim3(256), 27 * Cout * sizeof(float), s, img, B, srcH,
+                       srcW, nh, nw, H, W, hs, ws, w, Cout, mean, sf, beta, act, out);
     return hipGetLastError();
 }
 

@@ -56,9 +56,10 @@ int igemm_tile_bn(int tile);
 hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s);
 
 // elementwise / memory-bound kernels -----------------------------------------------------
-hipError_t launch_first_conv(const uint8_t *img, int B, int H, int W, const float *w /*[27][Cout] phys-n*/,
-                             int Cout, const float *mean, const float *sf, const float *beta, int act,
-                             float *out, hipStream_t s);
+// source image [B,srcH,srcW,3] is NN-resized to [nh,nw], zero padded to [H,W] (even), normalised and convolved
+hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int nh, int nw, int H, int W,
+                             const float *w /*[27][Cout] phys-n*/, int Cout, const float *mean, const float *sf,
+                             const float *beta, int act, float *out, hipStream_t s);
 hipError_t launch_depthwise(const float *in, int B, int H, int W, int C, const float *w /*[9][C]*/,
                             int stride, int pad, int OH, int OW, const float *mean, const float *sf,
                             const float *beta, int act, float *out, hipStream_t s);

@@ -47,7 +47,8 @@ class Detector:
         self.device = device
 
     def detect_batch(self, images):
-        """images: uint8 ndarray [B,H,W,3] (or CUDA tensor) -> the graph outputs
+        """images: uint8 ndarray [B,H,W,3] (or CUDA tensor), any H, W (the graph's
+        resize_keeping_aspect_ratio is fused into the first kernel) -> the graph outputs
         (boxes [B,T,4], labels [B,T], scores [B,T], num_boxes [B]) as numpy arrays
         (model.py:70-73)."""
         torch = _torch()

@@ -132,8 +132,14 @@ def test_detector_drop_in(cuda, ssd, oracle_graph, tmp_path):
     assert (scores > 0.2).all() and len(scores) > 0
     with pytest.raises(ValueError):
         det(img.astype(np.float32))
-    with pytest.raises(ssd.SsdError):
-        det(np.zeros((100, 128, 3), np.uint8))              # not a multiple of 128
+    # any image size: resize_keeping_aspect_ratio (pipeline.py:138-194) is fused into the first kernel
+    for shape in [(100, 151, 3), (300, 128, 3), (128, 128, 3), (77, 201, 3)]:
+        im = np.random.default_rng(shape[0]).integers(0, 256, shape, dtype=np.uint8)
+        b2, l2, s2 = det(im, score_threshold=0.2)
+        r2 = oracle_graph.detector_call(oracle_graph.forward(im[None], Wt, ssd.load_config(params)), 0.2)
+        assert np.array_equal(l2, r2[1]) and len(l2) > 0, shape
+        assert np.abs(s2 - r2[2]).max() <= TOL and np.abs(b2 - r2[0]).max() <= TOL, shape
+        assert np.array_equal(b2, r2[0]) and np.array_equal(s2, r2[2]), shape
     with pytest.raises(FileNotFoundError):
         ssd.Detector(str(tmp_path / "nope.npz"))
     # SSD mirror (ssd.py:10-69): raw predictions + get_predictions with other thresholds

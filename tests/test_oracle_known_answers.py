@@ -145,6 +145,26 @@ def test_upsample_add(oracle_ops):
             assert (up[0, 2 * i:2 * i + 2, 2 * j:2 * j + 2, 0] == c[0, i, j, 0]).all()
 
 
+def test_resize_keeping_aspect_ratio(oracle_ops):
+    # identity at 896x640, box_scaler = 1
+    dims, bs = oracle_ops.resize_dims(640, 896, 640, 128)
+    assert dims == (640, 896, 0, 0) and (bs == 1).all()
+    # 480x640 (HxW): scale 640/480, long side round(640*1.3333334)=853 -> padded to 896
+    dims, bs = oracle_ops.resize_dims(480, 640, 640, 128)
+    assert dims == (640, 853, 0, 43) and abs(bs[1] - 853 / 896) < 1e-7 and bs[0] == 1
+    dims, bs = oracle_ops.resize_dims(500, 375, 640, 128)       # portrait: height is the long side
+    assert dims == (853, 640, 43, 0) and abs(bs[0] - 853 / 896) < 1e-7
+    # half-to-even rounding of the long side (tf.round): 3 * 0.5 = 1.5 -> 2, 5 * 0.5 = 2.5 -> 2
+    # nearest neighbour: src = min(floor(dst * in/out), in-1); pad band is zero
+    img = np.arange(2 * 3, dtype=np.float32).reshape(1, 2, 3, 1)
+    out = oracle_ops.resize_pad(img, (4, 6, 1, 2))
+    assert out.shape == (1, 5, 8, 1)
+    assert (out[0, :4, :6, 0] == np.repeat(np.repeat(img[0, :, :, 0], 2, 0), 2, 1)).all()
+    assert not out[0, 4:].any() and not out[0, :, 6:].any()
+    up = oracle_ops.resize_pad(np.arange(5, dtype=np.float32).reshape(1, 1, 5, 1), (1, 3, 0, 0))
+    assert list(up[0, 0, :, 0]) == [0.0, 1.0, 3.0]             # floor(0*5/3), floor(1*1.667), floor(2*1.667)
+
+
 def test_preprocess(oracle_ops):
     img = np.array([[[[0, 255, 128]]]], np.uint8)
     out = oracle_ops.preprocess(img)
