@@ -15,6 +15,7 @@ import numpy as np
 
 from .config import load_config
 from .ssd import Engine, _torch
+from .pb_import import load_pb_weights
 from .variables import load_weights
 
 
@@ -23,7 +24,8 @@ class Detector:
                  config=None):
         """
         Arguments:
-            model_path: path to the weight file (.npz), or a dict {variable name: ndarray}.
+            model_path: path to the reference's frozen graph (.pb, read without TensorFlow),
+                to this build's weight file (.npz), or a dict {variable name: ndarray}.
             gpu_memory_fraction: accepted for compatibility and ignored (the library
                 allocates exactly the arena the network needs).
             visible_device_list: a string like the reference's; the first entry is the HIP
@@ -38,9 +40,12 @@ class Detector:
         else:
             if not os.path.exists(model_path):
                 raise FileNotFoundError(model_path)       # tf.gfile.GFile would raise too
-            weights = load_weights(model_path)
             if config is None:
                 config = os.path.join(os.path.dirname(os.path.abspath(model_path)), "config.json")
+            if str(model_path).endswith(".pb"):            # the reference's frozen graph (create_pb.py:57-85)
+                weights = load_pb_weights(model_path, load_config(config))
+            else:
+                weights = load_weights(model_path)
         self.params = load_config(config)
         device = int(str(visible_device_list).split(",")[0])
         self.engine = Engine(self.params, weights, device=device)

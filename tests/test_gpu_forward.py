@@ -142,6 +142,11 @@ def test_detector_drop_in(cuda, ssd, oracle_graph, tmp_path):
         assert np.array_equal(b2, r2[0]) and np.array_equal(s2, r2[2]), shape
     with pytest.raises(FileNotFoundError):
         ssd.Detector(str(tmp_path / "nope.npz"))
+    # the reference's own container: a frozen GraphDef (.pb), read without TensorFlow
+    ssd.write_frozen_graph(Wt, str(tmp_path / "model.pb"))
+    det_pb = ssd.Detector(str(tmp_path / "model.pb"))
+    b3, l3, s3 = det_pb(img, score_threshold=0.2)
+    assert np.array_equal(b3, boxes) and np.array_equal(l3, labels) and np.array_equal(s3, scores)
     # SSD mirror (ssd.py:10-69): raw predictions + get_predictions with other thresholds
     s = ssd.SSD(cuda.from_numpy(img[None].copy()).cuda(), det.engine)
     pred = s.get_predictions(score_threshold=0.3, iou_threshold=0.5, max_boxes_per_class=10)

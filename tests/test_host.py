@@ -54,6 +54,41 @@ def test_weights_roundtrip(ssd, tmp_path):
     assert abs(float(W["class_net/logits/bias"][0]) + np.log(99.0)) < 1e-6   # box_predictor.py:121-127
 
 
+def test_frozen_graph_reader(ssd, tmp_path):
+    """`.pb` weights without TensorFlow: GraphDef wire format round trip (Const nodes with
+    tensor_content or packed float_val, non-Const nodes skipped, 'import/' prefix stripped)."""
+    p = {"backbone": "shufflenet", "depth_multiplier": 0.5, "num_classes": 2, "score_threshold": 0.1,
+         "iou_threshold": 0.5, "max_boxes_per_class": 5, "min_dimension": 128}
+    W = ssd.synthetic_weights(p, seed=4)
+    names = list(W)
+    data = ssd.write_frozen_graph(W, str(tmp_path / "model.pb"), use_float_val=set(names[::7]))
+    consts = ssd.read_frozen_graph(str(tmp_path / "model.pb"))
+    assert set(W) <= set(consts) and "images" not in consts
+    L = ssd.load_pb_weights(data, p)
+    assert set(L) == set(W) and all(np.array_equal(W[k], L[k]) and L[k].dtype == np.float32 for k in W)
+    pref = ssd.write_frozen_graph({"import/" + k: v for k, v in list(W.items())[:3]}, extra_nodes=False)
+    assert set(ssd.read_frozen_graph(pref)) == set(names[:3])
+    broken = dict(W)
+    del broken[names[5]]
+    with pytest.raises(KeyError):
+        ssd.load_pb_weights(ssd.write_frozen_graph(broken), p)
+    with pytest.raises(ValueError):
+        ssd.read_frozen_graph(data[:len(data) // 2 + 3])
+
+
+def test_coco_records(ssd):
+    """evaluate_on_COCO.ipynb cell 10 record construction (no GPU: a stub detector)."""
+    def det(image, score_threshold=0.15):
+        return (np.array([[0.1, 0.2, 0.5, 0.9], [0.0, 0.0, 1.0, 1.0]], np.float32), np.array([0, 79], np.int32),
+                np.array([0.9, 0.2], np.float32))
+    cats = [{"name": n, "id": i + 1 if i < 11 else i + 2} for i, n in enumerate(ssd.coco_eval.COCO_NAMES)]
+    m = ssd.coco_eval.integer_to_coco_id(cats)
+    assert m[0] == 1 and m[79] == 81 and len(m) == 80
+    recs = ssd.coco_eval.detection_records(det, np.zeros((480, 640, 3), np.uint8), 42, m)
+    assert recs[0] == {"image_id": 42, "category_id": 1, "bbox": [128, 48, 448, 192], "score": float(np.float32(0.9))}
+    assert recs[1]["bbox"] == [0, 0, 640, 480] and recs[1]["category_id"] == 81
+
+
 def test_abi_exports_every_declared_symbol(ssd):
     """The C-ABI library loads and exports every function include/ssd_hip.h declares."""
     hdr = open(os.path.join(ROOT, "include", "ssd_hip.h")).read()
