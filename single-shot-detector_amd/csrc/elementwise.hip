@@ -38,7 +38,9 @@ __device__ __forceinline__ v4f bn_act4(v4f v, const float *mean, const float *sf
 // resized / padded / normalised image never exists in memory.  Pixels of the pad band are
 // 0 before normalisation, i.e. 2*0-1 = -1 after it; taps beyond [H,W] contribute 0.
 // One thread = one output pixel x 4 output channels; weights [27][Cout] staged in LDS.
-__global__ __launch_bounds__(256) void first_conv_kernel(const uint8_t *__restrict__ img, int B, int srcH, int srcW,
+// IDENT: the resize is the identity (srcH == nh == H, srcW == nw == W): no index arithmetic.
+template <bool IDENT>
+__global__ __launch_bounds__(256, IDENT ? 4 : 2) void first_conv_kernel(const uint8_t *__restrict__ img, int B, int srcH, int srcW,
                                                           int nh, int nw, int H, int W, float hs, float ws,
                                                           const float *__restrict__ w, int Cout,
                                                           const float *mean, const float *sf, const float *beta,
@@ -62,25 +64,42 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const uint8_t *__restri
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = 2 * oy + ky;
-            int sy = (int)floorf((float)iy * hs);
-            sy = sy < srcH - 1 ? sy : srcH - 1;
+            int sy = iy;
+            if constexpr (!IDENT) {
+                sy = (int)floorf((float)iy * hs);
+                sy = sy < srcH - 1 ? sy : srcH - 1;
+            }
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = 2 * ox + kx;
-                int sx = (int)floorf((float)ix * ws);
-                sx = sx < srcW - 1 ? sx : srcW - 1;
-                const bool inside = iy < H && ix < W;      // else: zero padding of the convolution
-                const bool inimg = iy < nh && ix < nw;     // else (but inside): the resize's zero pad band
-                const uint8_t *p = img + (((long long)b * srcH + sy) * srcW + sx) * 3;
+                if constexpr (IDENT) {
+                    const bool ok = iy < H && ix < W;
+                    const uint8_t *p = img + (((long long)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * 3;
 #pragma unroll
-                for (int ci = 0; ci < 3; ++ci) {
-                    float x = inimg ? (float)p[ci] : 0.0f;
-                    x = x * inv255;
-                    x = 2.0f * x - 1.0f;
-                    if (!inside) x = 0.0f;
-                    const v4f wv = *(const v4f *)(wl + ((ky * 3 + kx) * 3 + ci) * Cout + c4 * 4);
+                    for (int ci = 0; ci < 3; ++ci) {
+                        float x = (float)p[ci] * inv255;
+                        x = 2.0f * x - 1.0f;
+                        if (!ok) x = 0.0f;
+                        const v4f wv = *(const v4f *)(wl + ((ky * 3 + kx) * 3 + ci) * Cout + c4 * 4);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(x, wv[i], acc[i]);
+                        for (int i = 0; i < 4; ++i) acc[i] = fmaf(x, wv[i], acc[i]);
+                    }
+                } else {
+                    int sx = (int)floorf((float)ix * ws);
+                    sx = sx < srcW - 1 ? sx : srcW - 1;
+                    const bool inside = iy < H && ix < W;      // else: zero padding of the convolution
+                    const bool inimg = iy < nh && ix < nw;     // else (but inside): the resize's zero pad band
+                    const uint8_t *p = img + (((long long)b * srcH + (inimg ? sy : 0)) * srcW + (inimg ? sx : 0)) * 3;
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) {
+                        float x = inimg ? (float)p[ci] : 0.0f;
+                        x = x * inv255;
+                        x = 2.0f * x - 1.0f;
+                        if (!inside) x = 0.0f;
+                        const v4f wv = *(const v4f *)(wl + ((ky * 3 + kx) * 3 + ci) * Cout + c4 * 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] = fmaf(x, wv[i], acc[i]);
+                    }
                 }
             }
         }
@@ -99,8 +118,12 @@ hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int 
     const long long total = (long long)B * (H / 2) * (W / 2) * (Cout / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(first_conv_kernel, dim3((unsigned)blocks), dim3(256), 27 * Cout * sizeof(float), s, img, B, srcH,
-                       srcW, nh, nw, H, W, hs, ws, w, Cout, mean, sf, beta, act, out);
+    if (srcH == nh && nh == H && srcW == nw && nw == W)
+        hipLaunchKernelGGL(first_conv_kernel<true>, dim3((unsigned)blocks), dim3(256), 27 * Cout * sizeof(float), s, img, B,
+                           srcH, srcW, nh, nw, H, W, hs, ws, w, Cout, mean, sf, beta, act, out);
+    else
+        hipLaunchKernelGGL(first_conv_kernel<false>, dim3((unsigned)blocks), dim3(256), 27 * Cout * sizeof(float), s, img, B,
+                           srcH, srcW, nh, nw, H, W, hs, ws, w, Cout, mean, sf, beta, act, out);
     return hipGetLastError();
 }
 

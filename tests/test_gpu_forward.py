@@ -95,11 +95,13 @@ def test_sub_batch_plans(cuda, ssd, oracle_graph, monkeypatch):
     eng.close()
 
 
-def test_forward_vs_oracle_full_size(cuda, ssd, oracle_graph):
-    """BASELINE config 2: MobileNet-v1 + FPN + heads at 640x896 (H x W), batch 1."""
-    params = ssd.load_config(os.path.join(HERE, "golden", "config_mobilenet.json"))
-    Wt = ssd.synthetic_weights(params, seed=0, logits_bias=-4.0)
-    img = np.random.default_rng(0).integers(0, 256, (1, 640, 896, 3), dtype=np.uint8)
+@pytest.mark.parametrize("cfg,H,W", [("config_mobilenet.json", 640, 896), ("config_shufflenet.json", 640, 640)])
+def test_forward_vs_oracle_full_size(cuda, ssd, oracle_graph, cfg, H, W):
+    """BASELINE config 2 (MobileNet-v1 + FPN + heads at 640x896, batch 1) and config 4's
+    network (ShuffleNet-v2 + FPN at 640x640) at full size."""
+    params = ssd.load_config(os.path.join(HERE, "golden", cfg))
+    Wt = ssd.synthetic_weights(params, seed=0, logits_bias=-4.0 if "mobile" in cfg else -9.0)
+    img = np.random.default_rng(0).integers(0, 256, (1, H, W, 3), dtype=np.uint8)
     keep = {}
     ref = oracle_graph.forward(img, Wt, params, keep)
     eng = ssd.Engine(params, Wt)
@@ -107,7 +109,7 @@ def test_forward_vs_oracle_full_size(cuda, ssd, oracle_graph):
     assert out[0].shape == (1, 2000, 4) and out[1].dtype == np.int32 and out[3].dtype == np.int32
     stage_check(eng, keep, STAGES, "full")
     compare_outputs(out, ref, "full size")
-    assert ref["num_boxes"][0] > 50
+    assert ref["num_boxes"][0] > 50, ref["num_boxes"]
     eng.close()
 
 
