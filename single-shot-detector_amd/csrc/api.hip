@@ -172,6 +172,11 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
         long long t128 = 0;
         for (size_t i = 0; i < lv.size(); ++i) t128 += ((long long)B * lv[i].OH * lv[i].OW + 127) / 128;
         if (t128 * (cw.CoutPad / 128) < 2 * 256) tile = IGEMM_64x64;
+        // tests: SSD_IGEMM_TILE=128 / 64 pins the choice so both variants see every shape
+        if (const char *e = getenv("SSD_IGEMM_TILE")) {
+            if (atoi(e) == 128) tile = IGEMM_128x128;
+            else if (atoi(e) == 64) tile = IGEMM_64x64;
+        }
     }
     a.n_tiles_n = cw.CoutPad / igemm_tile_bn(tile);
     a.dense_out = dense ? 1 : 0;

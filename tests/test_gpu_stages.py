@@ -52,8 +52,12 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("tile", ["128", "64"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
-def test_conv2d(cuda, ssd, oracle_ops, case):
+def test_conv2d(cuda, ssd, oracle_ops, case, tile, monkeypatch):
+    # the library picks 64x64 tiles for small problems and 128x128 for large ones: pin each
+    # in turn so both kernels see every shape (narrow outputs keep their 128x64 / 128x32 tiles)
+    monkeypatch.setenv("SSD_IGEMM_TILE", tile)
     B, H, W, Cin, Cout, k, stride, mode, use_bn, use_bias, act, use_up = case
     rng = np.random.default_rng(100 + CONV_CASES.index(case))
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
