@@ -143,7 +143,10 @@ struct DwW { float *w = nullptr, *mean = nullptr, *sf = nullptr, *beta = nullptr
 // ----------------------------------------------------------------------------- ops
 struct Op {
     int cls;            // profile class
-    int stream = 0;     // 0: the caller's stream, 1: the handle's second stream (class tower)
+    int stream = 0;     // 0: the plan's main stream, 1: its second stream
+    std::vector<int> deps;          // indices of ops (on the other stream) that must have finished
+    hipEvent_t done = nullptr;      // recorded after the op when another op depends on it
+    bool fpn_end = false;           // last op of backbone + FPN (sub-batch stagger point)
     double flops, bytes;
     std::function<hipError_t(hipStream_t)> run;
 };
@@ -221,6 +224,7 @@ struct Plan {
     hipStream_t s_main = nullptr;       // null: the caller's stream (sub-batch 0)
     hipStream_t s_aux = nullptr;        // class tower beside the box tower (box_predictor.py:47-59)
     hipEvent_t ev_fpn = nullptr, ev_join = nullptr, ev_done = nullptr;
+    int last_aux = -1;                  // index of the last op on the second stream
 };
 
 struct ssd_handle {
@@ -253,6 +257,8 @@ struct ssd_handle {
 static void free_plans(ssd_handle *h)
 {
     for (Plan *pl : h->plans) {
+        for (Op &op : pl->ops)
+            if (op.done) (void)hipEventDestroy(op.done);
         pl->pool.free_all();
         if (pl->s_main) (void)hipStreamDestroy(pl->s_main);
         if (pl->s_aux) (void)hipStreamDestroy(pl->s_aux);
@@ -860,34 +866,46 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     SSDCHK(falloc(&X3, (long long)B * py.h[0] * py.w[0] * 256));
     SSDCHK(falloc(&T6, (long long)B * py.h[3] * py.w[3] * 256));
     auto lvl = [&](int l, int CoutP) { return dense_level(py.h[l], py.w[l], py.h[l], py.w[l], CoutP); };
-    // x5 = lateral5(c5); p5 = conv(x5)
-    pl.ops.push_back(make_conv_op(h->lat[2], C5, X5, nullptr, nullptr, B, 1, 0, SSD_ACT_NONE, {lvl(2, 256)}, true));
-    {
-        LevelDesc d = lvl(2, 256);
-        d.out_off = py.off[2];
-        pl.ops.push_back(make_conv_op(h->pconv[2], X5, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true));
-    }
+    // Two streams, explicit dependencies.  Main: lateral5 -> lateral4 (+up) -> lateral3 (+up) -> p3
+    // (the critical path); second stream: p6 -> p7 (need only c5), p5 (needs x5), p4 (needs x4).
+    // All of them are the same 3x3 kernel, and two such kernels side by side fill each other's
+    // tails (measured: paired tower layers run at 0.91 of the MFMA peak, a lone one at 0.85).
+    auto push = [&](Op op, int stream, std::vector<int> deps = {}) {
+        op.stream = stream;
+        op.deps = deps;
+        pl.ops.push_back(op);
+        if (stream == 1) pl.last_aux = (int)pl.ops.size() - 1;
+        return (int)pl.ops.size() - 1;
+    };
+    const int id_c5 = (int)pl.ops.size() - 1;          // last backbone op (produces c5)
+    const int id_l5 = push(make_conv_op(h->lat[2], C5, X5, nullptr, nullptr, B, 1, 0, SSD_ACT_NONE, {lvl(2, 256)}, true), 0);
     {   // p6 = conv s2 (c5): BN+ReLU -> P6, ReLU(raw) -> T6 (input of p7, :60)
         LevelDesc d = dense_level(py.h[2], py.w[2], py.h[3], py.w[3], 256);
         d.out_off = py.off[3];
-        Op op = make_conv_op(h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true);
-        pl.ops.push_back(op);
+        push(make_conv_op(h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true), 1, {id_c5});
         LevelDesc d7 = dense_level(py.h[3], py.w[3], py.h[4], py.w[4], 256);
         d7.out_off = py.off[4];
-        pl.ops.push_back(make_conv_op(h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true));
+        push(make_conv_op(h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true), 1);
+    }
+    {   // p5 = conv(x5)
+        LevelDesc d = lvl(2, 256);
+        d.out_off = py.off[2];
+        push(make_conv_op(h->pconv[2], X5, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true), 1, {id_l5});
     }
     // x4 = up(x5) + lateral4(c4); p4;  x3 = up(x4) + lateral3(c3); p3
-    pl.ops.push_back(make_conv_op(h->lat[1], C4, X4, nullptr, X5, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true));
+    const int id_l4 = push(make_conv_op(h->lat[1], C4, X4, nullptr, X5, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true), 0);
+    int id_p4, id_p3;
     {
         LevelDesc d = lvl(1, 256);
         d.out_off = py.off[1];
-        pl.ops.push_back(make_conv_op(h->pconv[1], X4, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true));
+        id_p4 = push(make_conv_op(h->pconv[1], X4, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true), 1, {id_l4});
     }
-    pl.ops.push_back(make_conv_op(h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true));
+    push(make_conv_op(h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true), 0);
     {
         LevelDesc d = lvl(0, 256);
         d.out_off = py.off[0];
-        pl.ops.push_back(make_conv_op(h->pconv[0], X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true));
+        id_p3 = push(make_conv_op(h->pconv[0], X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true), 0);
+        pl.ops[id_p3].fpn_end = true;
     }
     for (int l = 0; l < 5; ++l) {
         char nm[8];
@@ -895,7 +913,8 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         pl.retained[nm] = Retained{P + py.off[l], B, py.h[l], py.w[l], 256, 256, true};
     }
 
-    // ---------------- heads (box_predictor.py:36-155), all levels per launch
+    // ---------------- heads (box_predictor.py:36-155), all levels per launch; box tower on the
+    // main stream, class tower on the second stream (independent chains)
     const int C = h->cfg.num_classes, A = 6;
     long long N = 0, aoff[5];
     for (int l = 0; l < 5; ++l) { aoff[l] = N; N += (long long)py.h[l] * py.w[l] * A; }
@@ -929,14 +948,19 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         }
         tower_ops[t].push_back(make_conv_op(h->final_[t], in, t == 0 ? codes : logits, nullptr, nullptr, B, 1, 1, SSD_ACT_NONE, lv, false));
     }
-    // enqueue order interleaved so both hardware queues stay fed; class tower (t = 1) on the
-    // second stream
+    // enqueue order interleaved so both hardware queues stay fed.  The first box-tower layer
+    // (main) needs p4..p7 from the second stream, the first class-tower layer (second stream)
+    // needs p3 from the main stream.
     for (size_t i = 0; i < tower_ops[0].size(); ++i)
         for (int t = 1; t >= 0; --t) {
-            Op op = tower_ops[t][i];
-            op.stream = t;
-            pl.ops.push_back(op);
+            std::vector<int> deps;
+            if (i == 0) deps.push_back(t == 0 ? id_p4 : id_p3);
+            push(tower_ops[t][i], t, deps);
         }
+    // events for every op another stream waits on
+    for (const Op &op : pl.ops)
+        for (int d : op.deps)
+            if (!pl.ops[d].done) HIPCHK(hipEventCreateWithFlags(&pl.ops[d].done, hipEventDisableTiming));
     pl.retained["encoded_boxes"] = Retained{codes, B, 1, (int)N, 4, 4, false};
     pl.retained["class_predictions"] = Retained{logits, B, 1, (int)N, C, C, false};
 
@@ -1051,17 +1075,16 @@ extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, 
             HIPCHK(hipStreamWaitEvent(sm, h->ev_start, 0));
             HIPCHK(hipStreamWaitEvent(sm, h->plans[k - 1]->ev_fpn, 0));
         }
-        bool forked = false;
+        bool aux_used = false;
         for (const Op &op : pl.ops) {
-            if (op.stream == 1 && !forked) {        // fork: the second stream starts after the FPN
-                HIPCHK(hipEventRecord(pl.ev_fpn, sm));
-                HIPCHK(hipStreamWaitEvent(pl.s_aux, pl.ev_fpn, 0));
-                forked = true;
-            }
-            HIPCHK(run_op(h, op, op.stream == 1 ? pl.s_aux : sm));
+            hipStream_t st = op.stream == 1 ? pl.s_aux : sm;
+            for (int d : op.deps) HIPCHK(hipStreamWaitEvent(st, pl.ops[d].done, 0));
+            HIPCHK(run_op(h, op, st));
+            if (op.done) HIPCHK(hipEventRecord(op.done, st));
+            if (op.fpn_end) HIPCHK(hipEventRecord(pl.ev_fpn, sm));
+            aux_used |= op.stream == 1;
         }
-        if (!forked) HIPCHK(hipEventRecord(pl.ev_fpn, sm));
-        if (forked) {                               // join before the post-processing reads the logits
+        if (aux_used) {                             // join before the post-processing reads the logits
             HIPCHK(hipEventRecord(pl.ev_join, pl.s_aux));
             HIPCHK(hipStreamWaitEvent(sm, pl.ev_join, 0));
         }
