@@ -26,8 +26,11 @@ run("fpn p3 3x3 256->256 80x112", 80, 112, 256, 256, 3, 1, [0])
 run("logits 3x3 256->480 5 levels", 80, 112, 256, 480, 3, 1, [0], pyramid=1)
 run("boxes 3x3 256->24 5 levels", 80, 112, 256, 24, 3, 1, [2], pyramid=1)
 run("pw 32->64 320x448", 320, 448, 32, 64, 1, 1, [1, 0])
-run("pw 64->128 160x224", 160, 224, 64, 128, 1, 1, [0])
-run("pw 128->128 160x224", 160, 224, 128, 128, 1, 1, [0])
-run("pw 256->256 80x112", 80, 112, 256, 256, 1, 1, [0])
-run("pw 512->512 40x56", 40, 56, 512, 512, 1, 1, [0])
-run("pw 1024->1024 20x28", 20, 28, 1024, 1024, 1, 1, [0])
+run("pw 64->128 160x224", 160, 224, 64, 128, 1, 1, [0, 1, 5])
+run("pw 128->128 160x224", 160, 224, 128, 128, 1, 1, [0, 1, 5])
+run("pw 128->256 80x112", 80, 112, 128, 256, 1, 1, [0, 1, 5])
+run("pw 256->256 80x112", 80, 112, 256, 256, 1, 1, [0, 1, 5])
+run("pw 256->512 40x56", 40, 56, 256, 512, 1, 1, [0, 1, 5])
+run("pw 512->512 40x56", 40, 56, 512, 512, 1, 1, [0, 1, 5])
+run("pw 512->1024 20x28", 20, 28, 512, 1024, 1, 1, [0, 1, 5])
+run("pw 1024->1024 20x28", 20, 28, 1024, 1024, 1, 1, [0, 1, 5])
