@@ -227,6 +227,14 @@ struct Plan {
     int last_aux = -1;                  // index of the last op on the second stream
 };
 
+struct GraphKey {
+    const void *img; void *boxes, *labels, *scores, *num; int B, H, W;
+    bool operator==(const GraphKey &o) const
+    {
+        return img == o.img && boxes == o.boxes && labels == o.labels && scores == o.scores && num == o.num && B == o.B && H == o.H && W == o.W;
+    }
+};
+
 struct ssd_handle {
     ssd_config cfg;
     std::map<std::string, Tensor> vars;
@@ -246,6 +254,11 @@ struct ssd_handle {
     std::vector<Plan *> plans;
     hipEvent_t ev_start = nullptr;
     const uint8_t *cur_images = nullptr;
+    // hipGraph replay
+    hipStream_t gstream = nullptr;
+    hipEvent_t ev_gin = nullptr, ev_gout = nullptr;
+    std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
+    GraphKey last_key{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     // profiling
     bool profiling = false;
     std::vector<EvPair> evs;
@@ -256,6 +269,9 @@ struct ssd_handle {
 
 static void free_plans(ssd_handle *h)
 {
+    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.second);
+    h->graphs.clear();
+    h->last_key = GraphKey{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     for (Plan *pl : h->plans) {
         for (Op &op : pl->ops)
             if (op.done) (void)hipEventDestroy(op.done);
@@ -594,7 +610,10 @@ extern "C" int ssd_create(const ssd_config *cfg, ssd_handle **out)
     HIPCHK(hipSetDevice(cfg->device));
     ssd_handle *h = new ssd_handle();
     h->cfg = *cfg;
-    if (hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_gin, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_gout, hipEventDisableTiming) != hipSuccess) {
         delete h;
         return fail(SSD_ERR_HIP, "ssd_create: cannot create events");
     }
@@ -609,8 +628,11 @@ extern "C" void ssd_destroy(ssd_handle *h)
     (void)hipDeviceSynchronize();
     for (auto &e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto r : h->ref_evs) (void)hipEventDestroy(r);
-    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     free_plans(h);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->ev_gin) (void)hipEventDestroy(h->ev_gin);
+    if (h->ev_gout) (void)hipEventDestroy(h->ev_gout);
+    if (h->gstream) (void)hipStreamDestroy(h->gstream);
     h->wpool.free_all();
     delete h;
 }
@@ -1037,26 +1059,11 @@ static int make_plans(ssd_handle *h, int B, int H, int W)
     return SSD_OK;
 }
 
-extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
-                           int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, void *stream)
+// Enqueues one forward on stream `s` (plus the plans' internal streams): kernels only, no host
+// synchronisation -- also what a hipGraph capture records.
+static int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, int32_t *labels_dev,
+                           float *scores_dev, int32_t *num_boxes_dev, hipStream_t s)
 {
-    if (!h || !images_dev || !boxes_dev || !labels_dev || !scores_dev || !num_boxes_dev)
-        return fail(SSD_ERR_INVALID, "ssd_forward: null argument");
-    if (!h->finalized) return fail(SSD_ERR_STATE, "ssd_forward before ssd_finalize");
-    if (B < 1 || H < 1 || W < 1 || h->cfg.min_dimension < 128 || h->cfg.min_dimension % 128)
-        return fail(SSD_ERR_INVALID, "ssd_forward: B, H, W must be positive and min_dimension a multiple of 128 (pipeline.py:152)");
-    {
-        const ResizeDims rd = resize_dims(H, W, h->cfg.min_dimension, 128);
-        if ((long long)(rd.nh + rd.ph) * (rd.nw + rd.pw) > (1LL << 26))
-            return fail(SSD_ERR_INVALID, "ssd_forward: aspect ratio too extreme (resized image exceeds 64 Mpixel)");
-    }
-    HIPCHK(hipSetDevice(h->cfg.device));
-    if (B != h->pB || H != h->pH || W != h->pW) {
-        HIPCHK(hipDeviceSynchronize());
-        int rc = make_plans(h, B, H, W);
-        if (rc != SSD_OK) { free_plans(h); return rc; }
-    }
-    hipStream_t s = (hipStream_t)stream;
     h->cur_images = images_dev;
     if (h->profiling) {
         hipEvent_t ref;
@@ -1103,6 +1110,67 @@ extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, 
         if (k > 0) HIPCHK(hipEventRecord(pl.ev_done, sm));
     }
     for (size_t k = 1; k < h->plans.size(); ++k) HIPCHK(hipStreamWaitEvent(s, h->plans[k]->ev_done, 0));
+    return SSD_OK;
+}
+
+extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
+                           int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, void *stream)
+{
+    if (!h || !images_dev || !boxes_dev || !labels_dev || !scores_dev || !num_boxes_dev)
+        return fail(SSD_ERR_INVALID, "ssd_forward: null argument");
+    if (!h->finalized) return fail(SSD_ERR_STATE, "ssd_forward before ssd_finalize");
+    if (B < 1 || H < 1 || W < 1 || h->cfg.min_dimension < 128 || h->cfg.min_dimension % 128)
+        return fail(SSD_ERR_INVALID, "ssd_forward: B, H, W must be positive and min_dimension a multiple of 128 (pipeline.py:152)");
+    {
+        const ResizeDims rd = resize_dims(H, W, h->cfg.min_dimension, 128);
+        if ((long long)(rd.nh + rd.ph) * (rd.nw + rd.pw) > (1LL << 26))
+            return fail(SSD_ERR_INVALID, "ssd_forward: aspect ratio too extreme (resized image exceeds 64 Mpixel)");
+    }
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (B != h->pB || H != h->pH || W != h->pW) {
+        HIPCHK(hipDeviceSynchronize());
+        int rc = make_plans(h, B, H, W);
+        if (rc != SSD_OK) { free_plans(h); return rc; }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    // hipGraph replay (launch-bound regime: batch 1 is ~35 short kernels on two streams).  A
+    // forward whose pointers, shape and stream repeat is captured on the handle's own stream at
+    // its second occurrence and replayed from then on; profiling or SSD_GRAPH=0 keep it eager.
+    static int use_graph = -1;
+    // Measured (batch 1, 640x896): replay 2.49 ms vs eager 2.33 ms p50 -- the forward is GPU-bound
+    // (host enqueue 0.9 ms < 2.3 ms of kernels), so replay is OFF unless SSD_GRAPH=1.
+    if (use_graph < 0) { const char *e = getenv("SSD_GRAPH"); use_graph = e ? atoi(e) : 0; }
+    if (!use_graph || h->profiling || h->plans.size() != 1)
+        return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, s);
+    GraphKey key{images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, B, H, W};
+    hipGraphExec_t exec = nullptr;
+    for (auto &g : h->graphs)
+        if (g.first == key) exec = g.second;
+    if (!exec) {
+        if (!(h->last_key == key)) {             // first sighting: run eagerly (lazy one-time inits happen here)
+            h->last_key = key;
+            return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, s);
+        }
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(h->gstream, hipStreamCaptureModeRelaxed));
+        int rc = enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, h->gstream);
+        hipError_t ce = hipStreamEndCapture(h->gstream, &graph);
+        if (rc != SSD_OK || ce != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            use_graph = 0;                       // capture unsupported here: stay eager from now on
+            return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, s);
+        }
+        HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        if (h->graphs.size() >= 4) { (void)hipGraphExecDestroy(h->graphs.front().second); h->graphs.erase(h->graphs.begin()); }
+        h->graphs.push_back({key, exec});
+    }
+    HIPCHK(hipEventRecord(h->ev_gin, s));
+    HIPCHK(hipStreamWaitEvent(h->gstream, h->ev_gin, 0));
+    HIPCHK(hipGraphLaunch(exec, h->gstream));
+    HIPCHK(hipEventRecord(h->ev_gout, h->gstream));
+    HIPCHK(hipStreamWaitEvent(s, h->ev_gout, 0));
     return SSD_OK;
 }
 

@@ -56,12 +56,11 @@ class Detector:
         resize_keeping_aspect_ratio is fused into the first kernel) -> the graph outputs
         (boxes [B,T,4], labels [B,T], scores [B,T], num_boxes [B]) as numpy arrays
         (model.py:70-73)."""
-        torch = _torch()
+        _torch()
         if isinstance(images, np.ndarray):
             if images.dtype != np.uint8 or images.ndim != 4 or images.shape[3] != 3:
                 raise ValueError("images must be a uint8 array of shape [B, height, width, 3]")
-            images = torch.from_numpy(np.ascontiguousarray(images)).to("cuda:%d" % self.device)
-        boxes, labels, scores, num = self.engine.forward(images)
+        boxes, labels, scores, num = self.engine.forward_cached(images)
         return boxes.cpu().numpy(), labels.cpu().numpy(), scores.cpu().numpy(), num.cpu().numpy()
 
     def __call__(self, image, score_threshold=0.1):

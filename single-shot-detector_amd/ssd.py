@@ -218,6 +218,7 @@ class Engine:
             self._h = None
             raise
         self.T = int(params["num_classes"]) * int(params["max_boxes_per_class"])
+        self._static = {}
 
     def close(self):
         if getattr(self, "_h", None):
@@ -248,6 +249,33 @@ class Engine:
         check(lib().ssd_forward(self._h, _ptr(images), B, H, W, _ptr(boxes), _ptr(labels),
                                 _ptr(scores), _ptr(num), _stream(torch)))
         return boxes, labels, scores, num
+
+    def forward_cached(self, images):
+        """Serving form of `forward`: `images` (uint8 numpy array or tensor [B,H,W,3]) is copied
+        into a persistent device buffer and the outputs live in persistent buffers too, so every
+        call with the same shape presents the same pointers to ssd_forward and is replayed
+        as a hipGraph from the second repetition on.  The returned tensors are overwritten
+        by the next call: consume (e.g. `.cpu()`) before calling again."""
+        torch = _torch()
+        if isinstance(images, np.ndarray):
+            images = torch.from_numpy(np.ascontiguousarray(images))
+        if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[3] != 3:
+            raise ValueError("images must be uint8 with shape [B,H,W,3]")
+        key = tuple(images.shape)
+        slot = self._static.get(key)
+        if slot is None:
+            dev = "cuda:%d" % self.device
+            B = key[0]
+            slot = (torch.empty(key, dtype=torch.uint8, device=dev),
+                    (torch.empty((B, self.T, 4), dtype=torch.float32, device=dev),
+                     torch.empty((B, self.T), dtype=torch.int32, device=dev),
+                     torch.empty((B, self.T), dtype=torch.float32, device=dev),
+                     torch.empty((B,), dtype=torch.int32, device=dev)))
+            if len(self._static) >= 4:
+                self._static.pop(next(iter(self._static)))
+            self._static[key] = slot
+        slot[0].copy_(images, non_blocking=True)
+        return self.forward(slot[0], out=slot[1])
 
     def get_tensor(self, name):
         """Retained intermediate of the last forward as a numpy array [B,H,W,C]."""

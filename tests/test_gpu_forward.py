@@ -159,6 +159,25 @@ def test_detector_drop_in(cuda, ssd, oracle_graph, tmp_path):
     assert np.abs(pred["boxes"].cpu().numpy() - ref2["boxes"]).max() <= TOL
 
 
+def test_graph_replay(cuda, ssd, monkeypatch):
+    """SSD_GRAPH=1: the serving path (persistent buffers) is captured into a hipGraph at its
+    second repetition and replayed; results stay identical to the eager forward."""
+    monkeypatch.setenv("SSD_GRAPH", "1")
+    params = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
+              "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
+    Wt = ssd.synthetic_weights(params, seed=21, logits_bias=-4.0)
+    eng = ssd.Engine(params, Wt)
+    rng = np.random.default_rng(8)
+    imgs = [rng.integers(0, 256, (2, 128, 128, 3), dtype=np.uint8) for _ in range(4)]
+    eager = [[t.cpu().numpy() for t in eng.forward(cuda.from_numpy(im).cuda())] for im in imgs]
+    for rep in range(2):
+        for im, ref in zip(imgs, eager):
+            got = [t.cpu().numpy() for t in eng.forward_cached(im)]      # 1st eager, 2nd capture, then replay
+            for a, b in zip(got, ref):
+                assert np.array_equal(a, b)
+    eng.close()
+
+
 def test_missing_weight_fails_loudly(cuda, ssd):
     params = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
               "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
