@@ -239,7 +239,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     // The accumulators (lane = column, 16 registers = 16 rows of a 32x32 tile) go through a
     // per-wave LDS transpose so that every lane ends up with 4 consecutive channels of one
     // row: 16-B global stores (256 contiguous bytes per row and instruction) and vector loads
-    // of the BN parameters, a quarter of the store instructions of the direct form.
+    // of the BN parameters, a quarter of the store instructions of the direct form.  The LDS
+    // image is plain row-major: a 32-lane ds_write_b32 covers 32 consecutive dwords of one row
+    // and a 16-lane ds_read_b128 group covers 16 distinct 16-B chunks -- conflict-free as is.
     const bool has_bn = a.mean != nullptr;
     constexpr int RW = WN * 32;                  // floats per row of the wave's sub-tile
     constexpr int C4N = RW / 4;                  // 16-B chunks per row
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
                 for (int r = 0; r < 16; ++r) {
                     const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const int col = j * 32 + (lane & 31);
-                    reg[row * RW + (((col >> 2) ^ (row & (C4N - 1))) << 2) + (col & 3)] = acc[i][j][r];
+                    reg[row * RW + col] = acc[i][j][r];
                 }
         __syncthreads();
         const int c4 = lane % C4N;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         for (int it = 0; it < WM * 32 / ROWS_PER_IT; ++it) {
             const int row = it * ROWS_PER_IT + lane / C4N;
             const int m = m0 + wave_m * WM * 32 + row;
-            const v4f raw = *(const v4f *)(reg + row * RW + ((c4 ^ (row & (C4N - 1))) << 2));
+            const v4f raw = *(const v4f *)(reg + row * RW + (c4 << 2));
             if (m < M && colok) {
                 v4f v = raw;
                 if (has_bn) {
