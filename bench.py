@@ -195,6 +195,10 @@ def main():
                          "algorithmic_gflop_per_launch": flops_per_launch / 1e9,
                          "algorithmic_gbyte_per_launch": c3["bytes"] / max(c3["launches"], 1) / 1e9},
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
+            # per kernel class: algorithmic TFLOP/s and TB/s over the union of its launches' intervals
+            # (MFMA peak 157.3 TFLOP/s; HBM 8.0 TB/s spec, 6.3 measured copy)
+            "kernel_rates": {k: {"tflops": v["flops"] / max(v["ms"], 1e-9) / 1e9, "tbytes_per_s": v["bytes"] / max(v["ms"], 1e-9) / 1e9}
+                             for k, v in prof.items() if v["launches"] > 0},
             "pcie_inclusive_img_s_per_gpu": pcie_img_s,
             "whole_net_roofline_frac": (1.113 * B) / ms_step,       # 1.113 ms/img at the per-layer roofline
         }

@@ -217,6 +217,24 @@ def test_postprocess_edge_cases(cuda, ssd, oracle_ops):
     run_post(cuda, ssd, oracle_ops, codes, logits, anc, m=5)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_postprocess_fuzz(cuda, ssd, oracle_ops, seed):
+    """Random class counts, thresholds, caps, densities, box scalers and batch sizes."""
+    rng = np.random.default_rng(1000 + seed)
+    H, W = [(128, 128), (128, 256), (256, 128)][seed % 3]
+    anc = oracle_ops.anchors(H, W)
+    N = anc.shape[0]
+    C = int(rng.choice([1, 2, 3, 4, 7, 20, 80]))
+    B = int(rng.integers(1, 4))
+    codes = (rng.standard_normal((B, N, 4)) * rng.choice([0.1, 0.5, 1.5])).astype(np.float32)
+    logits = (rng.standard_normal((B, N, C)) * rng.choice([0.5, 1.5, 3.0]) + rng.choice([-6.0, -3.0, -1.0])).astype(np.float32)
+    thr = float(rng.choice([0.05, 0.15, 0.5, 0.9]))
+    iou = float(rng.choice([0.3, 0.5, 0.6, 0.9]))
+    m = int(rng.choice([1, 5, 25, 40]))
+    scaler = None if seed % 2 else rng.uniform(0.5, 1.0, 4).astype(np.float32)
+    run_post(cuda, ssd, oracle_ops, codes, logits, anc, thr=thr, iou=iou, m=m, scaler=scaler)
+
+
 def test_postprocess_long_lists(cuda, ssd, oracle_ops, monkeypatch):
     """Candidate lists longer than the register paths: > 512 (block kernel, registers) and
     > 8192 (block kernel, keys in global memory); and the block kernel forced on short lists."""
