@@ -1041,6 +1041,15 @@ static int make_plans(ssd_handle *h, int B, int H, int W)
     // than the overlap returns, so the default is ONE plan; SSD_NSUB keeps the experiment alive.
     int nsub = 1;
     if (const char *e = getenv("SSD_NSUB")) { const int v = atoi(e); if (v >= 1 && v <= 8) nsub = v; }
+    {   // every tensor an MFMA launch reads must stay < 2 GiB (32-bit buffer offsets): the largest is
+        // the first depthwise / max-pool output [B, H/2, W/2, 32] -> split very large batches
+        const ResizeDims rd = resize_dims(H, W, h->cfg.min_dimension, 128);
+        const long long per_img = (long long)((rd.nh + rd.ph) / 2) * ((rd.nw + rd.pw) / 2) * 32 * 4;
+        const long long bmax = ((1LL << 31) - 1) / per_img;
+        if (bmax < 1) return fail(SSD_ERR_INVALID, "ssd_forward: image too large for one launch");
+        const int need = (int)((B + bmax - 1) / bmax);
+        if (need > nsub) nsub = need;
+    }
     if (nsub > B) nsub = B;
     int img0 = 0;
     for (int k = 0; k < nsub; ++k) {
