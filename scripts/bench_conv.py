@@ -9,7 +9,7 @@ from ssd_amd._lib import check
 assert torch.cuda.is_available()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 L = ssd_amd.lib()
-TILES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "128x256", 4: "256x128", 5: "64x64"}
+TILES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "128x256", 4: "256x128", 5: "64x64", 6: "128x96"}
 
 
 def run(name, H, W, Cin, Cout, k, stride, tiles, pyramid=0, reps=10):
@@ -23,7 +23,7 @@ def run(name, H, W, Cin, Cout, k, stride, tiles, pyramid=0, reps=10):
 for rnd in range(2):
     run("tower 3x3 256->256 5 levels", 80, 112, 256, 256, 3, 1, [0, 1, 5] if B <= 4 else [0], pyramid=1)
 run("fpn p3 3x3 256->256 80x112", 80, 112, 256, 256, 3, 1, [0])
-run("logits 3x3 256->480 5 levels", 80, 112, 256, 480, 3, 1, [0], pyramid=1)
+run("logits 3x3 256->480 5 levels", 80, 112, 256, 480, 3, 1, [0, 6], pyramid=1)
 run("boxes 3x3 256->24 5 levels", 80, 112, 256, 24, 3, 1, [2], pyramid=1)
 run("pw 32->64 320x448", 320, 448, 32, 64, 1, 1, [1, 0])
 run("pw 64->128 160x224", 160, 224, 64, 128, 1, 1, [0, 1, 5])

@@ -105,7 +105,16 @@ struct ConvW {
     int Cin_l = 0, Cout_l = 0;
 };
 
-static int pick_tile(int CoutP) { return CoutP <= 32 ? IGEMM_128x32 : (CoutP <= 64 ? IGEMM_128x64 : IGEMM_128x128); }
+static int pick_tile(int CoutP)
+{
+    if (CoutP <= 32) return IGEMM_128x32;
+    if (CoutP <= 64) return IGEMM_128x64;
+    // an output width that 96 divides but 128 does not (the 480 = 6 x 80 class logits): no padded columns
+    const char *e = getenv("SSD_IGEMM_96");   // tests / A-B runs: 0 keeps the padded 128-wide tiles
+    const int use96 = e ? atoi(e) : 1;
+    if (use96 && CoutP % 128 != 0 && CoutP % 96 == 0) return IGEMM_128x96;
+    return IGEMM_128x128;
+}
 
 // w: HWIO [k,k,Cin_l,Cout_l] -> wt [taps][CoutPad][CinP]
 static int g_force_tile = -1;   // diagnostics only (ssd_bench_conv)

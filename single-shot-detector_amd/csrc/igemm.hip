@@ -263,7 +263,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         __syncthreads();
         const int c4 = lane % C4N;
         const int col = tile_n * BN + wave_n * RW + c4 * 4;
-        const bool colok = col < a.Cout;         // Cout is a multiple of 4 (host check)
+        constexpr int ROWS_PER_IT = 64 / C4N;    // rows per wave-instruction (C4N = 24: 2 rows, lanes 48-63 idle)
+        const bool colok = col < a.Cout && lane < ROWS_PER_IT * C4N;   // Cout is a multiple of 4 (host check)
         v4f mean = {0.f, 0.f, 0.f, 0.f}, sf = {1.f, 1.f, 1.f, 1.f}, beta = {0.f, 0.f, 0.f, 0.f}, bias = {0.f, 0.f, 0.f, 0.f};
         if (colok && has_bn) {
             mean = *(const v4f *)(a.mean + L.param_off + col);
@@ -271,10 +272,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
             beta = *(const v4f *)(a.beta + L.param_off + col);
         }
         if (colok && a.bias) bias = *(const v4f *)(a.bias + L.param_off + col);
-        constexpr int ROWS_PER_IT = 64 / C4N;
 #pragma unroll
         for (int it = 0; it < WM * 32 / ROWS_PER_IT; ++it) {
-            const int row = it * ROWS_PER_IT + lane / C4N;
+            const int row = it * ROWS_PER_IT + (lane / C4N) % ROWS_PER_IT;
             const int m = m0 + wave_m * WM * 32 + row;
             const v4f raw = *(const v4f *)(reg + row * RW + (c4 << 2));
             if (m < M && colok) {
@@ -328,6 +328,7 @@ int igemm_tile_bn(int tile)
     case IGEMM_128x256: return 256;
     case IGEMM_128x128: case IGEMM_256x128: return 128;
     case IGEMM_128x64: case IGEMM_64x64: return 64;
+    case IGEMM_128x96: return 96;
     case IGEMM_128x32: return 32;
     default: return 128;   // diagnostic variants of 128x128
     }
@@ -373,6 +374,7 @@ hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStre
     case IGEMM_128x64: return launch_t<4, 1, 1, 2>(a, total_tiles_m, s);
     case IGEMM_128x32: return launch_t<4, 1, 1, 1>(a, total_tiles_m, s);
     case IGEMM_64x64: return launch_t<2, 2, 1, 1>(a, total_tiles_m, s);
+    case IGEMM_128x96: return launch_t<4, 1, 1, 3>(a, total_tiles_m, s);
     case 10: return launch_t<2, 2, 2, 2, 1>(a, total_tiles_m, s);
     case 11: return launch_t<2, 2, 2, 2, 2>(a, total_tiles_m, s);
     case 12: return launch_t<2, 2, 2, 2, 3>(a, total_tiles_m, s);

@@ -50,7 +50,7 @@ struct IgemmArgs {
 };
 
 // tile variants of the implicit-GEMM kernel: BM x BN
-enum IgemmTile { IGEMM_128x128 = 0, IGEMM_128x64 = 1, IGEMM_128x32 = 2, IGEMM_128x256 = 3, IGEMM_256x128 = 4, IGEMM_64x64 = 5 };
+enum IgemmTile { IGEMM_128x128 = 0, IGEMM_128x64 = 1, IGEMM_128x32 = 2, IGEMM_128x256 = 3, IGEMM_256x128 = 4, IGEMM_64x64 = 5, IGEMM_128x96 = 6 };
 int igemm_tile_bm(int tile);
 int igemm_tile_bn(int tile);
 hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s);

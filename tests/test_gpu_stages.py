@@ -87,6 +87,21 @@ def test_conv2d(cuda, ssd, oracle_ops, case, tile, monkeypatch):
     assert exact == 1.0, "conv2d result is within tolerance but not bit-identical to the oracle"
 
 
+@pytest.mark.parametrize("cout", [96, 192, 480])
+@pytest.mark.parametrize("use96", ["0", "1"])
+def test_conv2d_96_wide_tiles(cuda, ssd, oracle_ops, cout, use96, monkeypatch):
+    # output widths that 96 divides and 128 does not (class logits 480, ShuffleNet 96/192) run on
+    # 128x96 tiles; SSD_IGEMM_96=0 keeps the zero-padded 128-wide tiles.  Same bits either way.
+    monkeypatch.setenv("SSD_IGEMM_96", use96)
+    rng = np.random.default_rng(cout)
+    x = rng.standard_normal((2, 19, 23, 64)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 64, cout)) * np.sqrt(2.0 / (9 * 64))).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    ref = oracle_ops.bias_add(oracle_ops.conv2d(x, w, 1, "SAME"), bias)
+    got = ssd.ssd.conv2d(dev(cuda, x), w, 1, "SAME", bias=bias).cpu().numpy()
+    assert close(got, ref, "conv2d Cout=%d use96=%s" % (cout, use96)) == 1.0
+
+
 def test_conv2d_empty_and_errors(cuda, ssd):
     x = cuda.zeros((1, 4, 4, 8), dtype=cuda.float32, device="cuda")
     with pytest.raises(ValueError):
