@@ -127,7 +127,8 @@ int ssd_anchors(int32_t H, int32_t W, float *anchors_host /* [N,4] */);
  * 0 for TF 'SAME' stride 2 on even sizes and for k = 1.
  * bn_*: moving_mean, gamma*rsqrt(var+eps), beta (batch_norm_relu, layer_utils.py:5-12).
  * up_dev: coarser map [B,OH/2,OW/2,Cout] added after nearest x2 upsampling
- * (feature_extractor.py:67,79-100).  Cin must be a multiple of 8. */
+ * (feature_extractor.py:67,79-100).  Cin must be a multiple of 8.  Batch norm, bias and
+ * up_dev are mutually exclusive (the reference's graph has no layer combining them). */
 int ssd_conv2d(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t Cin,
                const float *w_host /* [k,k,Cin,Cout] */, int32_t k, int32_t Cout,
                int32_t stride, int32_t pad_beg, int32_t OH, int32_t OW,

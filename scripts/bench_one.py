@@ -1,5 +1,5 @@
 """One conv shape, few launches: the target of rocprofv3 --pmc passes.
-usage: python scripts/bench_one.py tile [reps] [shape]   shape: tower | pw512 | logits"""
+usage: python scripts/bench_one.py tile [reps] [shape]   shape: tower | pw512 | logits | pw2 | pw3 | pw5"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,6 +15,12 @@ if shape == "tower":
     check(L.ssd_bench_conv(32, 80, 112, 256, 256, 3, 1, tile, reps, 1, ctypes.byref(ms), ctypes.byref(gf)))
 elif shape == "logits":
     check(L.ssd_bench_conv(32, 80, 112, 256, 480, 3, 1, tile, reps, 1, ctypes.byref(ms), ctypes.byref(gf)))
+elif shape == "pw2":
+    check(L.ssd_bench_conv(32, 160, 224, 64, 128, 1, 1, tile, reps, 0, ctypes.byref(ms), ctypes.byref(gf)))
+elif shape == "pw3":
+    check(L.ssd_bench_conv(32, 160, 224, 128, 128, 1, 1, tile, reps, 0, ctypes.byref(ms), ctypes.byref(gf)))
+elif shape == "pw5":
+    check(L.ssd_bench_conv(32, 80, 112, 256, 256, 1, 1, tile, reps, 0, ctypes.byref(ms), ctypes.byref(gf)))
 else:
     check(L.ssd_bench_conv(32, 40, 56, 512, 512, 1, 1, tile, reps, 0, ctypes.byref(ms), ctypes.byref(gf)))
 print("%s tile %d: %.3f ms %.1f TFLOP/s" % (shape, tile, ms.value, gf.value / ms.value))

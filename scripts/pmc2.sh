@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts/pmc2.sh <out> <tile> : SQ + TCC counters for bench_one.py tower with a tile/DBG variant
+# usage: scripts/pmc2.sh <out> <tile> [shape] : SQ + TCC counters for bench_one.py tower with a tile/DBG variant
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
@@ -7,7 +7,7 @@ for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BU
            "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_64B_sum TCC_TAG_STALL_sum" \
            "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum TCP_TA_TCP_STATE_READ_sum TCP_TCR_TCP_STALL_CYCLES_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/scripts/bench_one.py $2 3 tower > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/scripts/bench_one.py $2 3 ${3:-tower} > $OUT/p$i.log 2>&1
 done
 cd $R
 python3 - "$OUT" <<'PY'

@@ -1,0 +1,53 @@
+"""Per-block phase timestamps of the 128x128 implicit-GEMM kernel (diagnostic tile id 17).
+usage: python scripts/ts_phases.py H W Cin Cout k [B] [pyramid]
+Phases (100 MHz wall clock, thread 0 of each block): start -> first stage in LDS -> K loop done ->
+accumulators transposed in LDS -> last store issued."""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import ssd_amd
+from ssd_amd._lib import check
+H, W, Cin, Cout, k = [int(v) for v in sys.argv[1:6]]
+B = int(sys.argv[6]) if len(sys.argv) > 6 else 32
+pyr = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+path = "/tmp/ts_dump.bin"
+os.environ["SSD_TS_DUMP"] = path
+L = ssd_amd.lib()
+ms, gf = ctypes.c_double(), ctypes.c_double()
+check(L.ssd_bench_conv(B, H, W, Cin, Cout, k, 1, 17, 3, pyr, ctypes.byref(ms), ctypes.byref(gf)))
+t = np.fromfile(path, dtype=np.int64).reshape(-1, 9)
+st = t[:, :5].astype(np.float64) * 0.01          # us
+span = st[:, 4].max() - st[:, 0].min()
+print("%dx%d %d->%d k%d B=%d: %.3f ms/launch (events), %d blocks, span of last launch %.1f us" %
+      (H, W, Cin, Cout, k, B, ms.value, len(t), span))
+names = ["prologue (offsets, 2 gloads, first stage in LDS)", "K loop", "acc -> LDS transpose", "BN/act + stores issued"]
+ep = t[:, 5:8].astype(np.float64) * 0.01
+print("   inside the last phase: parameters arrived +%.2f us, first row stored +%.2f us, half the rows +%.2f us (means, from the transpose mark)" %
+      tuple((ep[:, i] - st[:, 3]).mean() for i in range(3)))
+d = np.diff(st, axis=1)
+for i, n in enumerate(names):
+    print("   %-52s mean %7.2f us  p10 %7.2f  p50 %7.2f  p90 %7.2f" % (n, d[:, i].mean(), *np.percentile(d[:, i], [10, 50, 90])))
+life = st[:, 4] - st[:, 0]
+print("   %-52s mean %7.2f us  p10 %7.2f  p50 %7.2f  p90 %7.2f" % ("block lifetime", life.mean(), *np.percentile(life, [10, 50, 90])))
+print("   sum of lifetimes / span = %.1f blocks resident on average (512 slots)" % (life.sum() / span))
+hw = t[:, 8] & 0xFFFFFFFF
+xcc = t[:, 8] >> 32
+cu = ((hw >> 8) & 0xF) | (((hw >> 13) & 0x7) << 4) | ((xcc & 0xF) << 8)    # CU_ID, SE_ID(+SH), XCC
+ids, cnt = np.unique(cu, return_counts=True)
+print("   %d distinct (xcc, se, cu) ids; blocks per id min %d max %d" % (len(ids), cnt.min(), cnt.max()))
+# gaps between consecutive blocks on the same slot are invisible here; idle estimate per CU:
+busy = []
+for i in ids[:: max(1, len(ids) // 32)]:
+    s = st[cu == i]
+    ev = sorted([(a, 1) for a in s[:, 0]] + [(b, -1) for b in s[:, 4]])
+    depth, last, acc = 0, ev[0][0], {0: 0.0, 1: 0.0, 2: 0.0, 3: 0.0}
+    for tt, dd in ev:
+        acc[min(depth, 3)] += tt - last
+        last = tt
+        depth += dd
+    tot = sum(acc.values())
+    busy.append([acc[j] / tot for j in range(4)])
+b = np.array(busy).mean(0)
+print("   sampled CUs: time with 0 / 1 / 2 / 3+ resident blocks = %.2f / %.2f / %.2f / %.2f" % tuple(b))

@@ -118,6 +118,7 @@ static int pick_tile(int CoutP)
 
 // w: HWIO [k,k,Cin_l,Cout_l] -> wt [taps][CoutPad][CinP]
 static int g_force_tile = -1;   // diagnostics only (ssd_bench_conv)
+static long long *g_dbg_ts = nullptr;   // diagnostics only (ssd_bench_conv tile 17)
 
 static int pack_conv(DevPool &pool, const float *w, int k, int Cin_l, int Cout_l, const std::vector<int> &inmap,
                      const std::vector<int> &outmap, ConvW &cw)
@@ -177,6 +178,7 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
     a.B = B; a.Cin = cw.CinP; a.Cout = cw.CoutP; a.CoutPad = cw.CoutPad; a.taps = cw.taps;
     a.stride = stride; a.pad = pad; a.act = act;
     a.nlevels = (int)lv.size();
+    a.ts = g_dbg_ts;
     // Small problems (batch 1, coarse pyramid levels): 128x128 tiles would leave most of the
     // 256 CUs with one wave per SIMD or idle; 64x64 tiles give 4x the blocks.
     int tile = cw.tile;
@@ -1334,6 +1336,9 @@ extern "C" int ssd_conv2d(const float *in_dev, int32_t B, int32_t H, int32_t W, 
     if ((OH - 1) * stride + k - pad_beg > H + k - 1 || (OW - 1) * stride + k - pad_beg > W + k - 1)
         return fail(SSD_ERR_INVALID, "ssd_conv2d: output size inconsistent with input size");
     if (up_dev && ((OH & 1) || (OW & 1))) return fail(SSD_ERR_INVALID, "ssd_conv2d: upsample-add needs even output size");
+    // the forms the reference's graph contains: conv, conv + BN (+ act), conv + bias, conv + upsampled map
+    if ((bn_mean && (bias_host || up_dev)) || (bias_host && up_dev))
+        return fail(SSD_ERR_INVALID, "ssd_conv2d: batch norm, bias and upsample-add are mutually exclusive");
     hipStream_t s = (hipStream_t)stream;
     DevPool pool;
     int rc = SSD_OK;
@@ -1562,7 +1567,16 @@ extern "C" int ssd_bench_conv(int32_t B, int32_t H, int32_t W, int32_t Cin, int3
             for (auto &v : hin) v = rnd();
             HIPCHK(hipMemcpy(in, hin.data(), hin.size() * 4, hipMemcpyHostToDevice));
         }
+        long long *ts = nullptr;
+        long long nblk = 0;
+        if (tile == 17) {   // per-block phase timestamps of the last launch -> $SSD_TS_DUMP (int64[nblk][9])
+            for (size_t l = 0; l < lv.size(); ++l) nblk += ((long long)B * lv[l].OH * lv[l].OW + 127) / 128;
+            nblk *= cw.CoutPad / 128;
+            SSDCHK(pool.alloc((void **)&ts, (size_t)nblk * 9 * 8));
+            g_dbg_ts = ts;
+        }
         Op op = make_conv_op(cw, in, out, nullptr, nullptr, B, stride, pad, SSD_ACT_RELU, lv, true);
+        g_dbg_ts = nullptr;
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0));
         HIPCHK(hipEventCreate(&e1));
@@ -1575,6 +1589,13 @@ extern "C" int ssd_bench_conv(int32_t B, int32_t H, int32_t W, int32_t Cin, int3
         HIPCHK(hipEventElapsedTime(&ms, e0, e1));
         *avg_ms = ms / reps;
         if (gflop) *gflop = fl / 1e9;
+        if (ts) {
+            if (const char *path = getenv("SSD_TS_DUMP")) {
+                std::vector<long long> hts((size_t)nblk * 9);
+                HIPCHK(hipMemcpy(hts.data(), ts, hts.size() * 8, hipMemcpyDeviceToHost));
+                if (FILE *f = fopen(path, "wb")) { fwrite(hts.data(), 8, hts.size(), f); fclose(f); }
+            }
+        }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         return SSD_OK;

@@ -18,15 +18,24 @@
 //               increasing logical (ky,kx,ci) order: bit-identical to the fmaf chain
 //               of the oracle.  Epilogue ops are separately rounded (-ffp-contract=off).
 #include "ssd_internal.h"
+#include <type_traits>
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 // DBG (timing experiments only, results are wrong): 1 = no global loads / LDS writes in the
 // K loop, 2 = additionally no LDS fragment reads, 3 = additionally no barrier.
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int DBG = 0>
+// DBG 7 (results are right): thread 0 of every block records 100 MHz timestamps of its phases.
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int DBGT = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const IgemmArgs a)
 {
+    constexpr int DBG = DBGT == 7 ? 0 : DBGT;
+    long long stamp[8];
+    auto mark = [&](int i) {
+        if constexpr (DBGT == 7) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[i] = wall_clock64(); }
+    };
+    if constexpr (DBGT == 7) stamp[0] = wall_clock64();
     constexpr int NT = 64 * WAVES_M * WAVES_N;   // threads per block (256 or 512)
     constexpr int RPP = NT / 8;                  // tile rows covered by one pass of the block
     constexpr int BM = WAVES_M * WM * 32;
@@ -196,6 +205,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     gload();
     gadvance();
     __syncthreads();
+    mark(1);
     rdfrag(0, 0, fa0, fb0);
     if (KS > 1) {
       int ks = 0;
@@ -242,6 +252,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     // of the BN parameters, a quarter of the store instructions of the direct form.  The LDS
     // image is plain row-major: a 32-lane ds_write_b32 covers 32 consecutive dwords of one row
     // and a 16-lane ds_read_b128 group covers 16 distinct 16-B chunks -- conflict-free as is.
+    mark(2);
     const bool has_bn = a.mean != nullptr;
     constexpr int RW = WN * 32;                  // floats per row of the wave's sub-tile
     constexpr int C4N = RW / 4;                  // 16-B chunks per row
@@ -261,9 +272,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
                     reg[row * RW + col] = acc[i][j][r];
                 }
         __syncthreads();
+        mark(3);
         const int c4 = lane % C4N;
         const int col = tile_n * BN + wave_n * RW + c4 * 4;
         constexpr int ROWS_PER_IT = 64 / C4N;    // rows per wave-instruction (C4N = 24: 2 rows, lanes 48-63 idle)
+        constexpr int ITS = WM * 32 / ROWS_PER_IT;
         const bool colok = col < a.Cout && lane < ROWS_PER_IT * C4N;   // Cout is a multiple of 4 (host check)
         v4f mean = {0.f, 0.f, 0.f, 0.f}, sf = {1.f, 1.f, 1.f, 1.f}, beta = {0.f, 0.f, 0.f, 0.f}, bias = {0.f, 0.f, 0.f, 0.f};
         if (colok && has_bn) {
@@ -272,51 +285,117 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
             beta = *(const v4f *)(a.beta + L.param_off + col);
         }
         if (colok && a.bias) bias = *(const v4f *)(a.bias + L.param_off + col);
+        // Row geometry without per-row divisions: row m = (image b, position p); the rows of one
+        // lane advance by ROWS_PER_IT, i.e. by (qR images, rR positions) with one possible wrap.
+        const int row0 = (lane / C4N) % ROWS_PER_IT;
+        const int mfirst = m0 + wave_m * WM * 32 + row0;
+        const int b0 = mfirst / P, p0 = mfirst - b0 * P;
+        const int qR = ROWS_PER_IT / P, rR = ROWS_PER_IT - qR * P;
+        const int bstride = (int)L.out_bstride, rstride = L.out_rstride;
+        const int step = (qR * bstride + rR * rstride) * 4, wrapstep = (bstride - P * rstride) * 4;   // bytes
+        // upsample-add operand (FPN laterals): all rows' loads first, then ONE wait (see below)
+        v4f rv[ITS];
+        if (a.res) {
 #pragma unroll
-        for (int it = 0; it < WM * 32 / ROWS_PER_IT; ++it) {
-            const int row = it * ROWS_PER_IT + (lane / C4N) % ROWS_PER_IT;
-            const int m = m0 + wave_m * WM * 32 + row;
-            const v4f raw = *(const v4f *)(reg + row * RW + (c4 << 2));
-            if (m < M && colok) {
-                v4f v = raw;
-                if (has_bn) {
+            for (int it = 0; it < ITS; ++it) {
+                const int m = mfirst + it * ROWS_PER_IT;
+                rv[it] = v4f{0.f, 0.f, 0.f, 0.f};
+                if (m < M && colok) {
+                    const int b = m / P, p = m - b * P;
+                    const int oy = p / OW, ox = p - oy * OW;
+                    const int ch = L.OH >> 1, cw = OW >> 1;
+                    rv[it] = *(const v4f *)(a.res + L.res_off + (((long long)b * ch + (oy >> 1)) * cw + (ox >> 1)) * a.Cout + col);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < ITS; ++it) asm volatile("" : "+v"(rv[it]));
+        }
+        // The parameters must have ARRIVED before the store loop: gfx9 counts loads and stores in
+        // one in-order counter (vmcnt), and a parameter still pending on any path makes the
+        // compiler wait for vmcnt(0) in every iteration -- i.e. for the previous iteration's stores
+        // to retire.  Using the values here puts the one wait in front of the loop.
+        asm volatile("" : "+v"(mean), "+v"(sf), "+v"(beta), "+v"(bias));
+        if constexpr (DBGT == 7) stamp[5] = wall_clock64();
+        // Stores go through buffer resources like the loads: rows beyond M and columns beyond Cout
+        // get an out-of-range offset and are dropped by the range check, so the loop is branch-free
+        // straight-line code the scheduler can interleave across rows (the wave shares its SIMD with
+        // a block that is issuing MFMAs; dependent address arithmetic per row cost 1.3 us a row).
+        constexpr unsigned OOBS = 0x80000000u;
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + L.out_off), 0, (int)OOBS, 0x00020000);
+        const __amdgpu_buffer_rsrc_t o2rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.out2 ? a.out2 : a.out) + L.out_off), 0, (int)OOBS, 0x00020000);
+        const unsigned off0 = (unsigned)(b0 * bstride + p0 * rstride + col) * 4u;
+        // One straight-line loop per epilogue form (uniform switch below): all LDS reads first,
+        // then arithmetic and stores of independent rows for the scheduler to interleave.
+        auto store_rows = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;   // 0 plain, 1 +upsampled, 2 BN, 3 BN + relu(raw) copy, 4 bias
+            v4f raw[ITS];
+#pragma unroll
+            for (int it = 0; it < ITS; ++it) raw[it] = *(const v4f *)(reg + (it * ROWS_PER_IT + row0) * RW + (c4 << 2));
+            unsigned off = off0;
+            int p = p0;
+#pragma unroll
+            for (int it = 0; it < ITS; ++it) {
+                const int m = mfirst + it * ROWS_PER_IT;
+                if constexpr (DBGT == 7) { if (it == 1) stamp[6] = wall_clock64(); if (it == ITS / 2) stamp[7] = wall_clock64(); }
+                v4f v = raw[it];
+                if constexpr (MODE == 2 || MODE == 3) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float t = (v[e] - mean[e]) * sf[e];
                         v[e] = t + beta[e];
                     }
                 }
-                if (a.bias) {
+                if constexpr (MODE == 4) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] + bias[e];
                 }
-                long long off;
-                if (a.dense_out && !a.res) {
-                    off = L.out_off + (long long)m * L.out_rstride + col;
-                } else {
-                    const int b = m / P, p = m - b * P;
-                    off = L.out_off + b * L.out_bstride + (long long)p * L.out_rstride + col;
-                    if (a.res) {
-                        const int oy = p / OW, ox = p - oy * OW;
-                        const int ch = L.OH >> 1, cw = OW >> 1;
-                        const v4f rv = *(const v4f *)(a.res + L.res_off + (((long long)b * ch + (oy >> 1)) * cw + (ox >> 1)) * a.Cout + col);
+                if constexpr (MODE == 1) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = rv[e] + v[e];
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] = rv[it][e] + v[e];
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (a.act >= 1) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
                     if (a.act == 2) v[e] = v[e] < 6.0f ? v[e] : 6.0f;
                 }
-                *(v4f *)(a.out + off) = v;
-                if (a.out2) {
+                const unsigned o = (m < M && colok) ? off : OOBS;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), orsrc, (int)o, 0, 0);
+                if constexpr (MODE == 3) {
                     v4f q;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) q[e] = raw[e] > 0.0f ? raw[e] : 0.0f;
-                    *(v4f *)(a.out2 + off) = q;
+                    for (int e = 0; e < 4; ++e) q[e] = raw[it][e] > 0.0f ? raw[it][e] : 0.0f;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, q), o2rsrc, (int)o, 0, 0);
                 }
+                p += rR;
+                const bool wrap = p >= P;
+                p -= wrap ? P : 0;
+                off += (unsigned)(step + (wrap ? wrapstep : 0));
             }
+        };
+        // (host checks: bias and batch norm are exclusive, the upsampled operand comes without
+        // either, the second output only with batch norm)
+        if (has_bn) {
+            if (a.out2) store_rows(std::integral_constant<int, 3>{});
+            else store_rows(std::integral_constant<int, 2>{});
+        } else if (a.bias) {
+            store_rows(std::integral_constant<int, 4>{});
+        } else if (a.res) {
+            store_rows(std::integral_constant<int, 1>{});
+        } else {
+            store_rows(std::integral_constant<int, 0>{});
+        }
+    }
+    if constexpr (DBGT == 7) {
+        // stamp 4 is taken with the stores still in flight (a wave does not wait for them to retire)
+        stamp[4] = wall_clock64();
+        if (tid == 0 && a.ts) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            long long *t = a.ts + (long long)blockIdx.x * 9;
+            for (int i = 0; i < 8; ++i) t[i] = stamp[i];
+            t[8] = ((long long)xcc << 32) | hw;
         }
     }
 }
@@ -368,6 +447,13 @@ hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStre
     if ((long long)a.taps * a.CoutPad * a.Cin * 4 >= (1LL << 31)) return hipErrorInvalidValue;
     for (int i = 0; i < a.nlevels; ++i)
         if ((long long)a.B * a.lv[i].H * a.lv[i].W * a.Cin * 4 >= (1LL << 31)) return hipErrorInvalidValue;
+    // epilogue forms the kernel implements
+    if ((a.mean != nullptr) != (a.sf != nullptr) || (a.mean != nullptr) != (a.beta != nullptr)) return hipErrorInvalidValue;
+    if (a.mean && (a.bias || a.res)) return hipErrorInvalidValue;
+    if (a.bias && a.res) return hipErrorInvalidValue;
+    if (a.out2 && !a.mean) return hipErrorInvalidValue;
+    for (int i = 0; i < a.nlevels; ++i)     // 32-bit byte offsets in the epilogue's buffer stores, relative to the level's base
+        if ((long long)a.B * a.lv[i].out_bstride * 4 >= (1LL << 31) || a.lv[i].out_bstride < 0) return hipErrorInvalidValue;
     if (a.n_tiles_n * igemm_tile_bn(tile >= 10 ? 0 : tile) != a.CoutPad || a.nlevels < 1 || a.nlevels > SSD_MAX_LEVELS) return hipErrorInvalidValue;
     switch (tile) {
     case IGEMM_128x128: return launch_t<2, 2, 2, 2>(a, total_tiles_m, s);
@@ -378,6 +464,7 @@ hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStre
     case 10: return launch_t<2, 2, 2, 2, 1>(a, total_tiles_m, s);
     case 11: return launch_t<2, 2, 2, 2, 2>(a, total_tiles_m, s);
     case 12: return launch_t<2, 2, 2, 2, 3>(a, total_tiles_m, s);
+    case 17: return launch_t<2, 2, 2, 2, 7>(a, total_tiles_m, s);
     }
     return hipErrorInvalidValue;
 }

@@ -46,6 +46,7 @@ struct IgemmArgs {
     int nlevels;
     int n_tiles_n;
     int dense_out;         // 1: out_bstride == OH*OW*out_rstride for every level
+    long long *ts;         // diagnostics (ssd_bench_conv tile 17): per-block phase timestamps, else null
     IgemmLevel lv[SSD_MAX_LEVELS];
 };
 

@@ -38,13 +38,9 @@ def unpack_detections(rec):
     return boxes, labels, scores, num
 
 
-def all_gather_detections(boxes, labels, scores, num, group=None):
-    """Every rank contributes the records of its B_local images (equal on all ranks) and
-    receives all world_size*B_local records in rank order."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return boxes, labels, scores, num
+def gather_records(rec, group=None):
+    """ONE all-gather of the [B_local, 6T+1] int32 records -> [world*B_local, 6T+1], rank order."""
     world = dist.get_world_size(group)
-    rec = pack_detections(boxes, labels, scores, num)
     out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
     try:
         dist.all_gather_into_tensor(out, rec, group=group)
@@ -52,7 +48,15 @@ def all_gather_detections(boxes, labels, scores, num, group=None):
         parts = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(parts, rec, group=group)
         out = torch.cat(parts, 0)
-    return unpack_detections(out)
+    return out
+
+
+def all_gather_detections(boxes, labels, scores, num, group=None):
+    """Every rank contributes the records of its B_local images (equal on all ranks) and
+    receives all world_size*B_local records in rank order."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return boxes, labels, scores, num
+    return unpack_detections(gather_records(pack_detections(boxes, labels, scores, num), group))
 
 
 def detect_sharded(engine, images_local, group=None):

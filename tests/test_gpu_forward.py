@@ -211,3 +211,43 @@ def test_batch_independence_full_batch(cuda, ssd):
         assert np.array_equal(a[17:18], b)
     assert full[3].min() > 0
     eng.close()
+
+
+_RCCL_CHILD = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+import ssd_amd
+from importlib import import_module
+d = import_module("ssd_amd.distributed")
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+params = ssd_amd.load_config(os.path.join(sys.argv[1], "tests", "golden", "config_mobilenet.json"))
+W = ssd_amd.synthetic_weights(params, seed=3, logits_bias=-5.0)
+eng = ssd_amd.Engine(params, W, device=0)
+g = torch.Generator().manual_seed(5)
+frames = torch.randint(0, 256, (2, 128, 256, 3), dtype=torch.uint8, generator=g).cuda()
+out = eng.forward(frames)
+rec = d.pack_detections(*out)
+got = d.gather_records(rec)            # RCCL all-gather on the records (world 1: must be the identity)
+torch.cuda.synchronize()
+assert torch.equal(got, rec)
+back = d.unpack_detections(got)
+assert all(torch.equal(a, b) for a, b in zip(back, out))
+full = ssd_amd.detect_sharded(eng, frames)
+assert all(torch.equal(a, b) for a, b in zip(full, out))
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK", int(out[3].sum()))
+"""
+
+
+def test_rccl_all_gather_of_engine_records(cuda, ssd, tmp_path):
+    # the N > 1 bench path minus the second GPU: backend 'nccl' (RCCL) process group in a child
+    # process, all-gather of the packed detection records the engine just produced
+    import subprocess
+    script = tmp_path / "rccl_child.py"
+    script.write_text(_RCCL_CHILD)
+    port = str(29600 + os.getpid() % 2000)
+    r = subprocess.run([sys.executable, str(script), os.path.dirname(HERE), port], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
