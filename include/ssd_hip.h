@@ -142,6 +142,17 @@ int ssd_depthwise3x3(const float *in_dev, int32_t B, int32_t H, int32_t W, int32
                      int32_t OW, const float *bn_mean_host, const float *bn_sf_host,
                      const float *bn_beta_host, int32_t act, float *out_dev, void *stream);
 
+/* depthwise_conv + BN + act followed by the 1x1 conv + BN + act that consumes it, as ONE kernel
+ * (the MobileNet block, mobilenet_v1.py:59-67; shufflenet_v2.py:118-137 depthwise -> conv1x1_after):
+ * the depthwise result stays in LDS.  'SAME' padding; stride 2 needs even H, W.  Limits of the
+ * fused kernel (SSD_ERR_INVALID otherwise): C <= 256, OW and OH*OW multiples of 4. */
+int ssd_dw_pw(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t C,
+              const float *dw_w_host /* [3,3,C,1] */, int32_t stride, const float *dw_mean_host,
+              const float *dw_sf_host, const float *dw_beta_host, int32_t dw_act,
+              const float *pw_w_host /* [1,1,C,Cout] */, int32_t Cout, const float *pw_mean_host,
+              const float *pw_sf_host, const float *pw_beta_host, int32_t pw_act,
+              float *out_dev, void *stream);
+
 /* uint8 image -> /255 -> 2x-1 -> 3x3 stride-2 'SAME' conv -> BN -> act, fused
  * (create_pb.py:42-47; mobilenet_v1.py:34,49; shufflenet_v2.py:37,50). */
 int ssd_first_conv(const uint8_t *images_dev, int32_t B, int32_t H, int32_t W,

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SOURCES = ["api.hip", "igemm.hip", "elementwise.hip", "postprocess.hip"]
+_SOURCES = ["api.hip", "igemm.hip", "dwpw.hip", "elementwise.hip", "postprocess.hip"]
 _LIB_PATH = os.path.join(_CSRC, "libssd_hip.so")
 _lib = None
 
@@ -75,6 +75,7 @@ SIGNATURES = {
                                   _vp, _i, _vp, _vp]),
     "ssd_depthwise3x3": (ctypes.c_int, [_vp, _i, _i, _i, _i, _f, _i, _i, _i, _i, _f, _f, _f, _i,
                                         _vp, _vp]),
+    "ssd_dw_pw": (ctypes.c_int, [_vp, _i, _i, _i, _i, _f, _i, _f, _f, _f, _i, _f, _i, _f, _f, _f, _i, _vp, _vp]),
     "ssd_first_conv": (ctypes.c_int, [_vp, _i, _i, _i, _f, _i, _f, _f, _f, _i, _vp, _vp]),
     "ssd_maxpool3x3s2": (ctypes.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "ssd_concat_shuffle_split": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _i, _vp, _vp, _vp]),

@@ -117,6 +117,7 @@ static int pick_tile(int CoutP)
 }
 
 // w: HWIO [k,k,Cin_l,Cout_l] -> wt [taps][CoutPad][CinP]
+#define SSD_FUSE_DW_DEFAULT 0x0u     // set from measurements (profiles/)
 static int g_force_tile = -1;   // diagnostics only (ssd_bench_conv)
 static long long *g_dbg_ts = nullptr;   // diagnostics only (ssd_bench_conv tile 17)
 
@@ -712,6 +713,39 @@ static Op make_dw_op(const DwW &d, const float *in, int B, int H, int W, int str
     return op;
 }
 
+// depthwise + pointwise in one launch (dwpw.hip) when the shapes allow it
+static bool dwpw_eligible(const DwW &d, const ConvW &cw, int B, int H, int W, int stride)
+{
+    const int OH = H / stride, OW = W / stride;
+    if (cw.taps != 1 || d.Cp != cw.CinP || d.Cp > 256 || !cw.mean || cw.bias) return false;
+    if (OW % 4 != 0 || (OH * OW) % 4 != 0) return false;
+    if ((long long)B * H * W * d.Cp * 4 >= (1LL << 31) || (long long)B * OH * OW * cw.CoutP * 4 >= (1LL << 31)) return false;
+    const int shape = cw.CoutP <= 64 ? DWPW_128x64 : DWPW_64x128;
+    return cw.CoutPad % dwpw_tile_bn(shape) == 0;
+}
+
+static Op make_dwpw_op(const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact,
+                       int act, float *out)
+{
+    DwPwArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.wdw = d.w; a.dmean = d.mean; a.dsf = d.sf; a.dbeta = d.beta;
+    a.wt = cw.wt; a.mean = cw.mean; a.sf = cw.sf; a.beta = cw.beta; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.K = d.Cp; a.OH = H / stride; a.OW = W / stride;
+    a.Cout = cw.CoutP; a.CoutPad = cw.CoutPad;
+    a.pad = stride == 1 ? 1 : 0;
+    a.dact = dact; a.act = act;
+    const int shape = cw.CoutP <= 64 ? DWPW_128x64 : DWPW_64x128;
+    a.n_tiles_n = cw.CoutPad / dwpw_tile_bn(shape);
+    a.M = B * a.OH * a.OW;
+    Op op;
+    op.cls = 1;
+    op.flops = (2.0 * 9 * cw.Cin_l + 2.0 * cw.Cin_l * cw.Cout_l) * (double)a.M;
+    op.bytes = ((double)B * H * W * cw.Cin_l + (double)a.M * cw.Cout_l) * 4.0 + (double)cw.Cin_l * cw.Cout_l * 4.0;
+    op.run = [a, shape, stride](hipStream_t s) { return launch_dwpw(shape, stride, a, s); };
+    return op;
+}
+
 static LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long in_off = 0, long long out_off = 0,
                              int param_off = 0, long long res_off = 0)
 {
@@ -770,12 +804,17 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         }
         float *cur = X;
         int ch = h2, cwid = w2;
+        // depthwise -> pointwise pairs that run as one launch (bit i = Conv2d_{i+1}); SSD_FUSE_DW overrides
+        unsigned fuse_mask = SSD_FUSE_DW_DEFAULT;
+        if (const char *e = getenv("SSD_FUSE_DW")) fuse_mask = (unsigned)strtoul(e, nullptr, 0);
         for (int i = 0; i < 13; ++i) {
             const int s = MB_STRIDE[i];
             float *dwo = (cur == X) ? Y : X;
-            pl.ops.push_back(make_dw_op(h->dw[i], cur, B, ch, cwid, s, SSD_ACT_RELU6, dwo, h->pw[i].Cin_l));
-            ch /= s; cwid /= s;
             const ConvW &cw = h->pw[i];
+            const bool fuse = ((fuse_mask >> i) & 1) && dwpw_eligible(h->dw[i], cw, B, ch, cwid, s);
+            if (!fuse) pl.ops.push_back(make_dw_op(h->dw[i], cur, B, ch, cwid, s, SSD_ACT_RELU6, dwo, h->pw[i].Cin_l));
+            const int dh = ch, dwid = cwid;
+            ch /= s; cwid /= s;
             float *pwo;
             if (i == 4 || i == 10 || i == 12) {
                 SSDCHK(falloc(&pwo, (long long)B * ch * cwid * cw.CoutP));
@@ -783,10 +822,13 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 const char *nm = i == 4 ? "c3" : (i == 10 ? "c4" : "c5");
                 pl.retained[nm] = Retained{pwo, B, ch, cwid, cw.Cout_l, cw.CoutP, true};
             } else {
-                pwo = (dwo == X) ? Y : X;
+                pwo = fuse ? dwo : ((dwo == X) ? Y : X);    // fused: input `cur` is live until the launch ends
             }
-            pl.ops.push_back(make_conv_op(cw, dwo, pwo, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU6,
-                                          {dense_level(ch, cwid, ch, cwid, cw.CoutP)}, true));
+            if (fuse)
+                pl.ops.push_back(make_dwpw_op(h->dw[i], cw, cur, B, dh, dwid, s, SSD_ACT_RELU6, SSD_ACT_RELU6, pwo));
+            else
+                pl.ops.push_back(make_conv_op(cw, dwo, pwo, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU6,
+                                              {dense_level(ch, cwid, ch, cwid, cw.CoutP)}, true));
             cur = pwo;
         }
     } else {
@@ -1411,6 +1453,53 @@ extern "C" int ssd_depthwise3x3(const float *in_dev, int32_t B, int32_t H, int32
         HIPCHK(launch_permute_channels(in_dev, rin, C, Cp, 1, tin, s));
         HIPCHK(launch_depthwise(tin, B, H, W, Cp, dw_, stride, pad_beg, OH, OW, dm, ds, db, act, tout, s));
         HIPCHK(launch_permute_channels(tout, rout, C, Cp, 0, out_dev, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return SSD_OK;
+    };
+    int rc = body();
+    (void)hipStreamSynchronize(s);
+    pool.free_all();
+    return rc;
+}
+
+extern "C" int ssd_dw_pw(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t C, const float *dw_w_host,
+                         int32_t stride, const float *dw_mean, const float *dw_sf, const float *dw_beta, int32_t dw_act,
+                         const float *pw_w_host, int32_t Cout, const float *pw_mean, const float *pw_sf,
+                         const float *pw_beta, int32_t pw_act, float *out_dev, void *stream)
+{
+    if (!in_dev || !dw_w_host || !dw_mean || !dw_sf || !dw_beta || !pw_w_host || !pw_mean || !pw_sf || !pw_beta || !out_dev ||
+        B < 1 || H < 1 || W < 1 || C < 1 || Cout < 1 || (stride != 1 && stride != 2) || dw_act < 0 || dw_act > 2 || pw_act < 0 || pw_act > 2)
+        return fail(SSD_ERR_INVALID, "ssd_dw_pw: bad arguments");
+    if (stride == 2 && ((H & 1) || (W & 1))) return fail(SSD_ERR_INVALID, "ssd_dw_pw: stride 2 needs even H, W");
+    hipStream_t s = (hipStream_t)stream;
+    DevPool pool;
+    auto body = [&]() -> int {
+        const int Cp = round_up(C, 32), CoutP = round_up(Cout, 8);
+        std::vector<int> map = phys_map(C, Cp), outmap = phys_map(Cout, CoutP);
+        DwW d;
+        d.Cp = Cp;
+        std::vector<float> wt((size_t)9 * Cp, 0.f), m, sf, be;
+        for (int t = 0; t < 9; ++t)
+            for (int p = 0; p < Cp; ++p)
+                if (map[p] >= 0) wt[(size_t)t * Cp + p] = dw_w_host[(size_t)t * C + map[p]];
+        for (int p : map) { m.push_back(p < 0 ? 0.f : dw_mean[p]); sf.push_back(p < 0 ? 0.f : dw_sf[p]); be.push_back(p < 0 ? 0.f : dw_beta[p]); }
+        SSDCHK(pool.upload(&d.w, wt)); SSDCHK(pool.upload(&d.mean, m)); SSDCHK(pool.upload(&d.sf, sf)); SSDCHK(pool.upload(&d.beta, be));
+        ConvW cw;
+        SSDCHK(pack_conv(pool, pw_w_host, 1, C, Cout, map, outmap, cw));
+        BnHost b;
+        for (int p : outmap) { b.mean.push_back(p < 0 ? 0.f : pw_mean[p]); b.sf.push_back(p < 0 ? 0.f : pw_sf[p]); b.beta.push_back(p < 0 ? 0.f : pw_beta[p]); }
+        SSDCHK(upload_bn(pool, b, cw));
+        if (!dwpw_eligible(d, cw, B, H, W, stride))
+            return fail(SSD_ERR_INVALID, "ssd_dw_pw: shape not supported by the fused kernel (C <= 256 after padding, OW and OH*OW multiples of 4)");
+        const int OH = H / stride, OW = W / stride;
+        float *tin, *tout;
+        const long long rin = (long long)B * H * W, rout = (long long)B * OH * OW;
+        SSDCHK(pool.alloc((void **)&tin, (size_t)rin * Cp * 4));
+        SSDCHK(pool.alloc((void **)&tout, (size_t)rout * CoutP * 4));
+        HIPCHK(launch_permute_channels(in_dev, rin, C, Cp, 1, tin, s));
+        Op op = make_dwpw_op(d, cw, tin, B, H, W, stride, dw_act, pw_act, tout);
+        HIPCHK(op.run(s));
+        HIPCHK(launch_permute_channels(tout, rout, Cout, CoutP, 0, out_dev, s));
         HIPCHK(hipStreamSynchronize(s));
         return SSD_OK;
     };

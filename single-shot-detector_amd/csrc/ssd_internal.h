@@ -56,6 +56,24 @@ int igemm_tile_bm(int tile);
 int igemm_tile_bn(int tile);
 hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s);
 
+// depthwise 3x3 (+BN+act) -> pointwise 1x1 (+BN+act) fused (dwpw.hip) ------------------------
+struct DwPwArgs {
+    const float *in;                       // [B,H,W,K] depthwise input, physical channel order
+    const float *wdw;                      // [9][K] depthwise weights
+    const float *dmean, *dsf, *dbeta;      // [K] depthwise batch norm
+    const float *wt;                       // [CoutPad][K] pointwise weights (igemm B layout, taps = 1)
+    const float *mean, *sf, *beta;         // [CoutPad] pointwise batch norm
+    float *out;                            // [B,OH,OW,Cout]
+    int B, H, W, K, OH, OW, Cout, CoutPad;
+    int pad;                               // depthwise pad_beg (1 for stride 1, 0 for stride 2 on even sizes)
+    int dact, act;                         // activation after the depthwise / the pointwise batch norm
+    int n_tiles_n, M;                      // CoutPad / tile width, B*OH*OW
+};
+enum DwPwShape { DWPW_128x64 = 0, DWPW_64x128 = 1 };   // rows x output channels per block
+int dwpw_tile_bm(int shape);
+int dwpw_tile_bn(int shape);
+hipError_t launch_dwpw(int shape, int stride, const DwPwArgs &a, hipStream_t s);
+
 // elementwise / memory-bound kernels -----------------------------------------------------
 // source image [B,srcH,srcW,3] is NN-resized to [nh,nw], zero padded to [H,W] (even), normalised and convolved
 hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int nh, int nw, int H, int W,

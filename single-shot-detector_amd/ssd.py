@@ -94,6 +94,29 @@ def depthwise3x3(x, w, stride=1, bn=None, act=None):
     return out
 
 
+def dw_pw(x, dw_w, stride, dw_bn, dw_act, pw_w, pw_bn, pw_act):
+    """depthwise 3x3 + BN + act -> 1x1 conv + BN + act in one kernel (mobilenet_v1.py:59-67).
+    bn arguments are (mean, scale_factor, beta) as for conv2d; both are required."""
+    torch = _torch()
+    _check_dev(torch, x, torch.float32, "x")
+    dw_w = np.ascontiguousarray(dw_w, dtype=np.float32)
+    pw_w = np.ascontiguousarray(pw_w, dtype=np.float32)
+    B, H, W, C = x.shape
+    if dw_w.shape != (3, 3, C, 1) or pw_w.shape[:3] != (1, 1, C):
+        raise ValueError("weights must be [3,3,C,1] and [1,1,C,Cout]")
+    Cout = pw_w.shape[3]
+    OH, _ = out_size(H, 3, stride, "SAME")
+    OW, _ = out_size(W, 3, stride, "SAME")
+    out = torch.empty((B, OH, OW, Cout), dtype=torch.float32, device=x.device)
+    kd = [_fp(v) for v in dw_bn]
+    kp = [_fp(v) for v in pw_bn]
+    fp = ctypes.POINTER(ctypes.c_float)
+    check(lib().ssd_dw_pw(_ptr(x), B, H, W, C, dw_w.ctypes.data_as(fp), stride, kd[0][1], kd[1][1], kd[2][1],
+                          ACT[dw_act], pw_w.ctypes.data_as(fp), Cout, kp[0][1], kp[1][1], kp[2][1], ACT[pw_act],
+                          _ptr(out), _stream(torch)))
+    return out
+
+
 def first_conv(images, w, bn=None, act=None):
     torch = _torch()
     _check_dev(torch, images, torch.uint8, "images")

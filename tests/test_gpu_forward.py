@@ -159,6 +159,23 @@ def test_detector_drop_in(cuda, ssd, oracle_graph, tmp_path):
     assert np.abs(pred["boxes"].cpu().numpy() - ref2["boxes"]).max() <= TOL
 
 
+def test_fused_depthwise_pointwise_plan(cuda, ssd, monkeypatch):
+    # SSD_FUSE_DW picks the MobileNet blocks that run as one dw+pw launch: any choice gives the same bits
+    params = ssd.load_config(os.path.join(HERE, "golden", "config_mobilenet.json"))
+    Wt = ssd.synthetic_weights(params, seed=11, logits_bias=-4.0)
+    rng = np.random.default_rng(11)
+    img = cuda.from_numpy(rng.integers(0, 256, (2, 256, 384, 3), dtype=np.uint8)).cuda()
+    outs = []
+    for mask in ("0", "0x1fff", "0x15"):
+        monkeypatch.setenv("SSD_FUSE_DW", mask)
+        eng = ssd.Engine(params, Wt)
+        o = [t.cpu().numpy() for t in eng.forward(img)]
+        outs.append(o + [eng.get_tensor("c3"), eng.get_tensor("c4"), eng.get_tensor("c5")])
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
+
+
 def test_graph_replay(cuda, ssd, monkeypatch):
     """SSD_GRAPH=1: the serving path (persistent buffers) is captured into a hipGraph at its
     second repetition and replayed; results stay identical to the eager forward."""

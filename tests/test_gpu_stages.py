@@ -112,6 +112,45 @@ def test_conv2d_empty_and_errors(cuda, ssd):
         ssd.ssd.conv2d(x.cpu(), np.zeros((3, 3, 8, 8), np.float32))   # no CPU path
 
 
+DWPW_CASES = [
+    # B, H, W, C, Cout, stride, dw_act, pw_act
+    (2, 16, 24, 32, 64, 1, "relu6", "relu6"),       # Conv2d_1: 128x64 block shape
+    (1, 24, 16, 64, 128, 2, "relu6", "relu6"),      # Conv2d_2: stride 2, 64x128 blocks
+    (2, 12, 20, 128, 128, 1, "relu6", "relu6"),     # Conv2d_3
+    (1, 16, 16, 128, 256, 2, "relu6", "relu6"),     # Conv2d_4: two column tiles
+    (1, 8, 12, 256, 256, 1, "relu6", "relu6"),      # Conv2d_5: 8 K-steps resident
+    (3, 4, 4, 24, 58, 1, None, "relu"),             # ShuffleNet unit: odd channels, no act after dw, M tail
+    (1, 8, 8, 116, 116, 2, None, "relu"),           # ShuffleNet down-sampling branch
+]
+
+
+@pytest.mark.parametrize("case", DWPW_CASES, ids=[str(i) for i in range(len(DWPW_CASES))])
+def test_dw_pw_fused(cuda, ssd, oracle_ops, case):
+    B, H, W, C, Cout, stride, dact, pact = case
+    rng = np.random.default_rng(500 + DWPW_CASES.index(case))
+    x = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    wd = rng.standard_normal((3, 3, C, 1)).astype(np.float32)
+    wp = (rng.standard_normal((1, 1, C, Cout)) * np.sqrt(2.0 / C)).astype(np.float32)
+    g1, b1, m1, v1 = bn_params(rng, C)
+    g2, b2, m2, v2 = bn_params(rng, Cout)
+    mid = oracle_ops.bn_act(oracle_ops.depthwise3x3(x, wd, stride), g1, b1, m1, v1, dact)
+    ref = oracle_ops.bn_act(oracle_ops.conv2d(mid, wp, 1, "SAME"), g2, b2, m2, v2, pact)
+    got = ssd.ssd.dw_pw(dev(cuda, x), wd, stride, (m1, oracle_ops.bn_scale(g1, v1), b1), dact,
+                        wp, (m2, oracle_ops.bn_scale(g2, v2), b2), pact).cpu().numpy()
+    assert close(got, ref, "dw_pw %s" % (case,)) == 1.0
+    # and identical to the two separate kernels
+    sep = ssd.ssd.conv2d(ssd.ssd.depthwise3x3(dev(cuda, x), wd, stride, bn=(m1, oracle_ops.bn_scale(g1, v1), b1), act=dact),
+                         wp, 1, "SAME", bn=(m2, oracle_ops.bn_scale(g2, v2), b2), act=pact).cpu().numpy()
+    assert np.array_equal(got, sep)
+
+
+def test_dw_pw_unsupported_shapes_fail_loudly(cuda, ssd):
+    x = cuda.zeros((1, 6, 6, 32), dtype=cuda.float32, device="cuda")       # OW = 6 is not a multiple of 4
+    bn32 = (np.zeros(32, np.float32), np.ones(32, np.float32), np.zeros(32, np.float32))
+    with pytest.raises(ssd.SsdError):
+        ssd.ssd.dw_pw(x, np.zeros((3, 3, 32, 1), np.float32), 1, bn32, None, np.zeros((1, 1, 32, 32), np.float32), bn32, None)
+
+
 @pytest.mark.parametrize("B,H,W,C,stride,act", [(2, 20, 28, 32, 1, "relu6"), (1, 40, 56, 64, 2, "relu6"),
                                                 (2, 16, 16, 24, 2, None), (1, 10, 10, 58, 1, None),
                                                 (1, 6, 8, 1024, 1, "relu6")])
