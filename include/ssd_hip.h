@@ -106,7 +106,7 @@ int ssd_get_tensor_dev(ssd_handle *h, const char *name, float *dst_dev, int64_t 
 
 /* Per-kernel-class timing with HIP events on the forward's stream (bench.py roofline).
  * classes: 0 conv3x3 MFMA, 1 pointwise MFMA, 2 depthwise, 3 first conv, 4 postprocess,
- * 5 other.  total_ms of a class is the union of its kernels' intervals (the two head towers
+ * 5 other, 6 fused depthwise+pointwise.  total_ms of a class is the union of its kernels' intervals (the two head towers
  * overlap on two streams).  ssd_profile_read synchronises the recorded events. */
 int ssd_profile_enable(ssd_handle *h, int32_t on);
 int ssd_profile_read(ssd_handle *h, int32_t cls, double *total_ms, int64_t *launches,
@@ -184,11 +184,17 @@ int ssd_postprocess(const float *logits_dev, const float *codes_dev, const float
 
 /* Diagnostics (scripts/bench_conv.py): average milliseconds of `reps` launches of one dense
  * convolution with BN + ReLU on random data, with an explicit implicit-GEMM tile variant
- * (0: 128x128, 1: 128x64, 2: 128x32, 3: 128x256, 4: 256x128; -1: the library's choice).
+ * (0: 128x128, 1: 128x64, 2: 128x32, 5: 64x64, 6: 128x96; -1: the library's choice).
  * pyramid != 0 runs the five-level head-tower launch shape (H,W halved per level). */
 int ssd_bench_conv(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t k,
                    int32_t stride, int32_t tile, int32_t reps, int32_t pyramid, double *avg_ms,
                    double *gflop);
+
+/* Diagnostics (scripts/bench_dwpw.py): average milliseconds of `reps` launches of one depthwise +
+ * pointwise block (BN + ReLU6 after each) on random data: fused != 0 as the single ssd_dw_pw
+ * kernel, else as the depthwise kernel followed by the implicit-GEMM kernel. */
+int ssd_bench_dwpw(int32_t B, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t stride,
+                   int32_t fused, int32_t reps, double *avg_ms);
 
 #ifdef __cplusplus
 }

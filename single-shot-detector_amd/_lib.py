@@ -81,6 +81,7 @@ SIGNATURES = {
     "ssd_concat_shuffle_split": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _i, _vp, _vp, _vp]),
     "ssd_bench_conv": (ctypes.c_int, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "ssd_bench_dwpw": (ctypes.c_int, [_i, _i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_double)]),
     "ssd_postprocess_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i, _i]),
     "ssd_postprocess": (ctypes.c_int, [_vp, _vp, _vp, _i, _i, _i, ctypes.c_float, ctypes.c_float,
                                        _i, _f, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),

@@ -117,7 +117,11 @@ static int pick_tile(int CoutP)
 }
 
 // w: HWIO [k,k,Cin_l,Cout_l] -> wt [taps][CoutPad][CinP]
-#define SSD_FUSE_DW_DEFAULT 0x0u     // set from measurements (profiles/)
+#define SSD_NCLS 7                   // profile classes (include/ssd_hip.h)
+// Conv2d_1..4 as one depthwise+pointwise launch: 751.9 -> 760.6 img/s at B=32 (masks 0x3 / 0x5 / 0x7 / 0xf:
+// 754.6 / 757.2 / 760.2 / 760.6); from Conv2d_5 on (K >= 256) the two-kernel pair is faster.
+#define SSD_FUSE_DW_DEFAULT 0xfu
+#define SSD_FUSE_SHUFFLE_DEFAULT true    // ShuffleNet B=64 640x640: depthwise + pointwise 4.19 -> 3.76 ms per step
 static int g_force_tile = -1;   // diagnostics only (ssd_bench_conv)
 static long long *g_dbg_ts = nullptr;   // diagnostics only (ssd_bench_conv tile 17)
 
@@ -275,8 +279,8 @@ struct ssd_handle {
     bool profiling = false;
     std::vector<EvPair> evs;
     std::vector<hipEvent_t> ref_evs;     // one reference event per profiled forward
-    double acc_ms[6] = {0}, acc_flops[6] = {0}, acc_bytes[6] = {0};
-    long long acc_n[6] = {0};
+    double acc_ms[SSD_NCLS] = {0}, acc_flops[SSD_NCLS] = {0}, acc_bytes[SSD_NCLS] = {0};
+    long long acc_n[SSD_NCLS] = {0};
 };
 
 static void free_plans(ssd_handle *h)
@@ -724,6 +728,10 @@ static bool dwpw_eligible(const DwW &d, const ConvW &cw, int B, int H, int W, in
     return cw.CoutPad % dwpw_tile_bn(shape) == 0;
 }
 
+// depthwise -> pointwise pair: one fused launch when `fuse` and the shapes allow, else two kernels through `mid`
+static void push_dw_pw(std::vector<Op> &ops, bool fuse, const DwW &d, const ConvW &cw, const float *in, float *mid,
+                       float *out, int B, int H, int W, int stride, int dact, int act, int Cl);
+
 static Op make_dwpw_op(const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact,
                        int act, float *out)
 {
@@ -738,8 +746,9 @@ static Op make_dwpw_op(const DwW &d, const ConvW &cw, const float *in, int B, in
     const int shape = cw.CoutP <= 64 ? DWPW_128x64 : DWPW_64x128;
     a.n_tiles_n = cw.CoutPad / dwpw_tile_bn(shape);
     a.M = B * a.OH * a.OW;
+    a.ts = g_dbg_ts;
     Op op;
-    op.cls = 1;
+    op.cls = 6;
     op.flops = (2.0 * 9 * cw.Cin_l + 2.0 * cw.Cin_l * cw.Cout_l) * (double)a.M;
     op.bytes = ((double)B * H * W * cw.Cin_l + (double)a.M * cw.Cout_l) * 4.0 + (double)cw.Cin_l * cw.Cout_l * 4.0;
     op.run = [a, shape, stride](hipStream_t s) { return launch_dwpw(shape, stride, a, s); };
@@ -757,6 +766,18 @@ static LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long 
     d.param_off = param_off;
     d.res_off = res_off;
     return d;
+}
+
+static void push_dw_pw(std::vector<Op> &ops, bool fuse, const DwW &d, const ConvW &cw, const float *in, float *mid,
+                       float *out, int B, int H, int W, int stride, int dact, int act, int Cl)
+{
+    const int OH = H / stride, OW = W / stride;
+    if (fuse && in != out && dwpw_eligible(d, cw, B, H, W, stride)) {
+        ops.push_back(make_dwpw_op(d, cw, in, B, H, W, stride, dact, act, out));
+        return;
+    }
+    ops.push_back(make_dw_op(d, in, B, H, W, stride, dact, mid, Cl));
+    ops.push_back(make_conv_op(cw, mid, out, nullptr, nullptr, B, 1, 0, act, {dense_level(OH, OW, OH, OW, cw.CoutP)}, true));
 }
 
 static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int img0)
@@ -835,6 +856,9 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         // ---------------- ShuffleNet v2 (shufflenet_v2.py:50-69,79-137)
         const int units[3] = {4, 8, 4};
         const int fc = h->firstCp;
+        // depthwise -> 1x1 pairs of the units as one launch each (SSD_FUSE_DW=0 keeps them apart)
+        bool sn_fuse = SSD_FUSE_SHUFFLE_DEFAULT;
+        if (const char *e = getenv("SSD_FUSE_DW")) sn_fuse = strtoul(e, nullptr, 0) != 0;
         float *F, *MP;
         SSDCHK(falloc(&F, (long long)B * h2 * w2 * fc));
         const int h4 = h2 / 2, w4 = w2 / 2;
@@ -876,12 +900,8 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             SSDCHK(falloc(&U, rows * Dp)); SSDCHK(falloc(&V, rows * Dp));
             pl.ops.push_back(make_conv_op(before, cur, t1, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
                                           {dense_level(ch, cwid, ch, cwid, before.CoutP)}, true));
-            pl.ops.push_back(make_dw_op(d1, t1, B, ch, cwid, 2, SSD_ACT_NONE, t2, before.Cout_l));
-            pl.ops.push_back(make_conv_op(after, t2, Ya, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
-                                          {dense_level(oh, ow, oh, ow, Dp)}, true));
-            pl.ops.push_back(make_dw_op(d2, cur, B, ch, cwid, 2, SSD_ACT_NONE, t3, before.Cin_l));
-            pl.ops.push_back(make_conv_op(after2, t3, Xa, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
-                                          {dense_level(oh, ow, oh, ow, Dp)}, true));
+            push_dw_pw(pl.ops, sn_fuse, d1, after, t1, t2, Ya, B, ch, cwid, 2, SSD_ACT_NONE, SSD_ACT_RELU, before.Cout_l);
+            push_dw_pw(pl.ops, sn_fuse, d2, after2, cur, t3, Xa, B, ch, cwid, 2, SSD_ACT_NONE, SSD_ACT_RELU, before.Cin_l);
             float *x = Xa, *y = Ya, *xs = Xb, *ys = Yb;
             const int *tabx = h->tabs[st * 3], *taby = h->tabs[st * 3 + 1], *tabc = h->tabs[st * 3 + 2];
             for (int j = 2; j <= units[st]; ++j) {
@@ -901,10 +921,8 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 ipw += 2; idw += 1;
                 pl.ops.push_back(make_conv_op(b2, xs, U, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
                                               {dense_level(oh, ow, oh, ow, Dp)}, true));
-                pl.ops.push_back(make_dw_op(dd, U, B, oh, ow, 1, SSD_ACT_NONE, V, D));
                 // new x overwrites the old x buffer (dead after the shuffle); y' = ys
-                pl.ops.push_back(make_conv_op(a2, V, x, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
-                                              {dense_level(oh, ow, oh, ow, Dp)}, true));
+                push_dw_pw(pl.ops, sn_fuse, dd, a2, U, V, x, B, oh, ow, 1, SSD_ACT_NONE, SSD_ACT_RELU, D);
                 // now (x, ys) is the live pair; old y and xs are free
                 float *oldy = y;
                 y = ys; ys = oldy;
@@ -1301,10 +1319,10 @@ extern "C" int ssd_profile_enable(ssd_handle *h, int32_t on)
 // durations would count the shared GPU twice).
 static int drain_events(ssd_handle *h)
 {
-    std::vector<std::vector<std::pair<float, float>>> iv(6);
+    std::vector<std::vector<std::pair<float, float>>> iv(SSD_NCLS);
     int cur_fwd = -1;
     auto flush = [&]() {
-        for (int c = 0; c < 6; ++c) {
+        for (int c = 0; c < SSD_NCLS; ++c) {
             auto &v = iv[c];
             std::sort(v.begin(), v.end());
             float lo = 0, hi = -1;
@@ -1340,7 +1358,7 @@ static int drain_events(ssd_handle *h)
 
 extern "C" int ssd_profile_read(ssd_handle *h, int32_t cls, double *total_ms, int64_t *launches, double *flops, double *bytes)
 {
-    if (!h || cls < 0 || cls > 5) return fail(SSD_ERR_INVALID, "ssd_profile_read: bad arguments");
+    if (!h || cls < 0 || cls >= SSD_NCLS) return fail(SSD_ERR_INVALID, "ssd_profile_read: bad arguments");
     SSDCHK(drain_events(h));
     if (total_ms) *total_ms = h->acc_ms[cls];
     if (launches) *launches = h->acc_n[cls];
@@ -1353,7 +1371,7 @@ extern "C" int ssd_profile_reset(ssd_handle *h)
 {
     if (!h) return fail(SSD_ERR_INVALID, "null handle");
     SSDCHK(drain_events(h));
-    for (int i = 0; i < 6; ++i) { h->acc_ms[i] = h->acc_flops[i] = h->acc_bytes[i] = 0; h->acc_n[i] = 0; }
+    for (int i = 0; i < SSD_NCLS; ++i) { h->acc_ms[i] = h->acc_flops[i] = h->acc_bytes[i] = 0; h->acc_n[i] = 0; }
     return SSD_OK;
 }
 
@@ -1687,6 +1705,87 @@ extern "C" int ssd_bench_conv(int32_t B, int32_t H, int32_t W, int32_t Cin, int3
         }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
+        return SSD_OK;
+    };
+    int rc = body();
+    (void)hipDeviceSynchronize();
+    pool.free_all();
+    return rc;
+}
+
+extern "C" int ssd_bench_dwpw(int32_t B, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t stride, int32_t fused,
+                              int32_t reps, double *avg_ms)
+{
+    if (B < 1 || H < 1 || W < 1 || C < 1 || Cout < 1 || (stride != 1 && stride != 2) || reps < 1 || !avg_ms)
+        return fail(SSD_ERR_INVALID, "ssd_bench_dwpw: bad arguments");
+    DevPool pool;
+    auto body = [&]() -> int {
+        const int Cp = round_up(C, 32), CoutP = round_up(Cout, 8);
+        unsigned st = 777u;
+        auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 65536.0f - 0.5f; };
+        std::vector<int> map = phys_map(C, Cp), outmap = phys_map(Cout, CoutP);
+        DwW d;
+        d.Cp = Cp;
+        std::vector<float> wt((size_t)9 * Cp), m(Cp, 0.01f), sf(Cp, 1.01f), be(Cp, 0.02f);
+        for (auto &v : wt) v = rnd();
+        SSDCHK(pool.upload(&d.w, wt)); SSDCHK(pool.upload(&d.mean, m)); SSDCHK(pool.upload(&d.sf, sf)); SSDCHK(pool.upload(&d.beta, be));
+        std::vector<float> w((size_t)C * Cout);
+        for (auto &v : w) v = rnd() * 0.1f;
+        ConvW cw;
+        SSDCHK(pack_conv(pool, w.data(), 1, C, Cout, map, outmap, cw));
+        BnHost b;
+        for (int c = 0; c < CoutP; ++c) { b.mean.push_back(0.01f); b.sf.push_back(1.0f); b.beta.push_back(0.02f); }
+        SSDCHK(upload_bn(pool, b, cw));
+        const int OH = H / stride, OW = W / stride;
+        float *in, *mid, *out;
+        const long long nin = (long long)B * H * W * Cp;
+        SSDCHK(pool.alloc((void **)&in, (size_t)nin * 4));
+        SSDCHK(pool.alloc((void **)&mid, (size_t)B * OH * OW * Cp * 4));
+        SSDCHK(pool.alloc((void **)&out, (size_t)B * OH * OW * CoutP * 4));
+        {
+            std::vector<float> hin((size_t)nin);
+            for (auto &v : hin) v = rnd();
+            HIPCHK(hipMemcpy(in, hin.data(), hin.size() * 4, hipMemcpyHostToDevice));
+        }
+        std::vector<Op> ops;
+        long long *ts = nullptr;
+        long long nblk = 0;
+        if (fused) {
+            if (!dwpw_eligible(d, cw, B, H, W, stride)) return fail(SSD_ERR_INVALID, "ssd_bench_dwpw: shape not supported by the fused kernel");
+            ops.push_back(make_dwpw_op(d, cw, in, B, H, W, stride, SSD_ACT_RELU6, SSD_ACT_RELU6, out));
+        } else {
+            ops.push_back(make_dw_op(d, in, B, H, W, stride, SSD_ACT_RELU6, mid, C));
+            ops.push_back(make_conv_op(cw, mid, out, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU6, {dense_level(OH, OW, OH, OW, CoutP)}, true));
+        }
+        const char *dump = getenv("SSD_TS_DUMP");
+        if (fused && dump) {   // per-block phase timestamps of one extra launch -> $SSD_TS_DUMP (int64[nblk][5])
+            const int shape = cw.CoutP <= 64 ? DWPW_128x64 : DWPW_64x128;
+            nblk = (long long)((B * OH * OW + dwpw_tile_bm(shape) - 1) / dwpw_tile_bm(shape)) * (cw.CoutPad / dwpw_tile_bn(shape));
+            SSDCHK(pool.alloc((void **)&ts, (size_t)nblk * 5 * 8));
+        }
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        for (int i = 0; i < 2; ++i) for (auto &op : ops) HIPCHK(op.run(nullptr));
+        HIPCHK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < reps; ++i) for (auto &op : ops) HIPCHK(op.run(nullptr));
+        HIPCHK(hipEventRecord(e1, nullptr));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        *avg_ms = ms / reps;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (ts) {
+            g_dbg_ts = ts;
+            Op op = make_dwpw_op(d, cw, in, B, H, W, stride, SSD_ACT_RELU6, SSD_ACT_RELU6, out);
+            g_dbg_ts = nullptr;
+            HIPCHK(op.run(nullptr));
+            HIPCHK(hipDeviceSynchronize());
+            std::vector<long long> hts((size_t)nblk * 5);
+            HIPCHK(hipMemcpy(hts.data(), ts, hts.size() * 8, hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(dump, "wb")) { fwrite(hts.data(), 8, hts.size(), f); fclose(f); }
+        }
         return SSD_OK;
     };
     int rc = body();

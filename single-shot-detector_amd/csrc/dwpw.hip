@@ -14,12 +14,13 @@
 //   limits    K <= 256 (A operand resident in LDS: BM*K*4 bytes), OW and OH*OW multiples of 4
 //             (a thread produces 4 adjacent positions of one image row); host-checked.
 #include "ssd_internal.h"
+#include <cstdlib>
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
-template <int STRIDE, int WAVES_M, int WAVES_N, int WM, int WN>
+template <int STRIDE, int WAVES_M, int WAVES_N, int WM, int WN, bool BATCH>
 __global__ __launch_bounds__(256, 2) void dwpw_kernel(const DwPwArgs a)
 {
     static_assert(WAVES_M * WAVES_N == 4, "256 threads");
@@ -32,6 +33,9 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const DwPwArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    long long stamp[5];
+    auto mark = [&](int i) { if (a.ts) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[i] = wall_clock64(); } };
+    if (a.ts) stamp[0] = wall_clock64();
     int swz;
     {   // blocks b, b+8, ... share an XCD: consecutive tiles per XCD (igemm.hip)
         const int nblk = gridDim.x, bid = blockIdx.x;
@@ -69,44 +73,51 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const DwPwArgs a)
     // ---- depthwise 3x3 + BN + act for BM positions x K channels -> LDS A image.
     // item = (strip of 4 adjacent output positions, 4 channels); lanes run along channels.
     {
-        const int K4 = K >> 2;
-        const int nitems = (BM / 4) * K4;
-        for (int item = tid; item < nitems; item += 256) {
-            const int strip = item / K4, cc = item - strip * K4;
-            const int c = cc * 4;
+        // a thread keeps ONE channel chunk (weights and batch norm loaded once) and walks the strips
+        const int K4 = K >> 2, T = 256 / K4;
+        const int slot = tid / K4, cc = tid - slot * K4;
+        const int c = cc * 4;
+        v4f wv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[t] = *(const v4f *)(a.wdw + t * K + c);
+        const v4f dm = *(const v4f *)(a.dmean + c), ds = *(const v4f *)(a.dsf + c), db = *(const v4f *)(a.dbeta + c);
+        for (int strip = slot < T ? slot : BM; strip < BM / 4; strip += T) {
             const int m = m0 + strip * 4;
             const bool rowok = m < M;
             const int mm = rowok ? m : 0;
             const int b = mm / P, p = mm - b * P;
             const int oy = p / OW, ox0 = p - oy * OW;
-            v4f wv[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) wv[t] = *(const v4f *)(a.wdw + t * K + c);
-            v4f acc[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+            // every load of the item is issued before the first use (one memory round trip per item,
+            // not one per tap row): the scheduling barrier keeps the compiler from re-serialising them
             const int ix0 = ox0 * STRIDE - a.pad;
+            v4f x[3][NCOL];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = oy * STRIDE + ky - a.pad;
                 const bool yok = rowok && (unsigned)iy < (unsigned)H;
                 const int rowbase = (((b * H + iy) * W) * K + c) * 4;
-                v4f x[NCOL];
 #pragma unroll
                 for (int j = 0; j < NCOL; ++j) {
                     const int ix = ix0 + j;
                     const bool ok = yok && (unsigned)ix < (unsigned)W;
                     // out-of-image taps: range-checked buffer load returns 0, fmaf(0, w, acc) == acc
-                    x[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(arsrc, ok ? rowbase + ix * K * 4 : (int)OOB, 0, 0));
+                    x[ky][j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(arsrc, ok ? rowbase + ix * K * 4 : (int)OOB, 0, 0));
                 }
+            }
+            // BATCH: one memory round trip per item at the price of registers (2 waves per SIMD);
+            // otherwise the compiler interleaves loads and FMAs row by row (4 waves per SIMD).
+            if constexpr (BATCH) __builtin_amdgcn_sched_barrier(0);
+            v4f acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[q][i] = fmaf(x[q * STRIDE + kx][i], wv[ky * 3 + kx][i], acc[q][i]);
-            }
-            const v4f dm = *(const v4f *)(a.dmean + c), ds = *(const v4f *)(a.dsf + c), db = *(const v4f *)(a.dbeta + c);
+                        for (int i = 0; i < 4; ++i) acc[q][i] = fmaf(x[ky][q * STRIDE + kx][i], wv[ky * 3 + kx][i], acc[q][i]);
             const int kc = cc >> 3, ch8 = cc & 7;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -137,9 +148,11 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const DwPwArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    mark(1);
     storeB(0);
     if (KC > 1) loadB(1);
     __syncthreads();
+    mark(2);
     for (int s = 0; s < KC; ++s) {
         const int cur = s & 1;
         if (s + 1 < KC) storeB(cur ^ 1);          // rb holds K-step s+1; stage cur^1 was released by the last barrier
@@ -164,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const DwPwArgs a)
         __syncthreads();
     }
 
+    mark(3);
     // ---- epilogue (igemm.hip): per-wave LDS transpose, BN + act, 16-B buffer stores
     constexpr int RW = WN * 32, C4N = RW / 4;
     constexpr int WAVE_REGION = WM * 32 * RW * 4;
@@ -211,12 +225,16 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const DwPwArgs a)
         const unsigned o = (m < M && colok) ? (unsigned)(m * a.Cout + col) * 4u : OOB;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), orsrc, (int)o, 0, 0);
     }
+    if (a.ts) {
+        stamp[4] = wall_clock64();
+        if (tid == 0) for (int i = 0; i < 5; ++i) a.ts[(long long)blockIdx.x * 5 + i] = stamp[i];
+    }
 }
 
 int dwpw_tile_bm(int shape) { return shape == DWPW_128x64 ? 128 : 64; }
 int dwpw_tile_bn(int shape) { return shape == DWPW_128x64 ? 64 : 128; }
 
-template <int STRIDE, int WAVES_M, int WAVES_N, int WM, int WN>
+template <int STRIDE, int WAVES_M, int WAVES_N, int WM, int WN, bool BATCH>
 static hipError_t launch_shape(const DwPwArgs &a, hipStream_t s)
 {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
@@ -224,7 +242,7 @@ static hipError_t launch_shape(const DwPwArgs &a, hipStream_t s)
     const int lds_epi = 4 * WM * 32 * WN * 32 * 4;
     const int lds_bytes = lds_main > lds_epi ? lds_main : lds_epi;
     static int attr_max = 0;
-    auto k = dwpw_kernel<STRIDE, WAVES_M, WAVES_N, WM, WN>;
+    auto k = dwpw_kernel<STRIDE, WAVES_M, WAVES_N, WM, WN, BATCH>;
     if (lds_bytes > attr_max) {
         hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -248,9 +266,18 @@ hipError_t launch_dwpw(int shape, int stride, const DwPwArgs &a, hipStream_t s)
         (long long)a.CoutPad * a.K * 4 >= (1LL << 31)) return hipErrorInvalidValue;
     // every tap of every output must come from rows/columns the index arithmetic covers
     if ((a.OH - 1) * stride + 2 - a.pad > a.H + 1 || (a.OW - 1) * stride + 2 - a.pad > a.W + 1 || a.pad < 0 || a.pad > 1) return hipErrorInvalidValue;
-    if (shape == DWPW_128x64)
-        return stride == 1 ? launch_shape<1, 4, 1, 1, 2>(a, s) : launch_shape<2, 4, 1, 1, 2>(a, s);
-    if (shape == DWPW_64x128)
-        return stride == 1 ? launch_shape<1, 2, 2, 1, 2>(a, s) : launch_shape<2, 2, 2, 1, 2>(a, s);
+    static int batch_env = -2;
+    if (batch_env == -2) { const char *e = getenv("SSD_DWPW_BATCH"); batch_env = e ? atoi(e) : -1; }
+    // measured (scripts/bench_dwpw.py): with the weights hoisted the batched form no longer pays
+    // (Conv2d_1..4: 0.659/0.522/0.624/0.393 ms batched vs 0.612/0.489/0.640/0.366 ms); kept for A/B runs
+    const bool batch = batch_env > 0;
+    if (shape == DWPW_128x64) {
+        if (batch) return stride == 1 ? launch_shape<1, 4, 1, 1, 2, true>(a, s) : launch_shape<2, 4, 1, 1, 2, true>(a, s);
+        return stride == 1 ? launch_shape<1, 4, 1, 1, 2, false>(a, s) : launch_shape<2, 4, 1, 1, 2, false>(a, s);
+    }
+    if (shape == DWPW_64x128) {
+        if (batch) return stride == 1 ? launch_shape<1, 2, 2, 1, 2, true>(a, s) : launch_shape<2, 2, 2, 1, 2, true>(a, s);
+        return stride == 1 ? launch_shape<1, 2, 2, 1, 2, false>(a, s) : launch_shape<2, 2, 2, 1, 2, false>(a, s);
+    }
     return hipErrorInvalidValue;
 }

@@ -68,6 +68,7 @@ struct DwPwArgs {
     int pad;                               // depthwise pad_beg (1 for stride 1, 0 for stride 2 on even sizes)
     int dact, act;                         // activation after the depthwise / the pointwise batch norm
     int n_tiles_n, M;                      // CoutPad / tile width, B*OH*OW
+    long long *ts;                         // diagnostics: per-block phase timestamps [nblk][5], else null
 };
 enum DwPwShape { DWPW_128x64 = 0, DWPW_64x128 = 1 };   // rows x output channels per block
 int dwpw_tile_bm(int shape);

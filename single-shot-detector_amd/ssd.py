@@ -331,7 +331,8 @@ class Engine:
         check(lib().ssd_profile_reset(self._h))
 
     def profile_read(self):
-        names = ["conv3x3_mfma", "pointwise_mfma", "depthwise", "first_conv", "postprocess", "other"]
+        names = ["conv3x3_mfma", "pointwise_mfma", "depthwise", "first_conv", "postprocess", "other",
+                 "depthwise_pointwise_fused"]
         out = {}
         for i, n in enumerate(names):
             ms, cnt = ctypes.c_double(), ctypes.c_int64()

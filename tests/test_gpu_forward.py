@@ -159,9 +159,11 @@ def test_detector_drop_in(cuda, ssd, oracle_graph, tmp_path):
     assert np.abs(pred["boxes"].cpu().numpy() - ref2["boxes"]).max() <= TOL
 
 
-def test_fused_depthwise_pointwise_plan(cuda, ssd, monkeypatch):
-    # SSD_FUSE_DW picks the MobileNet blocks that run as one dw+pw launch: any choice gives the same bits
-    params = ssd.load_config(os.path.join(HERE, "golden", "config_mobilenet.json"))
+@pytest.mark.parametrize("cfg", ["config_mobilenet.json", "config_shufflenet.json"])
+def test_fused_depthwise_pointwise_plan(cuda, ssd, monkeypatch, cfg):
+    # SSD_FUSE_DW picks the blocks that run as one dw+pw launch (MobileNet: bit i = Conv2d_{i+1};
+    # ShuffleNet: non-zero = every unit): any choice gives the same bits
+    params = ssd.load_config(os.path.join(HERE, "golden", cfg))
     Wt = ssd.synthetic_weights(params, seed=11, logits_bias=-4.0)
     rng = np.random.default_rng(11)
     img = cuda.from_numpy(rng.integers(0, 256, (2, 256, 384, 3), dtype=np.uint8)).cuda()
