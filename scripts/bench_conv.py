@@ -21,7 +21,7 @@ def run(name, H, W, Cin, Cout, k, stride, tiles, pyramid=0, reps=10):
 
 
 for rnd in range(2):
-    run("tower 3x3 256->256 5 levels", 80, 112, 256, 256, 3, 1, [0, 1, 5] if B <= 4 else [0], pyramid=1)
+    run("tower 3x3 256->256 5 levels", 80, 112, 256, 256, 3, 1, [0, 1, 5], pyramid=1)
 run("fpn p3 3x3 256->256 80x112", 80, 112, 256, 256, 3, 1, [0])
 run("logits 3x3 256->480 5 levels", 80, 112, 256, 480, 3, 1, [0, 6], pyramid=1)
 run("boxes 3x3 256->24 5 levels", 80, 112, 256, 24, 3, 1, [2], pyramid=1)
