@@ -29,14 +29,28 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(_CSRC, s) for s in _SOURCES]
     deps = srcs + [os.path.join(_CSRC, "ssd_internal.h"),
                    os.path.join(_HERE, "..", "include", "ssd_hip.h")]
-    if not force and os.path.exists(_LIB_PATH) and \
-            os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+    def fresh():
+        return os.path.exists(_LIB_PATH) and \
+            os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(d) for d in deps)
+    if not force and fresh():
         return _LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", _LIB_PATH] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # one builder at a time (torch.distributed.run starts N ranks at once): lock, re-check,
+    # compile beside the target and rename over it, so no rank ever maps a half-written file
+    import fcntl
+    with open(os.path.join(_CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and fresh():
+                return _LIB_PATH
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            tmp = "%s.tmp.%d" % (_LIB_PATH, os.getpid())
+            cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp] + srcs
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(tmp, _LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB_PATH
 
 
