@@ -527,7 +527,9 @@ static int finalize_fpn_heads(ssd_handle *h)
         SSDCHK(load_conv(h, scope + "/kernel", "", 3, 256, Cout, cw, /*out_identity=*/true));
         const Tensor *bias = getvar(h, scope + "/bias", {Cout});
         if (!bias) return SSD_ERR_WEIGHT;
-        SSDCHK(h->wpool.upload(&cw.bias, bias->data));
+        std::vector<float> bpad(bias->data);
+        bpad.resize((size_t)round_up(Cout, 4), 0.0f);     // the epilogue reads parameters 4 at a time
+        SSDCHK(h->wpool.upload(&cw.bias, bpad));
     }
     return SSD_OK;
 }

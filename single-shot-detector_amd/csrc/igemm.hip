@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         const int col = tile_n * BN + wave_n * RW + c4 * 4;
         constexpr int ROWS_PER_IT = 64 / C4N;    // rows per wave-instruction (C4N = 24: 2 rows, lanes 48-63 idle)
         constexpr int ITS = WM * 32 / ROWS_PER_IT;
-        const bool colok = col < a.Cout && lane < ROWS_PER_IT * C4N;   // Cout is a multiple of 4 (host check)
+        const bool colok = col < a.Cout && lane < ROWS_PER_IT * C4N;   // parameter vectors are padded to CoutPad
         v4f mean = {0.f, 0.f, 0.f, 0.f}, sf = {1.f, 1.f, 1.f, 1.f}, beta = {0.f, 0.f, 0.f, 0.f}, bias = {0.f, 0.f, 0.f, 0.f};
         if (colok && has_bn) {
             mean = *(const v4f *)(a.mean + L.param_off + col);
@@ -324,6 +324,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + L.out_off), 0, (int)OOBS, 0x00020000);
         const __amdgpu_buffer_rsrc_t o2rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.out2 ? a.out2 : a.out) + L.out_off), 0, (int)OOBS, 0x00020000);
         const unsigned off0 = (unsigned)(b0 * bstride + p0 * rstride + col) * 4u;
+        const bool vec_rows = ((a.Cout | rstride | bstride | (int)L.out_off) & 3) == 0;
         // One straight-line loop per epilogue form (uniform switch below): all LDS reads first,
         // then arithmetic and stores of independent rows for the scheduler to interleave.
         auto store_rows = [&](auto mode_tag) {
@@ -359,7 +360,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
                     if (a.act == 2) v[e] = v[e] < 6.0f ? v[e] : 6.0f;
                 }
                 const unsigned o = (m < M && colok) ? off : OOBS;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), orsrc, (int)o, 0, 0);
+                if (vec_rows) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), orsrc, (int)o, 0, 0);
+                } else {   // output rows that are not 16-B aligned (head widths 6*C with odd C): per-element stores
+                    // (hipcc 7.2: bit-casting v[e] element by element inside the unrolled loop stored element 0
+                    //  four times; cast the vector once and index the integer vector)
+                    const v4u vu = __builtin_bit_cast(v4u, v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        __builtin_amdgcn_raw_buffer_store_b32(vu[e], orsrc, (int)((col + e < a.Cout) ? o + 4u * e : OOBS), 0, 0);
+                }
                 if constexpr (MODE == 3) {
                     v4f q;
 #pragma unroll
@@ -441,7 +451,8 @@ static hipError_t launch_t(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 {
     // host-side shape checks: the kernel assumes them
-    if (a.Cout % 4 != 0) return hipErrorInvalidValue;   // 16-B epilogue stores
+    // widths that are not a multiple of 4 take per-element stores; the vector forms need aligned rows
+    if (a.Cout % 4 != 0 && (a.mean || a.res || a.out2)) return hipErrorInvalidValue;
     if (a.Cin % 32 != 0 || a.CoutPad % igemm_tile_bn(tile >= 10 ? 0 : tile) != 0 || (a.taps != 1 && a.taps != 9)) return hipErrorInvalidValue;
     // 32-bit byte offsets inside buffer resources: every tensor of a launch stays < 2 GiB
     if ((long long)a.taps * a.CoutPad * a.Cin * 4 >= (1LL << 31)) return hipErrorInvalidValue;

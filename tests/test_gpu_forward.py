@@ -78,6 +78,26 @@ def test_forward_vs_oracle_small(cuda, ssd, oracle_graph, backbone, H, W, B):
     eng.close()
 
 
+@pytest.mark.parametrize("backbone,dm,classes,H,W", [("mobilenet", 0.5, 20, 128, 256), ("mobilenet", 0.75, 3, 256, 128),
+                                                     ("shufflenet", 0.5, 20, 128, 128), ("shufflenet", 1.5, 80, 128, 256)])
+def test_forward_other_widths_and_class_counts(cuda, ssd, oracle_graph, backbone, dm, classes, H, W):
+    """depth_multiplier and num_classes are part of the config surface (model.py:22-30): narrow
+    backbones exercise the channel padding (16 -> 32, 24 -> 32, 88 -> 96 ...), other class counts
+    the head widths (6*C = 18 / 120 / 480 columns) and every tile variant behind them."""
+    params = {"backbone": backbone, "depth_multiplier": dm, "num_classes": classes, "score_threshold": 0.15,
+              "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
+    Wt = ssd.synthetic_weights(params, seed=21, logits_bias=-4.0)
+    img = np.random.default_rng(7).integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    keep = {}
+    ref = oracle_graph.forward(img, Wt, params, keep)
+    eng = ssd.Engine(params, Wt)
+    out = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(img).cuda())]
+    assert stage_check(eng, keep, STAGES, "%s x%.2f" % (backbone, dm)) == 1.0
+    compare_outputs(out, ref, "%s x%.2f C=%d" % (backbone, dm, classes))
+    assert out[0].shape == (2, classes * 25, 4)
+    eng.close()
+
+
 def test_sub_batch_plans(cuda, ssd, oracle_graph, monkeypatch):
     """SSD_NSUB splits a batch into staggered sub-batch plans (uneven split 5 = 2+2+1): same
     results, same retained tensors."""
