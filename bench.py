@@ -26,6 +26,9 @@ import ssd_amd  # noqa: E402
 
 H, W = 640, 896                       # inference/just_try_detector.ipynb:111 resize((896, 640))
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# precision f16x3: every fp32 product costs three v_mfma_f32_32x32x16_f16 terms (xh*wh + xh*wl + xl*wh), so the
+# algorithmic-FLOP peak of that kernel is the dense F16 MFMA peak (2.5 PFLOP/s = 16 x 157.3) divided by 3
+PEAK_F16X3_TFLOPS = 16 * 157.3 / 3.0
 PARAMS = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80,
           "score_threshold": 0.15, "iou_threshold": 0.6, "max_boxes_per_class": 25,
           "min_dimension": 640}       # config_mobilenet.json:7-12,21
@@ -97,6 +100,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step (BASELINE config 5: 256/8)")
+    ap.add_argument("--precision", choices=["f32", "f16x3"], default=os.environ.get("SSD_BENCH_MODE", "f32"),
+                    help="arithmetic of the FPN / head convolutions (include/ssd_hip.h SSD_PRECISION_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
@@ -120,7 +125,8 @@ def main():
 
     B = args.batch
     Wt = ssd_amd.synthetic_weights(PARAMS, seed=0, logits_bias=LOGITS_BIAS)
-    engine = ssd_amd.Engine(PARAMS, Wt, device=local)
+    engine = ssd_amd.Engine(PARAMS, Wt, device=local, precision=args.precision)
+    peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16X3_TFLOPS
     # this rank's shard of the global batch, resident in HBM before the timed region
     lo, hi = ssd_amd.shard_range(B * world, rank, world)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -180,7 +186,9 @@ def main():
             "metric": "images/sec at 896x640, MobileNet-v1 RetinaNet (whole hot path incl. decode + per-class NMS)",
             "value": B * world * args.steps / dt, "unit": "img/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else "f32 carried as split f16 pairs (3 x f16 MFMA, f32 accumulate)",
+            "precision": args.precision,
             "data": "synthetic",
             "config": {"workload": "MobileNet-v1 + FPN + RetinaNet heads + decode + per-class NMS, 640x896 (HxW) "
                                    "uint8 frames, %d per GPU (BASELINE config 5 shard; config 2 = same graph at batch 1, "
@@ -188,8 +196,8 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W,
                        "parallelism": "dp%d" % world, "weights": "random-init (seed 0), logits bias %.1f" % LOGITS_BIAS,
                        "detections_per_image": det_per_image},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
                          "kernel": "igemm_kernel (3x3 convs: FPN outputs + head towers + class/box heads)",
                          "launches_per_step": c3["launches"] / args.steps, "avg_launch_ms": avg_ms,
                          "algorithmic_gflop_per_launch": flops_per_launch / 1e9,

@@ -48,6 +48,18 @@ extern "C" {
 #define SSD_BACKBONE_MOBILENET 0   /* detector/backbones/mobilenet_v1.py  */
 #define SSD_BACKBONE_SHUFFLENET 1  /* detector/backbones/shufflenet_v2.py */
 
+/* Arithmetic of the dense FPN / head convolutions (ssd_set_precision).  The reference graph is
+ * fp32 end to end (tf.float32 everywhere, model.py:13-77).
+ *   F32    every product on the exact-fp32 matrix instruction, one k-ordered fmaf chain per
+ *          output: bit-identical to the CPU oracle.
+ *   F16X3  each fp32 operand is carried as two halves x = h + l (22 significand bits) and a
+ *          product is evaluated as xh*wh + xh*wl + xl*wh on the fp16 matrix instruction with
+ *          fp32 accumulation: the error of one convolution equals that of an fp32 accumulation
+ *          chain (measured), but the summation ORDER differs from the oracle's, so
+ *          results agree within the north-star tolerance (1e-4), not bit for bit. */
+#define SSD_PRECISION_F32 0
+#define SSD_PRECISION_F16X3 1
+
 typedef struct ssd_handle ssd_handle;
 
 /* The inference keys of config_mobilenet.json / config_shufflenet.json (:7-12,21),
@@ -67,6 +79,16 @@ typedef struct ssd_config {
 int ssd_create(const ssd_config *cfg, ssd_handle **out);
 void ssd_destroy(ssd_handle *h);
 const char *ssd_last_error(void);
+
+/* Selects the arithmetic of the dense FPN / head convolutions for the following ssd_forward
+ * calls (synchronises and drops the cached layer plan when the mode changes).  A new handle
+ * takes its mode from the environment variable SSD_PRECISION ("f32" | "f16x3"), default f32. */
+int ssd_set_precision(ssd_handle *h, int32_t mode /* SSD_PRECISION_* */);
+int ssd_get_precision(ssd_handle *h);
+/* Synchronises the device and returns (and clears) the handle's status word.  Bit 0: in
+ * F16X3 mode an activation left the fp16 range (|x| > 65504) and was clamped -- the results
+ * of the forwards since the last call are not trustworthy; re-run them in F32 mode. */
+int ssd_status(ssd_handle *h, int32_t *flags_out);
 
 /* One call per TF variable of the frozen graph, by the reference's variable name
  * (e.g. "MobilenetV1/Conv2d_3_pointwise/weights", "fpn/p6/kernel",
@@ -135,6 +157,16 @@ int ssd_conv2d(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t Cin
                const float *bn_mean_host, const float *bn_sf_host, const float *bn_beta_host,
                const float *bias_host, const float *up_dev, int32_t act, float *out_dev,
                void *stream);
+
+/* The same convolution in F16X3 arithmetic (see SSD_PRECISION_F16X3): fp32 tensors in and
+ * out, the split-fp16 rows exist only inside the call.  Test entry point for the kernel the
+ * F16X3 forward runs. */
+int ssd_conv2d_f16x3(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                     const float *w_host /* [k,k,Cin,Cout] */, int32_t k, int32_t Cout,
+                     int32_t stride, int32_t pad_beg, int32_t OH, int32_t OW,
+                     const float *bn_mean_host, const float *bn_sf_host, const float *bn_beta_host,
+                     const float *bias_host, const float *up_dev, int32_t act, float *out_dev,
+                     void *stream);
 
 /* depthwise_conv (depthwise_conv.py:5-26): 3x3, weights [3,3,C,1], optional BN + act. */
 int ssd_depthwise3x3(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t C,

@@ -87,6 +87,11 @@ SIGNATURES = {
     "ssd_anchors": (ctypes.c_int, [_i, _i, _f]),
     "ssd_conv2d": (ctypes.c_int, [_vp, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f,
                                   _vp, _i, _vp, _vp]),
+    "ssd_conv2d_f16x3": (ctypes.c_int, [_vp, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f,
+                                        _vp, _i, _vp, _vp]),
+    "ssd_set_precision": (ctypes.c_int, [_vp, _i]),
+    "ssd_get_precision": (ctypes.c_int, [_vp]),
+    "ssd_status": (ctypes.c_int, [_vp, _i32p]),
     "ssd_depthwise3x3": (ctypes.c_int, [_vp, _i, _i, _i, _i, _f, _i, _i, _i, _i, _f, _f, _f, _i,
                                         _vp, _vp]),
     "ssd_dw_pw": (ctypes.c_int, [_vp, _i, _i, _i, _i, _f, _i, _f, _f, _f, _i, _f, _i, _f, _f, _f, _i, _vp, _vp]),

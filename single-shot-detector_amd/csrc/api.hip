@@ -101,6 +101,8 @@ static void bn_pack(const float *gamma, const float *beta, const float *mean, co
 
 struct ConvW {
     float *wt = nullptr, *mean = nullptr, *sf = nullptr, *beta = nullptr, *bias = nullptr;
+    float *wt16 = nullptr;     // the same rows in split-fp16 form, scaled by 2^s (precision mode f16x3)
+    float scale16 = 1.0f;      // 2^-s
     int CinP = 0, CoutP = 0, CoutPad = 0, taps = 1, tile = IGEMM_128x128;
     int Cin_l = 0, Cout_l = 0;
 };
@@ -143,7 +145,29 @@ static int pack_conv(DevPool &pool, const float *w, int k, int Cin_l, int Cout_l
             for (int p = 0; p < cw.CinP; ++p)
                 if (inmap[p] >= 0) dst[p] = w[((size_t)tap * Cin_l + inmap[p]) * Cout_l + outmap[n]];
         }
-    return pool.upload(&cw.wt, t);
+    SSDCHK(pool.upload(&cw.wt, t));
+    // split-fp16 rows of w * 2^s (igemm.hip "S16"): per octet of 8 input channels 8 halves h, then 8 halves
+    // l = f16(w*2^s - h).  s puts the largest magnitude into [2^8, 2^9): every l of a weight within 2^-10 of
+    // the largest is a normal half, and the scale is undone exactly in the epilogue (acc * 2^-s).
+    float mx = 0.0f;
+    for (float v : t) mx = fmaxf(mx, fabsf(v));
+    int sh = 0;
+    if (mx > 0.0f && std::isfinite(mx)) sh = 8 - ilogbf(mx);
+    sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+    cw.scale16 = ldexpf(1.0f, -sh);
+    std::vector<uint16_t> t16(t.size() * 2);
+    for (size_t r = 0; r < t.size() / 8; ++r)
+        for (int e = 0; e < 8; ++e) {
+            const float x = ldexpf(t[r * 8 + e], sh);
+            const _Float16 hh = (_Float16)x;
+            const _Float16 ll = (_Float16)(x - (float)hh);
+            memcpy(&t16[r * 16 + e], &hh, 2);
+            memcpy(&t16[r * 16 + 8 + e], &ll, 2);
+        }
+    uint16_t *d16 = nullptr;
+    SSDCHK(pool.upload(&d16, t16));
+    cw.wt16 = (float *)d16;
+    return SSD_OK;
 }
 
 static int upload_bn(DevPool &pool, const BnHost &b, ConvW &cw)
@@ -173,12 +197,17 @@ struct LevelDesc {
     long long res_off;
 };
 
+// in_fmt / out_fmt / res_fmt: 0 fp32 rows, 1 split-fp16 rows (ssd_internal.h); flags: the handle's status word
 static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2, const float *res, int B, int stride,
-                       int pad, int act, const std::vector<LevelDesc> &lv, bool dense)
+                       int pad, int act, const std::vector<LevelDesc> &lv, bool dense, int in_fmt = 0, int out_fmt = 0,
+                       int res_fmt = 0, int *flags = nullptr)
 {
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = in; a.wt = cw.wt; a.out = out; a.out2 = out2;
+    a.in = in; a.wt = in_fmt ? cw.wt16 : cw.wt; a.out = out; a.out2 = out2;
+    a.in_fmt = in_fmt; a.out_fmt = out_fmt; a.res_fmt = res ? res_fmt : 0;
+    a.acc_scale = in_fmt ? cw.scale16 : 1.0f;
+    a.flags = flags;
     a.mean = cw.mean; a.sf = cw.sf; a.beta = cw.beta; a.bias = cw.bias; a.res = res;
     a.B = B; a.Cin = cw.CinP; a.Cout = cw.CoutP; a.CoutPad = cw.CoutPad; a.taps = cw.taps;
     a.stride = stride; a.pad = pad; a.act = act;
@@ -224,7 +253,7 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
 }
 
 // ----------------------------------------------------------------------------- handle
-struct Retained { const float *dev; int B, H, W, C, Cp; bool permuted; };
+struct Retained { const float *dev; int B, H, W, C, Cp; bool permuted; int fmt = 0; /* 1: split-fp16 rows */ };
 
 struct EvPair { hipEvent_t a, b; int cls; int fwd; };
 
@@ -265,6 +294,8 @@ struct ssd_handle {
     ConvW tower[2][4], final_[2];       // [box, class]
     std::vector<int *> tabs;            // shufflenet gather tables (device)
     int c_ch[3] = {0, 0, 0};            // logical channels of c3, c4, c5
+    int precision = SSD_PRECISION_F32;  // ssd_set_precision
+    int *flags_dev = nullptr;           // status word (bit 0: an S16 tensor was clamped to the fp16 range)
     // plans
     int pB = 0, pH = 0, pW = 0;
     std::vector<Plan *> plans;
@@ -635,7 +666,41 @@ extern "C" int ssd_create(const ssd_config *cfg, ssd_handle **out)
         delete h;
         return fail(SSD_ERR_HIP, "ssd_create: cannot create events");
     }
+    if (hipMalloc((void **)&h->flags_dev, sizeof(int)) != hipSuccess || hipMemset(h->flags_dev, 0, sizeof(int)) != hipSuccess) {
+        delete h;
+        return fail(SSD_ERR_HIP, "ssd_create: cannot allocate the status word");
+    }
+    if (const char *e = getenv("SSD_PRECISION")) {     // default for handles that never call ssd_set_precision
+        if (!strcmp(e, "f16x3")) h->precision = SSD_PRECISION_F16X3;
+        else if (!strcmp(e, "f32")) h->precision = SSD_PRECISION_F32;
+        else { (void)hipFree(h->flags_dev); delete h; return fail(SSD_ERR_INVALID, "SSD_PRECISION must be f32 or f16x3"); }
+    }
     *out = h;
+    return SSD_OK;
+}
+
+extern "C" int ssd_set_precision(ssd_handle *h, int32_t mode)
+{
+    if (!h || (mode != SSD_PRECISION_F32 && mode != SSD_PRECISION_F16X3)) return fail(SSD_ERR_INVALID, "ssd_set_precision: bad arguments");
+    if (mode == h->precision) return SSD_OK;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    free_plans(h);                  // the layer plan (tensor formats, kernels) depends on the mode
+    h->precision = mode;
+    return SSD_OK;
+}
+
+extern "C" int ssd_get_precision(ssd_handle *h) { return h ? h->precision : SSD_ERR_INVALID; }
+
+extern "C" int ssd_status(ssd_handle *h, int32_t *flags_out)
+{
+    if (!h || !flags_out) return fail(SSD_ERR_INVALID, "ssd_status: null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    int v = 0;
+    HIPCHK(hipMemcpy(&v, h->flags_dev, sizeof(int), hipMemcpyDeviceToHost));
+    if (v) HIPCHK(hipMemset(h->flags_dev, 0, sizeof(int)));
+    *flags_out = v;
     return SSD_OK;
 }
 
@@ -651,6 +716,7 @@ extern "C" void ssd_destroy(ssd_handle *h)
     if (h->ev_gin) (void)hipEventDestroy(h->ev_gin);
     if (h->ev_gout) (void)hipEventDestroy(h->ev_gout);
     if (h->gstream) (void)hipStreamDestroy(h->gstream);
+    if (h->flags_dev) (void)hipFree(h->flags_dev);
     h->wpool.free_all();
     delete h;
 }
@@ -793,6 +859,10 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     DevPool &ap = pl.pool;
     auto falloc = [&](float **p, long long nfloats) { return ap.alloc((void **)p, (size_t)nfloats * sizeof(float)); };
 
+    // precision mode f16x3: FPN + heads run on split-fp16 operands (igemm.hip "S16"); the backbone stays exact
+    // fp32 and hands over c5 in S16 rows, c3 / c4 (which the next depthwise layer also reads) in fp32.
+    const int X16 = h->precision == SSD_PRECISION_F16X3 ? 1 : 0;
+    int *const FL = h->flags_dev;
     // ---------------- backbone
     float *C3 = nullptr, *C4 = nullptr, *C5 = nullptr;
     const int h2 = H / 2, w2 = W / 2;
@@ -849,9 +919,10 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             }
             if (fuse)
                 pl.ops.push_back(make_dwpw_op(h->dw[i], cw, cur, B, dh, dwid, s, SSD_ACT_RELU6, SSD_ACT_RELU6, pwo));
-            else
+            else   // c5 feeds only the FPN (lateral5, p6): in f16x3 mode it is written in split-fp16 rows
                 pl.ops.push_back(make_conv_op(cw, dwo, pwo, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU6,
-                                              {dense_level(ch, cwid, ch, cwid, cw.CoutP)}, true));
+                                              {dense_level(ch, cwid, ch, cwid, cw.CoutP)}, true, 0, (i == 12 && X16) ? 1 : 0, 0, h->flags_dev));
+            if (i == 12 && X16) pl.retained["c5"].fmt = 1;
             cur = pwo;
         }
     } else {
@@ -948,8 +1019,8 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         const ConvW &c5 = h->pw[ipw];
         SSDCHK(falloc(&C5, (long long)B * ch * cwid * c5.CoutP));
         pl.ops.push_back(make_conv_op(c5, cur, C5, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
-                                      {dense_level(ch, cwid, ch, cwid, c5.CoutP)}, true));
-        pl.retained["c5"] = Retained{C5, B, ch, cwid, c5.Cout_l, c5.CoutP, true};
+                                      {dense_level(ch, cwid, ch, cwid, c5.CoutP)}, true, 0, X16, 0, FL));
+        pl.retained["c5"] = Retained{C5, B, ch, cwid, c5.Cout_l, c5.CoutP, true, X16};
     }
 
     // ---------------- FPN (feature_extractor.py:40-76)
@@ -973,39 +1044,41 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         return (int)pl.ops.size() - 1;
     };
     const int id_c5 = (int)pl.ops.size() - 1;          // last backbone op (produces c5)
-    const int id_l5 = push(make_conv_op(h->lat[2], C5, X5, nullptr, nullptr, B, 1, 0, SSD_ACT_NONE, {lvl(2, 256)}, true), 0);
+    const int id_l5 = push(make_conv_op(h->lat[2], C5, X5, nullptr, nullptr, B, 1, 0, SSD_ACT_NONE, {lvl(2, 256)}, true, X16, X16, 0, FL), 0);
     {   // p6 = conv s2 (c5): BN+ReLU -> P6, ReLU(raw) -> T6 (input of p7, :60)
         LevelDesc d = dense_level(py.h[2], py.w[2], py.h[3], py.w[3], 256);
         d.out_off = py.off[3];
-        push(make_conv_op(h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true), 1, {id_c5});
+        push(make_conv_op(h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 1, {id_c5});
         LevelDesc d7 = dense_level(py.h[3], py.w[3], py.h[4], py.w[4], 256);
         d7.out_off = py.off[4];
-        push(make_conv_op(h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true), 1);
+        push(make_conv_op(h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true, X16, X16, 0, FL), 1);
     }
     {   // p5 = conv(x5)
         LevelDesc d = lvl(2, 256);
         d.out_off = py.off[2];
-        push(make_conv_op(h->pconv[2], X5, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true), 1, {id_l5});
+        push(make_conv_op(h->pconv[2], X5, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 1, {id_l5});
     }
     // x4 = up(x5) + lateral4(c4); p4;  x3 = up(x4) + lateral3(c3); p3
-    const int id_l4 = push(make_conv_op(h->lat[1], C4, X4, nullptr, X5, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true), 0);
+    // lateral4 / lateral3 read c4 / c3 in fp32 (exact-fp32 MFMA, 1.2 % of the work); the upsampled operand and the
+    // output follow the mode
+    const int id_l4 = push(make_conv_op(h->lat[1], C4, X4, nullptr, X5, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true, 0, X16, X16, FL), 0);
     int id_p4, id_p3;
     {
         LevelDesc d = lvl(1, 256);
         d.out_off = py.off[1];
-        id_p4 = push(make_conv_op(h->pconv[1], X4, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true), 1, {id_l4});
+        id_p4 = push(make_conv_op(h->pconv[1], X4, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 1, {id_l4});
     }
-    push(make_conv_op(h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true), 0);
+    push(make_conv_op(h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true, 0, X16, X16, FL), 0);
     {
         LevelDesc d = lvl(0, 256);
         d.out_off = py.off[0];
-        id_p3 = push(make_conv_op(h->pconv[0], X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true), 0);
+        id_p3 = push(make_conv_op(h->pconv[0], X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 0);
         pl.ops[id_p3].fpn_end = true;
     }
     for (int l = 0; l < 5; ++l) {
         char nm[8];
         snprintf(nm, sizeof nm, "p%d", l + 3);
-        pl.retained[nm] = Retained{P + py.off[l], B, py.h[l], py.w[l], 256, 256, true};
+        pl.retained[nm] = Retained{P + py.off[l], B, py.h[l], py.w[l], 256, 256, true, X16};
     }
 
     // ---------------- heads (box_predictor.py:36-155), all levels per launch; box tower on the
@@ -1027,7 +1100,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         for (int i = 0; i < 4; ++i) {
             std::vector<LevelDesc> lv;
             for (int l = 0; l < 5; ++l) lv.push_back(dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, py.off[l], py.off[l], l * 256));
-            tower_ops[t].push_back(make_conv_op(h->tower[t][i], in, out, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true));
+            tower_ops[t].push_back(make_conv_op(h->tower[t][i], in, out, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true, X16, X16, 0, FL));
             in = out;
             out = (out == TA) ? TB : TA;
         }
@@ -1041,7 +1114,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             d.param_off = 0;
             lv.push_back(d);
         }
-        tower_ops[t].push_back(make_conv_op(h->final_[t], in, t == 0 ? codes : logits, nullptr, nullptr, B, 1, 1, SSD_ACT_NONE, lv, false));
+        tower_ops[t].push_back(make_conv_op(h->final_[t], in, t == 0 ? codes : logits, nullptr, nullptr, B, 1, 1, SSD_ACT_NONE, lv, false, X16, 0, 0, FL));
     }
     // enqueue order interleaved so both hardware queues stay fed.  The first box-tower layer
     // (main) needs p4..p7 from the second stream, the first class-tower layer (second stream)
@@ -1273,8 +1346,15 @@ extern "C" int ssd_get_tensor(ssd_handle *h, const char *name, float *dst, int64
         std::vector<float> tmp((size_t)rows * r.Cp);
         HIPCHK(hipMemcpy(tmp.data(), r.dev, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
         for (long long q = 0; q < rows; ++q)
-            for (int c = 0; c < r.C; ++c)
-                dst[done + q * r.C + c] = tmp[q * r.Cp + (r.permuted ? ssd_phys_of_logical(c) : c)];
+            for (int c = 0; c < r.C; ++c) {
+                const int pc = r.permuted ? ssd_phys_of_logical(c) : c;
+                if (r.fmt) {          // split-fp16 row: per octet 8 halves h, 8 halves l
+                    const _Float16 *row = (const _Float16 *)&tmp[q * r.Cp];
+                    dst[done + q * r.C + c] = (float)row[(pc >> 3) * 16 + (pc & 7)] + (float)row[(pc >> 3) * 16 + 8 + (pc & 7)];
+                } else {
+                    dst[done + q * r.C + c] = tmp[q * r.Cp + pc];
+                }
+            }
         done += rows * r.C;
         Btot += r.B;
         dims[1] = r.H; dims[2] = r.W; dims[3] = r.C;
@@ -1298,7 +1378,7 @@ extern "C" int ssd_get_tensor_dev(ssd_handle *h, const char *name, float *dst_de
         const Retained &r = it->second;
         const long long rows = (long long)r.B * r.H * r.W;
         if (cap < done + rows * r.C) return fail(SSD_ERR_INVALID, "ssd_get_tensor_dev: destination too small");
-        if (r.permuted) HIPCHK(launch_permute_channels(r.dev, rows, r.C, r.Cp, 0, dst_dev + done, (hipStream_t)stream));
+        if (r.permuted) HIPCHK(launch_permute_channels(r.dev, rows, r.C, r.Cp, r.fmt ? 2 : 0, dst_dev + done, (hipStream_t)stream));
         else HIPCHK(hipMemcpyAsync(dst_dev + done, r.dev, (size_t)rows * r.C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
         done += rows * r.C;
         Btot += r.B;
@@ -1385,7 +1465,7 @@ static int to_dev(DevPool &pool, const float *host, size_t n, float **out)
     return pool.upload(out, v);
 }
 
-extern "C" int ssd_conv2d(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t Cin, const float *w_host,
+static int conv2d_impl(int x16, const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t Cin, const float *w_host,
                           int32_t k, int32_t Cout, int32_t stride, int32_t pad_beg, int32_t OH, int32_t OW,
                           const float *bn_mean, const float *bn_sf, const float *bn_beta, const float *bias_host,
                           const float *up_dev, int32_t act, float *out_dev, void *stream)
@@ -1427,21 +1507,49 @@ extern "C" int ssd_conv2d(const float *in_dev, int32_t B, int32_t H, int32_t W, 
         const long long rin = (long long)B * H * W, rout = (long long)B * OH * OW;
         SSDCHK(pool.alloc((void **)&tin, (size_t)rin * CinP * 4));
         SSDCHK(pool.alloc((void **)&tout, (size_t)rout * CoutP * 4));
-        HIPCHK(launch_permute_channels(in_dev, rin, Cin, CinP, 1, tin, s));
+        // f16x3: input, upsampled operand and (unless a bias form / odd width forbids S16 rows) output in split-fp16
+        const int o16 = x16 && !bias_host && CoutP % 8 == 0 ? 1 : 0;
+        int *flags = nullptr;
+        if (x16) { SSDCHK(pool.alloc((void **)&flags, sizeof(int))); HIPCHK(hipMemsetAsync(flags, 0, sizeof(int), s)); }
+        HIPCHK(launch_permute_channels(in_dev, rin, Cin, CinP, x16 ? 3 : 1, tin, s));
         if (up_dev) {
             SSDCHK(pool.alloc((void **)&tup, (size_t)(rout / 4) * CoutP * 4));
-            HIPCHK(launch_permute_channels(up_dev, rout / 4, Cout, CoutP, 1, tup, s));
+            HIPCHK(launch_permute_channels(up_dev, rout / 4, Cout, CoutP, o16 ? 3 : 1, tup, s));
         }
-        Op op = make_conv_op(cw, tin, tout, nullptr, tup, B, stride, pad_beg, act, {dense_level(H, W, OH, OW, CoutP)}, true);
+        Op op = make_conv_op(cw, tin, tout, nullptr, tup, B, stride, pad_beg, act, {dense_level(H, W, OH, OW, CoutP)}, true,
+                             x16, o16, o16, flags);
         HIPCHK(op.run(s));
-        HIPCHK(launch_permute_channels(tout, rout, Cout, CoutP, 0, out_dev, s));
+        HIPCHK(launch_permute_channels(tout, rout, Cout, CoutP, o16 ? 2 : 0, out_dev, s));
         HIPCHK(hipStreamSynchronize(s));
+        if (x16) {
+            int f = 0;
+            HIPCHK(hipMemcpy(&f, flags, sizeof(int), hipMemcpyDeviceToHost));
+            if (f) return fail(SSD_ERR_INVALID, "ssd_conv2d_f16x3: a value left the fp16 range (|x| > 65504)");
+        }
         return SSD_OK;
     };
     rc = body();
     (void)hipStreamSynchronize(s);
     pool.free_all();
     return rc;
+}
+
+extern "C" int ssd_conv2d(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t Cin, const float *w_host,
+                          int32_t k, int32_t Cout, int32_t stride, int32_t pad_beg, int32_t OH, int32_t OW,
+                          const float *bn_mean, const float *bn_sf, const float *bn_beta, const float *bias_host,
+                          const float *up_dev, int32_t act, float *out_dev, void *stream)
+{
+    return conv2d_impl(0, in_dev, B, H, W, Cin, w_host, k, Cout, stride, pad_beg, OH, OW, bn_mean, bn_sf, bn_beta, bias_host,
+                       up_dev, act, out_dev, stream);
+}
+
+extern "C" int ssd_conv2d_f16x3(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t Cin, const float *w_host,
+                                int32_t k, int32_t Cout, int32_t stride, int32_t pad_beg, int32_t OH, int32_t OW,
+                                const float *bn_mean, const float *bn_sf, const float *bn_beta, const float *bias_host,
+                                const float *up_dev, int32_t act, float *out_dev, void *stream)
+{
+    return conv2d_impl(1, in_dev, B, H, W, Cin, w_host, k, Cout, stride, pad_beg, OH, OW, bn_mean, bn_sf, bn_beta, bias_host,
+                       up_dev, act, out_dev, stream);
 }
 
 extern "C" int ssd_depthwise3x3(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t C, const float *w_host,
@@ -1684,7 +1792,16 @@ extern "C" int ssd_bench_conv(int32_t B, int32_t H, int32_t W, int32_t Cin, int3
             SSDCHK(pool.alloc((void **)&ts, (size_t)nblk * 9 * 8));
             g_dbg_ts = ts;
         }
-        Op op = make_conv_op(cw, in, out, nullptr, nullptr, B, stride, pad, SSD_ACT_RELU, lv, true);
+        // SSD_BENCH_PRECISION=f16x3: the same launch on split-fp16 rows (input converted in place of the fp32 image)
+        const char *bp = getenv("SSD_BENCH_PRECISION");
+        const int x16 = bp && !strcmp(bp, "f16x3") ? 1 : 0;
+        if (x16) {
+            float *in16;
+            SSDCHK(pool.alloc((void **)&in16, (size_t)in_total * 4));
+            HIPCHK(launch_permute_channels(in, in_total / CinP, CinP, CinP, 3, in16, nullptr));
+            in = in16;
+        }
+        Op op = make_conv_op(cw, in, out, nullptr, nullptr, B, stride, pad, SSD_ACT_RELU, lv, true, x16, x16);
         g_dbg_ts = nullptr;
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0));

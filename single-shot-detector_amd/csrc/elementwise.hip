@@ -284,20 +284,35 @@ hipError_t launch_gather_channels(const float *x, int xs, const float *y, int ys
 
 // to_phys = 1: in [rows][C] logical -> out [rows][Cpad] physical (pad channels zero)
 // to_phys = 0: in [rows][Cpad] physical -> out [rows][C] logical
+// to_phys = 2 / 3: the same with the physical side in split-fp16 (S16) rows: per octet of 8 physical
+//   channels 8 halves h then 8 halves l, value = h + l (igemm.hip)
 __global__ __launch_bounds__(256) void permute_kernel(const float *__restrict__ in, long long rows, int C, int Cpad,
                                                        int to_phys, float *__restrict__ out)
 {
-    const int Cw = to_phys ? Cpad : C;
+    const int Cw = (to_phys & 1) ? Cpad : C;
     const long long total = rows * Cw;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(idx % Cw);
         const long long r = idx / Cw;
-        if (to_phys) {
+        if (to_phys == 1) {
             const int l = logical_of_phys(j);
             out[idx] = l < C ? in[r * C + l] : 0.0f;
-        } else {
+        } else if (to_phys == 0) {
             out[idx] = in[r * Cpad + phys_of_logical(j)];
+        } else if (to_phys == 3) {
+            const int l = logical_of_phys(j);
+            float x = l < C ? in[r * C + l] : 0.0f;
+            x = fminf(fmaxf(x, -65504.0f), 65504.0f);
+            const _Float16 h = (_Float16)x;
+            const _Float16 lo = (_Float16)(x - (float)h);
+            _Float16 *row = (_Float16 *)(out + r * Cpad);
+            row[(j >> 3) * 16 + (j & 7)] = h;
+            row[(j >> 3) * 16 + 8 + (j & 7)] = lo;
+        } else {
+            const int p = phys_of_logical(j);
+            const _Float16 *row = (const _Float16 *)(in + r * Cpad);
+            out[idx] = (float)row[(p >> 3) * 16 + (p & 7)] + (float)row[(p >> 3) * 16 + 8 + (p & 7)];
         }
     }
 }
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(256) void permute_kernel(const float *__restrict__ 
 hipError_t launch_permute_channels(const float *in, long long rows, int C, int Cpad, int to_phys, float *out,
                                    hipStream_t s)
 {
-    const long long total = rows * (to_phys ? Cpad : C);
+    const long long total = rows * ((to_phys & 1) ? Cpad : C);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks < 1) blocks = 1;

@@ -23,11 +23,51 @@
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------
+// S16 ("split fp16", precision mode f16x3).  An fp32 value x is kept as two halves
+// h = f16(x), l = f16(x - h) (x - h is exact in fp32; h + l carries ~22 significand bits and
+// fp16 subnormals are honoured by the matrix cores, measured: scripts/experiments/
+// mfma_f16_probe.hip).  A tensor row of Cp channels is Cp*4 bytes as in fp32: per octet of 8
+// physical channels 16 B of h followed by 16 B of l.  A product x*w is evaluated as
+// xh*wh + xh*wl + xl*wh on v_mfma_f32_32x32x16_f16 (every term exact in fp32, the dropped
+// xl*wl term is 2^-22 relative), accumulated in fp32: 3 MFMAs of 32 pipe cycles per 16
+// channels instead of 8 exact-fp32 MFMAs of 64 cycles -- 5.3x the matrix throughput at the
+// accuracy of an fp32 accumulation chain (K = 2304: max error vs double 7.2e-6 for both).
+// The result is NOT bit-identical to the oracle's fmaf chain; tests bound it by the
+// north-star tolerance instead.  The K-step stays 32 channels = 128 B per row, so the
+// global -> LDS path and the LDS image are the ones of the fp32 kernel.
+// ---------------------------------------------------------------------------------------
+static __device__ __forceinline__ void split_f16(const v4f v, v2u &hi, v2u &lo, bool &ovf)
+{
+    v4h h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e];
+        ovf |= !(fabsf(x) <= 65504.0f);
+        x = __builtin_fminf(__builtin_fmaxf(x, -65504.0f), 65504.0f);
+        h[e] = (_Float16)x;
+        l[e] = (_Float16)(x - (float)h[e]);
+    }
+    hi = __builtin_bit_cast(v2u, h);
+    lo = __builtin_bit_cast(v2u, l);
+}
+static __device__ __forceinline__ v4f join_f16(const v2u hi, const v2u lo)
+{
+    const v4h h = __builtin_bit_cast(v4h, hi), l = __builtin_bit_cast(v4h, lo);
+    v4f v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)h[e] + (float)l[e];
+    return v;
+}
 
 // DBG (timing experiments only, results are wrong): 1 = no global loads / LDS writes in the
 // K loop, 2 = additionally no LDS fragment reads, 3 = additionally no barrier.
 // DBG 7 (results are right): thread 0 of every block records 100 MHz timestamps of its phases.
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int DBGT = 0>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int DBGT = 0, int S16 = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const IgemmArgs a)
 {
     constexpr int DBG = DBGT == 7 ? 0 : DBGT;
@@ -109,8 +149,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     // ---- per-lane fragment read offsets (4 octets of the 32-channel K-step)
     int roff[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-        roff[g] = (lane & 31) * 128 + (((2 * g + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4);
+    for (int g = 0; g < 4; ++g) {
+        // fp32: octet g, lanes 0-31 physical channels 0-3, lanes 32-63 physical 4-7.
+        // S16: g = 2*s + hl: 16-channel step s, lane group (lane >> 5) takes octet 2s + group,
+        //      hl = 0 the h chunk, 1 the l chunk of that octet.
+        const int chunk = S16 ? ((g >> 1) * 4 + 2 * (lane >> 5) + (g & 1)) : (2 * g + (lane >> 5));
+        roff[g] = (lane & 31) * 128 + ((chunk ^ (((lane & 31) >> 1) & 7)) << 4);
+    }
 
     v16f acc[WM][WN];
 #pragma unroll
@@ -198,6 +243,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    if constexpr (!S16) {
     v4f fa0[WM], fb0[WN], fa1[WM], fb1[WN];
     gload();
     gadvance();
@@ -245,6 +291,97 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         mfma16(fa1, fb1);
     }
 
+    } else {
+    // ---- S16 operands: a K-step is two 16-channel steps of 3*WM*WN MFMAs (32 pipe cycles each).
+    // Phase 0: fragments of step 1, registers (K-step ks+1) -> LDS stage nxt, MFMAs of step 0, then
+    // the global loads of K-step ks+2; barrier; phase 1: first fragments of the next stage, MFMAs of
+    // step 1.
+    auto rd16 = [&](int stage, int st, v4f (&ah)[WM], v4f (&al)[WM], v4f (&bh)[WN], v4f (&bl)[WN]) {
+        const unsigned char *abase = lds + stage * STAGE + wave_m * WM * 4096;
+        const unsigned char *bbase = lds + stage * STAGE + A_BYTES + wave_n * WN * 4096;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            ah[i] = *(const v4f *)(abase + i * 4096 + roff[2 * st]);
+            al[i] = *(const v4f *)(abase + i * 4096 + roff[2 * st + 1]);
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            bh[j] = *(const v4f *)(bbase + j * 4096 + roff[2 * st]);
+            bl[j] = *(const v4f *)(bbase + j * 4096 + roff[2 * st + 1]);
+        }
+    };
+    // small terms first; consecutive MFMAs go to different accumulators
+    auto mf16 = [&](const v4f (&ah)[WM], const v4f (&al)[WM], const v4f (&bh)[WN], const v4f (&bl)[WN]) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, al[i]), __builtin_bit_cast(v8h, bh[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, ah[i]), __builtin_bit_cast(v8h, bl[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, ah[i]), __builtin_bit_cast(v8h, bh[j]), acc[i][j], 0, 0, 0);
+    };
+    constexpr int PM16 = 3 * WM * WN;
+    constexpr int NFR16 = 2 * (WM + WN);
+    // phase 0 carries the NA+NB LDS writes and the NA+NB global loads, phase 1 only fragment reads
+    auto sched16 = [&](auto staging_tag) {
+        constexpr bool STG = decltype(staging_tag)::value;
+        constexpr int NST = NA + NB;
+        constexpr int PER = (NST + PM16 - 1) / PM16;      // staging instructions of each kind per MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, NFR16, 0);
+#pragma unroll
+        for (int i = 0; i < PM16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (STG) {
+                if (i * PER < NST) {
+                    __builtin_amdgcn_sched_group_barrier(0x200, PER, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, PER, 0);
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    v4f ah0[WM], al0[WM], bh0[WN], bl0[WN], ah1[WM], al1[WM], bh1[WN], bl1[WN];
+    gload();
+    gadvance();
+    lstore(0);
+    gload();
+    gadvance();
+    __syncthreads();
+    mark(1);
+    rd16(0, 0, ah0, al0, bh0, bl0);
+    if (KS > 1) {
+      int ks = 0;
+      do {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        rd16(cur, 1, ah1, al1, bh1, bl1);
+        lstore(nxt);
+        mf16(ah0, al0, bh0, bl0);
+        gload();
+        sched16(std::true_type{});
+        __syncthreads();
+        rd16(nxt, 0, ah0, al0, bh0, bl0);
+        mf16(ah1, al1, bh1, bl1);
+        sched16(std::false_type{});
+        gadvance();
+      } while (++ks < KS - 1);
+    }
+    {
+        const int cur = (KS - 1) & 1;
+        rd16(cur, 1, ah1, al1, bh1, bl1);
+        mf16(ah0, al0, bh0, bl0);
+        mf16(ah1, al1, bh1, bl1);
+    }
+    }
+
     // ---- epilogue: batch norm / bias / upsample-add / activation.
     // The accumulators (lane = column, 16 registers = 16 rows of a 32x32 tile) go through a
     // per-wave LDS transpose so that every lane ends up with 4 consecutive channels of one
@@ -275,6 +412,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         mark(3);
         const int c4 = lane % C4N;
         const int col = tile_n * BN + wave_n * RW + c4 * 4;
+        // S16 rows: the lane's 4 channels are half an octet -- h at (octet*8 + half*2) floats, l 4 floats on
+        const int col16 = tile_n * BN + wave_n * RW + (c4 >> 1) * 8 + (c4 & 1) * 2;
         constexpr int ROWS_PER_IT = 64 / C4N;    // rows per wave-instruction (C4N = 24: 2 rows, lanes 48-63 idle)
         constexpr int ITS = WM * 32 / ROWS_PER_IT;
         const bool colok = col < a.Cout && lane < ROWS_PER_IT * C4N;   // parameter vectors are padded to CoutPad
@@ -304,7 +443,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
                     const int b = m / P, p = m - b * P;
                     const int oy = p / OW, ox = p - oy * OW;
                     const int ch = L.OH >> 1, cw = OW >> 1;
-                    rv[it] = *(const v4f *)(a.res + L.res_off + (((long long)b * ch + (oy >> 1)) * cw + (ox >> 1)) * a.Cout + col);
+                    const float *rrow = a.res + L.res_off + (((long long)b * ch + (oy >> 1)) * cw + (ox >> 1)) * a.Cout;
+                    if (a.res_fmt) rv[it] = join_f16(*(const v2u *)(rrow + col16), *(const v2u *)(rrow + col16 + 4));
+                    else rv[it] = *(const v4f *)(rrow + col);
                 }
             }
 #pragma unroll
@@ -323,15 +464,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         constexpr unsigned OOBS = 0x80000000u;
         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + L.out_off), 0, (int)OOBS, 0x00020000);
         const __amdgpu_buffer_rsrc_t o2rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.out2 ? a.out2 : a.out) + L.out_off), 0, (int)OOBS, 0x00020000);
-        const unsigned off0 = (unsigned)(b0 * bstride + p0 * rstride + col) * 4u;
+        const unsigned off0 = (unsigned)(b0 * bstride + p0 * rstride + (a.out_fmt ? col16 : col)) * 4u;
         const bool vec_rows = ((a.Cout | rstride | bstride | (int)L.out_off) & 3) == 0;
+        bool ovf = false;
         // One straight-line loop per epilogue form (uniform switch below): all LDS reads first,
         // then arithmetic and stores of independent rows for the scheduler to interleave.
-        auto store_rows = [&](auto mode_tag) {
+        auto store_rows = [&](auto mode_tag, auto o16_tag) {
             constexpr int MODE = decltype(mode_tag)::value;   // 0 plain, 1 +upsampled, 2 BN, 3 BN + relu(raw) copy, 4 bias
+            constexpr bool O16 = decltype(o16_tag)::value;    // output rows in S16 form
             v4f raw[ITS];
 #pragma unroll
             for (int it = 0; it < ITS; ++it) raw[it] = *(const v4f *)(reg + (it * ROWS_PER_IT + row0) * RW + (c4 << 2));
+            if constexpr (S16) {                              // weights were scaled by a power of two (exact)
+#pragma unroll
+                for (int it = 0; it < ITS; ++it)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) raw[it][e] = raw[it][e] * a.acc_scale;
+            }
             unsigned off = off0;
             int p = p0;
 #pragma unroll
@@ -360,7 +509,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
                     if (a.act == 2) v[e] = v[e] < 6.0f ? v[e] : 6.0f;
                 }
                 const unsigned o = (m < M && colok) ? off : OOBS;
-                if (vec_rows) {
+                if constexpr (O16) {
+                    v2u hi, lo;
+                    split_f16(v, hi, lo, ovf);
+                    __builtin_amdgcn_raw_buffer_store_b64(hi, orsrc, (int)o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(lo, orsrc, (int)(o == OOBS ? OOBS : o + 16u), 0, 0);
+                } else if (vec_rows) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), orsrc, (int)o, 0, 0);
                 } else {   // output rows that are not 16-B aligned (head widths 6*C with odd C): per-element stores
                     // (hipcc 7.2: bit-casting v[e] element by element inside the unrolled loop stored element 0
@@ -374,7 +528,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
                     v4f q;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) q[e] = raw[it][e] > 0.0f ? raw[it][e] : 0.0f;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, q), o2rsrc, (int)o, 0, 0);
+                    if constexpr (O16) {
+                        v2u hi, lo;
+                        split_f16(q, hi, lo, ovf);
+                        __builtin_amdgcn_raw_buffer_store_b64(hi, o2rsrc, (int)o, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(lo, o2rsrc, (int)(o == OOBS ? OOBS : o + 16u), 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, q), o2rsrc, (int)o, 0, 0);
+                    }
                 }
                 p += rR;
                 const bool wrap = p >= P;
@@ -384,15 +545,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         };
         // (host checks: bias and batch norm are exclusive, the upsampled operand comes without
         // either, the second output only with batch norm)
-        if (has_bn) {
-            if (a.out2) store_rows(std::integral_constant<int, 3>{});
-            else store_rows(std::integral_constant<int, 2>{});
+        using F = std::false_type;
+        using T = std::true_type;
+        if (a.out_fmt) {          // S16 rows (host: never together with a bias or unaligned widths)
+            if (has_bn) {
+                if (a.out2) store_rows(std::integral_constant<int, 3>{}, T{});
+                else store_rows(std::integral_constant<int, 2>{}, T{});
+            } else if (a.res) {
+                store_rows(std::integral_constant<int, 1>{}, T{});
+            } else {
+                store_rows(std::integral_constant<int, 0>{}, T{});
+            }
+            // a value outside the fp16 range was clamped: tell the host (ssd_status)
+            if (ovf && a.flags) atomicOr(a.flags, 1);
+        } else if (has_bn) {
+            if (a.out2) store_rows(std::integral_constant<int, 3>{}, F{});
+            else store_rows(std::integral_constant<int, 2>{}, F{});
         } else if (a.bias) {
-            store_rows(std::integral_constant<int, 4>{});
+            store_rows(std::integral_constant<int, 4>{}, F{});
         } else if (a.res) {
-            store_rows(std::integral_constant<int, 1>{});
+            store_rows(std::integral_constant<int, 1>{}, F{});
         } else {
-            store_rows(std::integral_constant<int, 0>{});
+            store_rows(std::integral_constant<int, 0>{}, F{});
         }
     }
     if constexpr (DBGT == 7) {
@@ -423,13 +597,13 @@ int igemm_tile_bn(int tile)
     }
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int DBG = 0>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int DBG = 0, int S16 = 0>
 static hipError_t launch_tt(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
     constexpr int lds_bytes = 2 * (BM + BN) * 128;
     static bool attr_set = false;
-    auto k = igemm_kernel<WAVES_M, WAVES_N, WM, WN, TAPS, DBG>;
+    auto k = igemm_kernel<WAVES_M, WAVES_N, WM, WN, TAPS, DBG, S16>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -444,6 +618,11 @@ static hipError_t launch_tt(const IgemmArgs &a, int total_tiles_m, hipStream_t s
 template <int WAVES_M, int WAVES_N, int WM, int WN, int DBG = 0>
 static hipError_t launch_t(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 {
+    if constexpr (DBG == 0) {
+        if (a.in_fmt)
+            return a.taps == 9 ? launch_tt<WAVES_M, WAVES_N, WM, WN, 9, 0, 1>(a, total_tiles_m, s)
+                               : launch_tt<WAVES_M, WAVES_N, WM, WN, 1, 0, 1>(a, total_tiles_m, s);
+    }
     return a.taps == 9 ? launch_tt<WAVES_M, WAVES_N, WM, WN, 9, DBG>(a, total_tiles_m, s)
                        : launch_tt<WAVES_M, WAVES_N, WM, WN, 1, DBG>(a, total_tiles_m, s);
 }
@@ -463,6 +642,10 @@ hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStre
     if (a.mean && (a.bias || a.res)) return hipErrorInvalidValue;
     if (a.bias && a.res) return hipErrorInvalidValue;
     if (a.out2 && !a.mean) return hipErrorInvalidValue;
+    // S16 rows are whole octets: no bias form, widths and strides multiples of 8 floats; diagnostics are fp32 only
+    if (a.out_fmt && (a.bias || (a.Cout & 7) || !a.dense_out)) return hipErrorInvalidValue;
+    if (a.res_fmt && !a.res) return hipErrorInvalidValue;
+    if (a.in_fmt && tile >= 10) return hipErrorInvalidValue;
     for (int i = 0; i < a.nlevels; ++i)     // 32-bit byte offsets in the epilogue's buffer stores, relative to the level's base
         if ((long long)a.B * a.lv[i].out_bstride * 4 >= (1LL << 31) || a.lv[i].out_bstride < 0) return hipErrorInvalidValue;
     if (a.n_tiles_n * igemm_tile_bn(tile >= 10 ? 0 : tile) != a.CoutPad || a.nlevels < 1 || a.nlevels > SSD_MAX_LEVELS) return hipErrorInvalidValue;

@@ -46,6 +46,12 @@ struct IgemmArgs {
     int nlevels;
     int n_tiles_n;
     int dense_out;         // 1: out_bstride == OH*OW*out_rstride for every level
+    // precision mode f16x3 (igemm.hip, "S16"): formats of the activations this launch touches
+    int in_fmt;            // 1: `in` rows and `wt` rows are split-fp16 (h|l per octet), MFMA f16 x3
+    int out_fmt;           // 1: `out` (and `out2`) rows are written split-fp16
+    int res_fmt;           // 1: `res` rows are split-fp16
+    float acc_scale;       // in_fmt = 1: 2^-s undoing the power-of-two scale of the packed weights
+    int *flags;            // nullable: bit 0 set when an S16 output had to be clamped to the fp16 range
     long long *ts;         // diagnostics (ssd_bench_conv tile 17): per-block phase timestamps, else null
     IgemmLevel lv[SSD_MAX_LEVELS];
 };
@@ -88,6 +94,8 @@ hipError_t launch_maxpool(const float *in, int B, int H, int W, int C, float *ou
 hipError_t launch_gather_channels(const float *x, int xs, const float *y, int ys, long long rows, const int *tab,
                                   int Cout, float *out, hipStream_t s);
 // channel permutation logical<->physical (+ zero padding to Cpad) for the stage entry points
+// to_phys: 0 physical fp32 -> logical, 1 logical -> physical fp32,
+//          2 physical S16 -> logical fp32, 3 logical fp32 -> physical S16
 hipError_t launch_permute_channels(const float *in, long long rows, int C, int Cpad, int to_phys, float *out,
                                    hipStream_t s);
 

@@ -51,8 +51,8 @@ def out_size(n, k, stride, mode):
     return (n + (k - 1) - k) // stride + 1, pad_beg
 
 
-def conv2d(x, w, stride=1, mode="SAME", bn=None, bias=None, up=None, act=None):
-    """Dense 1x1 / 3x3 convolution on the MFMA kernel (ssd_conv2d).
+def conv2d(x, w, stride=1, mode="SAME", bn=None, bias=None, up=None, act=None, precision="f32"):
+    """Dense 1x1 / 3x3 convolution on the MFMA kernel (ssd_conv2d / ssd_conv2d_f16x3).
     x [B,H,W,Cin] cuda f32; w HWIO numpy; bn = (mean, sf, beta) numpy; up = coarser map."""
     torch = _torch()
     _check_dev(torch, x, torch.float32, "x")
@@ -70,10 +70,10 @@ def conv2d(x, w, stride=1, mode="SAME", bn=None, bias=None, up=None, act=None):
         _check_dev(torch, up, torch.float32, "up")
         if tuple(up.shape) != (B, OH // 2, OW // 2, Cout):
             raise ValueError("up must have shape [B, OH/2, OW/2, Cout]")
-    check(lib().ssd_conv2d(_ptr(x), B, H, W, Cin, w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
-                           k, Cout, stride, pb, OH, OW, keep[0][1], keep[1][1], keep[2][1], kb[1],
-                           _ptr(up) if up is not None else None, ACT[act], _ptr(out),
-                           _stream(torch)))
+    fn = {"f32": lib().ssd_conv2d, "f16x3": lib().ssd_conv2d_f16x3}[precision]
+    check(fn(_ptr(x), B, H, W, Cin, w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+             k, Cout, stride, pb, OH, OW, keep[0][1], keep[1][1], keep[2][1], kb[1],
+             _ptr(up) if up is not None else None, ACT[act], _ptr(out), _stream(torch)))
     return out
 
 
@@ -216,10 +216,20 @@ class Engine:
     """Owns one ssd_handle: weights + workspace on one GPU.  `forward` is the frozen
     graph's sess.run (inference/detector.py:51-52) for a batch."""
 
-    def __init__(self, params, weights, device=0):
+    PRECISIONS = {"f32": 0, "f16x3": 1}     # SSD_PRECISION_* of include/ssd_hip.h
+
+    def __init__(self, params, weights, device=0, precision=None):
+        """precision: "f32" (every convolution an exact fp32 fmaf chain, bit-identical to the
+        oracle), "f16x3" (FPN + heads on split-fp16 operands, fp32-chain accuracy, ~1e-6 from
+        the oracle) or None = params["precision"] if present, else the library default (the
+        SSD_PRECISION environment variable, else f32)."""
         torch = _torch()
         self.params = dict(params)
         self.device = int(device)
+        if precision is None:
+            precision = self.params.get("precision")
+        if precision is not None and precision not in self.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
         cfg = SsdConfig(0 if params["backbone"] == "mobilenet" else 1,
                         float(params["depth_multiplier"]), int(params["num_classes"]),
                         float(params["score_threshold"]), float(params["iou_threshold"]),
@@ -236,12 +246,29 @@ class Engine:
                                             a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
                                             shape, a.ndim))
             check(lib().ssd_finalize(self._h))
+            if precision is not None:
+                check(lib().ssd_set_precision(self._h, self.PRECISIONS[precision]))
         except Exception:
             lib().ssd_destroy(self._h)
             self._h = None
             raise
         self.T = int(params["num_classes"]) * int(params["max_boxes_per_class"])
         self._static = {}
+
+    @property
+    def precision(self):
+        v = lib().ssd_get_precision(self._h)
+        return {n: k for k, n in self.PRECISIONS.items()}[v]
+
+    def set_precision(self, precision):
+        check(lib().ssd_set_precision(self._h, self.PRECISIONS[precision]))
+
+    def status(self):
+        """Synchronises; returns and clears the handle's status word (bit 0: an f16x3 activation
+        left the fp16 range and was clamped -- re-run those forwards with precision "f32")."""
+        v = ctypes.c_int32()
+        check(lib().ssd_status(self._h, ctypes.byref(v)))
+        return v.value
 
     def close(self):
         if getattr(self, "_h", None):
