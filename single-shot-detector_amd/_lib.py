@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SOURCES = ["api.hip", "igemm.hip", "dwpw.hip", "elementwise.hip", "postprocess.hip"]
+_SOURCES = ["api.hip", "igemm.hip", "igemm16.hip", "dwpw.hip", "elementwise.hip", "postprocess.hip"]
 _LIB_PATH = os.path.join(_CSRC, "libssd_hip.so")
 _lib = None
 

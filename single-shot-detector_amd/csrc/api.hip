@@ -226,11 +226,22 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
             else if (atoi(e) == 64) tile = IGEMM_64x64;
         }
     }
-    a.n_tiles_n = cw.CoutPad / igemm_tile_bn(tile);
+    // Large S16 -> S16 batch-norm launches (head towers, FPN outputs at serving batch sizes) take the
+    // 256 x 256-tile kernel of igemm16.hip once there are at least two full rounds of tiles for the 256 CUs;
+    // SSD_IGEMM16=0 / 1 pins the choice (tests, A/B runs).
+    if (in_fmt && out_fmt && dense && cw.mean && !cw.bias && !res && cw.CoutPad % 256 == 0 && cw.CoutP == cw.CoutPad &&
+        cw.taps * (cw.CinP / 32) >= 3 && g_force_tile < 0) {
+        long long t256 = 0;
+        for (size_t i = 0; i < lv.size(); ++i) t256 += ((long long)B * lv[i].OH * lv[i].OW + 255) / 256;
+        bool use16 = t256 * (cw.CoutPad / 256) >= 2 * 256;
+        if (const char *e = getenv("SSD_IGEMM16")) use16 = atoi(e) != 0;
+        if (use16) tile = IGEMM16_TILE;
+    }
+    a.n_tiles_n = cw.CoutPad / (tile == IGEMM16_TILE ? 256 : igemm_tile_bn(tile));
     a.dense_out = dense ? 1 : 0;
     int tiles = 0;
     double rows = 0, inb = 0;
-    const int BM = igemm_tile_bm(tile);
+    const int BM = tile == IGEMM16_TILE ? 256 : igemm_tile_bm(tile);
     for (size_t i = 0; i < lv.size(); ++i) {
         IgemmLevel &L = a.lv[i];
         L.H = lv[i].H; L.W = lv[i].W; L.OH = lv[i].OH; L.OW = lv[i].OW;
@@ -248,7 +259,7 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
     op.cls = cw.taps == 9 ? 0 : 1;
     op.flops = 2.0 * rows * cw.taps * cw.Cin_l * cw.Cout_l;
     op.bytes = inb + rows * cw.Cout_l * 4.0 + (double)cw.taps * cw.Cin_l * cw.Cout_l * 4.0;
-    op.run = [a, tile, tiles](hipStream_t s) { return launch_igemm(tile, a, tiles, s); };
+    op.run = [a, tile, tiles](hipStream_t s) { return tile == IGEMM16_TILE ? launch_igemm16(a, tiles, s) : launch_igemm(tile, a, tiles, s); };
     return op;
 }
 
@@ -1790,6 +1801,7 @@ extern "C" int ssd_bench_conv(int32_t B, int32_t H, int32_t W, int32_t Cin, int3
             for (size_t l = 0; l < lv.size(); ++l) nblk += ((long long)B * lv[l].OH * lv[l].OW + 127) / 128;
             nblk *= cw.CoutPad / 128;
             SSDCHK(pool.alloc((void **)&ts, (size_t)nblk * 9 * 8));
+            HIPCHK(hipMemset(ts, 0, (size_t)nblk * 9 * 8));      // kernels with fewer blocks leave zero rows
             g_dbg_ts = ts;
         }
         // SSD_BENCH_PRECISION=f16x3: the same launch on split-fp16 rows (input converted in place of the fp32 image)

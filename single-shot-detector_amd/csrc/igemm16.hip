@@ -1,0 +1,406 @@
+// Large-tile implicit GEMM for split-fp16 (S16) operands -- the throughput form of precision mode
+// f16x3 (see igemm.hip for the format and the arithmetic): the 3x3 head-tower / FPN convolutions and
+// 1x1 convolutions whose input, weights and output are S16 rows and whose epilogue is batch norm +
+// activation (optionally the second relu(raw) output of fpn p6).
+//
+//   block     256 threads = 4 waves (2 x 2), ONE block per CU; tile 256 rows x 256 output channels,
+//             each wave a 128 x 128 sub-tile = 4 x 4 MFMA tiles of 32 x 32 -> 256 accumulator registers
+//             (the unified 512-entry register file of a wave that has its SIMD to itself)
+//   why       the LDS is the narrow resource of the f16x3 product: a K-step of 32 channels needs
+//             (WM + WN) x 4 KB of fragments per wave for WM x WN x 6 MFMAs of 32 cycles.  64 x 64 wave
+//             tiles (igemm.hip, two blocks per CU) ask for 125 B/clk/CU of the 128 B/clk the LDS has;
+//             128 x 128 wave tiles ask for 63.
+//   staging   LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write.  One wave
+//             instruction fills 8 rows x 128 B; the XOR swizzle of the LDS image (slot = chunk ^
+//             ((row >> 1) & 7), conflict-free ds_read_b128 fragments) is applied to the per-lane SOURCE
+//             address; the convolution's zero padding is the buffer range check (out-of-range lanes
+//             deliver zeros to the LDS, measured).  Two stages of 64 KB; the DMA of K-step k+2 is issued
+//             right behind the barrier that retires stage k and has a whole K-step (3072 matrix-pipe
+//             cycles) to land.
+//   K-step    two 16-channel steps of 48 MFMAs; fragments double buffered in registers; one barrier per
+//             K-step, placed before the last 16 MFMAs so that the first fragments of the next stage are
+//             read underneath them.
+#include "ssd_internal.h"
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+// DBG (timing experiments only, results are wrong): 1 = no DMA in the K loop, 2 = additionally no fragment
+// reads, 3 = additionally no barrier.  Selected by SSD_IGEMM16_DBG at launch.
+template <int TAPS, int DBG = 0>
+__global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
+{
+    constexpr int ABL = DBG == 7 ? 0 : DBG;   // ablation level
+    long long stamp[5] = {0, 0, 0, 0, 0};     // DBG 7 (results right): 100 MHz wall-clock stamps of thread 0
+    auto mark = [&](int i) {
+        if constexpr (DBG == 7) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[i] = wall_clock64(); }
+    };
+    mark(0);
+    constexpr int BM = 256, BN = 256, WM = 4, WN = 4;
+    constexpr int A_BYTES = BM * 128;
+    constexpr int STAGE = (BM + BN) * 128;          // 64 KB
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+
+    int swz;
+    {   // blocks b, b+8, ... share an XCD: consecutive tiles per XCD (bijective remap, as igemm.hip)
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_n = swz % a.n_tiles_n;
+    const int tile_m = swz / a.n_tiles_n;
+    int lvl = 0;
+#pragma unroll
+    for (int i = 1; i < SSD_MAX_LEVELS; ++i)
+        if (i < a.nlevels && tile_m >= a.lv[i].tile_begin) lvl = i;
+    const IgemmLevel &L = a.lv[lvl];
+    const int H = L.H, W = L.W, OW = L.OW, M = L.M;
+    const int P = L.OH * L.OW;
+    const int Cin = a.Cin;
+    const int m0 = (tile_m - L.tile_begin) * BM;
+
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.in + L.in_off), 0, (int)((long long)a.B * H * W * Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)a.wt, 0, (int)((long long)TAPS * a.CoutPad * Cin * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    // ---- DMA bookkeeping.  Wave w stages rows w*64 .. w*64+63 of the A tile and of the B tile, 8 rows
+    // per instruction: lane -> row (lane >> 3), LDS slot (lane & 7), source chunk slot ^ ((row >> 1) & 7).
+    int abase[8], aiy0[8], aix0[8];
+    unsigned offc[8];
+    int boff[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int row = wave * 64 + u * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int m = m0 + row;
+        const bool rowok = m < M;
+        const int mm = rowok ? m : 0;
+        const int b = mm / P, p = mm - b * P;
+        const int oy = p / OW, ox = p - oy * OW;
+        abase[u] = (b * H * W * Cin + chunk * 4) * 4;
+        aiy0[u] = rowok ? oy * a.stride - a.pad : -(1 << 20);
+        aix0[u] = ox * a.stride - a.pad;
+        boff[u] = ((tile_n * BN + row) * Cin + chunk * 4) * 4;
+    }
+    auto tap_offsets = [&](int t) {
+        const int tky = TAPS == 9 ? t / 3 : 0, tkx = TAPS == 9 ? t - 3 * tky : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int iy = aiy0[u] + tky, ix = aix0[u] + tkx;
+            const bool ok = ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+            const unsigned o = (unsigned)(abase[u] + (iy * W + ix) * Cin * 4);
+            offc[u] = ok ? o : OOB;
+        }
+    };
+    const int b_tapstride = a.CoutPad * Cin * 4;
+    const int KC = Cin >> 5;
+    const int KS = TAPS * KC;           // host: KS >= 3
+    // The A half and the B half of a K-step's DMA are issued in different phases; each keeps its own
+    // (tap, channel-block) cursor.
+    int atap = 0, akc = 0, bso = 0, bkc = 0;
+    auto dma_a = [&](int stage) {
+        const int so = akc * 128;
+        unsigned char *abuf = lds + stage * STAGE + wave * 64 * 128;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_ptr_t)(abuf + u * 1024), 16, (int)offc[u], so, 0, 0);
+    };
+    auto adv_a = [&]() {                // uniform branch once per tap, kept out of the MFMA phases
+        if (++akc == KC) {
+            akc = 0;
+            ++atap;
+            tap_offsets(atap < TAPS ? atap : TAPS - 1);
+        }
+    };
+    auto dma_b = [&](int stage) {
+        unsigned char *bbuf = lds + stage * STAGE + A_BYTES + wave * 64 * 128;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (lds_ptr_t)(bbuf + u * 1024), 16, boff[u], bso, 0, 0);
+        bso += 128;
+        if (++bkc == KC) { bkc = 0; bso += b_tapstride - KC * 128; }
+    };
+
+    // ---- fragments: g = 2*s + hl (16-channel step s, h / l chunk); lane group (lane >> 5) takes octet 2s + group
+    int roff[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int chunk = (g >> 1) * 4 + 2 * (lane >> 5) + (g & 1);
+        roff[g] = (lane & 31) * 128 + ((chunk ^ (((lane & 31) >> 1) & 7)) << 4);
+    }
+    // order of the reads = order of first use: l of A and h of B (first product), then h of A, l of B
+    auto rd16 = [&](int stage, int st, v4f (&ah)[WM], v4f (&al)[WM], v4f (&bh)[WN], v4f (&bl)[WN]) {
+        const unsigned char *ab = lds + stage * STAGE + wave_m * WM * 4096;
+        const unsigned char *bb = lds + stage * STAGE + A_BYTES + wave_n * WN * 4096;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) al[i] = *(const v4f *)(ab + i * 4096 + roff[2 * st + 1]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bh[j] = *(const v4f *)(bb + j * 4096 + roff[2 * st]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) ah[i] = *(const v4f *)(ab + i * 4096 + roff[2 * st]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bl[j] = *(const v4f *)(bb + j * 4096 + roff[2 * st + 1]);
+    };
+    v16f acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    auto mf = [&](const v4f (&x)[WM], const v4f (&y)[WN]) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, x[i]), __builtin_bit_cast(v8h, y[j]), acc[i][j], 0, 0, 0);
+    };
+    // One K-step = 96 MFMAs in three scheduling regions:
+    //   top1 (48 MFMAs of step 0): the 16 fragment reads of step 1, one per MFMA (a ds_read_b128 of the four
+    //        waves together is 32 LDS cycles = one MFMA), and the 8 B-tile DMA pieces of K-step ks+1, one per
+    //        three MFMAs (a 1-KB piece is 16 cycles of the CU's 64 B/clk vector-memory path; the four waves'
+    //        pieces together stay well under it, and the pieces have 40+ MFMAs to land before the barrier)
+    //   top2 (first 16 MFMAs of step 1), then the barrier that retires stage cur
+    //   post (last 32 MFMAs): the 16 fragment reads of the next stage's step 0, two per MFMA, then the 8 A-tile
+    //        DMA pieces of K-step ks+2 into stage cur, one per three MFMAs
+    // (sched_group_barrier chooses instruction classes, not instances: the MFMAs that use the fragments
+    //  being read must sit in a later region, or the scheduler issues them right behind their reads)
+    auto sched_top1 = [&]() {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto sched_post = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto retire = [&]() {
+        // this wave's share of the next stage has landed, every fragment of stage cur is in registers
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    v4f ah0[WM], al0[WM], bh0[WN], bl0[WN], ah1[WM], al1[WM], bh1[WN], bl1[WN];
+    tap_offsets(0);
+    dma_a(0); adv_a();
+    dma_b(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    dma_a(1); adv_a();                  // K-step 1 -> stage 1 (its B half follows in the first top phase)
+    rd16(0, 0, ah0, al0, bh0, bl0);
+    __builtin_amdgcn_sched_barrier(0);
+    mark(1);
+    int ks = 0;
+    for (; ks < KS - 2; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ABL < 2) rd16(cur, 1, ah1, al1, bh1, bl1);
+        if (ABL < 1) dma_b(nxt);        // B half of K-step ks+1
+        mf(al0, bh0);
+        mf(ah0, bl0);
+        mf(ah0, bh0);
+        sched_top1();
+        mf(al1, bh1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL < 3) retire();
+        if (ABL < 2) rd16(nxt, 0, ah0, al0, bh0, bl0);
+        if (ABL < 1) dma_a(cur);        // A half of K-step ks+2
+        mf(ah1, bl1);
+        mf(ah1, bh1);
+        sched_post();
+        adv_a();
+    }
+    {   // K-step KS-2: stages K-step KS-1's B half, nothing beyond
+        const int cur = ks & 1, nxt = cur ^ 1;
+        rd16(cur, 1, ah1, al1, bh1, bl1);
+        dma_b(nxt);
+        mf(al0, bh0);
+        mf(ah0, bl0);
+        mf(ah0, bh0);
+        mf(al1, bh1);
+        retire();
+        rd16(nxt, 0, ah0, al0, bh0, bl0);
+        mf(ah1, bl1);
+        mf(ah1, bh1);
+        // K-step KS-1
+        rd16(nxt, 1, ah1, al1, bh1, bl1);
+        mf(al0, bh0);
+        mf(ah0, bl0);
+        mf(ah0, bh0);
+        mf(al1, bh1);
+        mf(ah1, bl1);
+        mf(ah1, bh1);
+    }
+
+    // ---- epilogue: acc * 2^-s -> batch norm -> activation -> split -> S16 rows; 32 rows of the wave's
+    // sub-tile per pass through a per-wave LDS transpose (lane = column in the accumulators, lane = 8
+    // consecutive channels of one row in the stores: one 32-B octet [h x 8 | l x 8] per lane).
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    mark(2);
+    __syncthreads();
+    float *reg = (float *)(lds + wave * (32 * 128 * 4));
+    const int c8 = lane & 15;                               // octet of the wave's 128 columns
+    const int col = tile_n * BN + wave_n * 128 + c8 * 8;    // physical channel of the lane's first value
+    const int poff = L.param_off + col;
+    // Batch norm folded to one fused multiply-add per value, y = raw * (2^-s * sf) + (beta - mean * sf): this
+    // mode is bounded by a tolerance, not bit-identical to the oracle's three separately rounded operations,
+    // and the epilogue of a block that has its CU to itself is pure VALU time (no other block's MFMAs hide it).
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f ka[4], kb[4];
+    {
+        const v4f m0v = *(const v4f *)(a.mean + poff), m1v = *(const v4f *)(a.mean + poff + 4);
+        const v4f s0v = *(const v4f *)(a.sf + poff), s1v = *(const v4f *)(a.sf + poff + 4);
+        const v4f b0v = *(const v4f *)(a.beta + poff), b1v = *(const v4f *)(a.beta + poff + 4);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            ka[e] = v2f{s0v[2 * e] * a.acc_scale, s0v[2 * e + 1] * a.acc_scale};
+            ka[2 + e] = v2f{s1v[2 * e] * a.acc_scale, s1v[2 * e + 1] * a.acc_scale};
+            kb[e] = v2f{b0v[2 * e] - m0v[2 * e] * s0v[2 * e], b0v[2 * e + 1] - m0v[2 * e + 1] * s0v[2 * e + 1]};
+            kb[2 + e] = v2f{b1v[2 * e] - m1v[2 * e] * s1v[2 * e], b1v[2 * e + 1] - m1v[2 * e + 1] * s1v[2 * e + 1]};
+        }
+    }
+    constexpr unsigned OOBS = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + L.out_off), 0, (int)OOBS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t o2rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.out2 ? a.out2 : a.out) + L.out_off), 0, (int)OOBS, 0x00020000);
+    const int rstride = L.out_rstride;                      // dense output: row m at m * rstride floats
+    const bool second = a.out2 != nullptr;
+    float vmax = 0.0f;                                      // largest magnitude written (fp16 range check)
+    auto split8 = [&](const v2f (&v)[4], v4u &hi, v4u &lo) {
+        v8h h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(__builtin_fabsf(v[e][0]), __builtin_fabsf(v[e][1])));
+            h[2 * e] = (_Float16)v[e][0];
+            h[2 * e + 1] = (_Float16)v[e][1];
+            l[2 * e] = (_Float16)(v[e][0] - (float)h[2 * e]);
+            l[2 * e + 1] = (_Float16)(v[e][1] - (float)h[2 * e + 1]);
+        }
+        hi = __builtin_bit_cast(v4u, h);
+        lo = __builtin_bit_cast(v4u, l);
+    };
+    const int act = a.act;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                reg[row * 128 + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + (lane >> 4);
+            const v4f r0 = *(const v4f *)(reg + row * 128 + c8 * 8);
+            const v4f r1 = *(const v4f *)(reg + row * 128 + c8 * 8 + 4);
+            const v2f raw[4] = {v2f{r0[0], r0[1]}, v2f{r0[2], r0[3]}, v2f{r1[0], r1[1]}, v2f{r1[2], r1[3]}};
+            v2f v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v2f y = __builtin_elementwise_fma(raw[e], ka[e], kb[e]);
+                if (act >= 1) y = __builtin_elementwise_max(y, v2f{0.0f, 0.0f});
+                if (act == 2) y = __builtin_elementwise_min(y, v2f{6.0f, 6.0f});
+                v[e] = y;
+            }
+            const int m = m0 + wave_m * 128 + i * 32 + row;
+            const unsigned o = m < M ? (unsigned)(m * rstride + col) * 4u : OOBS;
+            v4u hi, lo;
+            split8(v, hi, lo);
+            __builtin_amdgcn_raw_buffer_store_b128(hi, orsrc, (int)o, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(lo, orsrc, (int)(o == OOBS ? OOBS : o + 16u), 0, 0);
+            if (second) {                                   // relu(raw) (fpn p6 -> p7 input)
+                v2f q[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[e] = __builtin_elementwise_max(raw[e] * a.acc_scale, v2f{0.0f, 0.0f});
+                split8(q, hi, lo);
+                __builtin_amdgcn_raw_buffer_store_b128(hi, o2rsrc, (int)o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(lo, o2rsrc, (int)(o == OOBS ? OOBS : o + 16u), 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const bool ovf = !(vmax <= 65504.0f);                   // out of the fp16 range (or NaN): h = inf, rows invalid
+    if (ovf && a.flags) atomicOr(a.flags, 1);
+    if constexpr (DBG == 7) {
+        stamp[3] = wall_clock64();               // stores issued
+        mark(4);                                 // stores retired
+        if (tid == 0 && a.ts) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            long long *t = a.ts + (long long)blockIdx.x * 9;
+            for (int i = 0; i < 5; ++i) t[i] = stamp[i];
+            t[5] = t[6] = t[7] = 0;
+            t[8] = ((long long)xcc << 32) | hw;
+        }
+    }
+}
+
+template <int TAPS, int DBG = 0>
+static hipError_t launch16_t(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
+{
+    constexpr int lds_bytes = 2 * (256 + 256) * 128;
+    static bool attr_set = false;
+    auto k = igemm16_kernel<TAPS, DBG>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long long nblk = (long long)total_tiles_m * a.n_tiles_n;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+// Host-side checks of everything the kernel assumes (shapes, formats, 32-bit offsets).
+hipError_t launch_igemm16(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
+{
+    if (!a.in_fmt || !a.out_fmt || !a.dense_out) return hipErrorInvalidValue;
+    if (!a.mean || !a.sf || !a.beta || a.bias || a.res) return hipErrorInvalidValue;
+    if (a.Cin % 32 != 0 || a.CoutPad % 256 != 0 || a.Cout != a.CoutPad || (a.taps != 1 && a.taps != 9)) return hipErrorInvalidValue;
+    if (a.n_tiles_n * 256 != a.CoutPad || a.nlevels < 1 || a.nlevels > SSD_MAX_LEVELS) return hipErrorInvalidValue;
+    if (a.taps * (a.Cin / 32) < 3) return hipErrorInvalidValue;      // the software pipeline is three K-steps deep
+    if ((long long)a.taps * a.CoutPad * a.Cin * 4 >= (1LL << 31)) return hipErrorInvalidValue;
+    for (int i = 0; i < a.nlevels; ++i) {
+        const IgemmLevel &L = a.lv[i];
+        if ((long long)a.B * L.H * L.W * a.Cin * 4 >= (1LL << 31)) return hipErrorInvalidValue;
+        if (L.out_rstride != a.Cout || L.out_bstride != (long long)L.OH * L.OW * L.out_rstride) return hipErrorInvalidValue;
+        if ((long long)L.M * L.out_rstride * 4 >= (1LL << 31)) return hipErrorInvalidValue;
+    }
+    if (a.ts && a.taps == 9) return launch16_t<9, 7>(a, total_tiles_m, s);     // ssd_bench_conv tile 17: phase stamps
+    if (const char *e = getenv("SSD_IGEMM16_DBG")) {     // timing experiments (scripts/bench_f16x3.py), 3x3 only
+        const int d = atoi(e);
+        if (a.taps == 9 && d == 1) return launch16_t<9, 1>(a, total_tiles_m, s);
+        if (a.taps == 9 && d == 2) return launch16_t<9, 2>(a, total_tiles_m, s);
+        if (a.taps == 9 && d == 3) return launch16_t<9, 3>(a, total_tiles_m, s);
+    }
+    return a.taps == 9 ? launch16_t<9>(a, total_tiles_m, s) : launch16_t<1>(a, total_tiles_m, s);
+}

@@ -61,6 +61,10 @@ enum IgemmTile { IGEMM_128x128 = 0, IGEMM_128x64 = 1, IGEMM_128x32 = 2, IGEMM_12
 int igemm_tile_bm(int tile);
 int igemm_tile_bn(int tile);
 hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s);
+// igemm16.hip: 256 x 256 tiles, one block per CU, S16 in / S16 out with batch norm (towers, FPN outputs);
+// tile_begin of the levels counts 256-row tiles, n_tiles_n = CoutPad / 256
+#define IGEMM16_TILE 100
+hipError_t launch_igemm16(const IgemmArgs &a, int total_tiles_m, hipStream_t s);
 
 // depthwise 3x3 (+BN+act) -> pointwise 1x1 (+BN+act) fused (dwpw.hip) ------------------------
 struct DwPwArgs {
