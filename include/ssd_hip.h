@@ -128,7 +128,8 @@ int ssd_get_tensor_dev(ssd_handle *h, const char *name, float *dst_dev, int64_t 
 
 /* Per-kernel-class timing with HIP events on the forward's stream (bench.py roofline).
  * classes: 0 conv3x3 MFMA, 1 pointwise MFMA, 2 depthwise, 3 first conv, 4 postprocess,
- * 5 other, 6 fused depthwise+pointwise.  total_ms of a class is the union of its kernels' intervals (the two head towers
+ * 5 other, 6 fused depthwise+pointwise, 7 conv3x3 on the 256x256-tile f16x3 kernel (igemm16.hip;
+ * class 0 then holds the remaining 3x3 launches).  total_ms of a class is the union of its kernels' intervals (the two head towers
  * overlap on two streams).  ssd_profile_read synchronises the recorded events. */
 int ssd_profile_enable(ssd_handle *h, int32_t on);
 int ssd_profile_read(ssd_handle *h, int32_t cls, double *total_ms, int64_t *launches,

@@ -61,7 +61,7 @@ def union_ms(intervals):
 
 
 nfwd = max(1, sum(len(v) for k, v in iv.items() if "first_conv" in k))
-c3 = [x for k, v in iv.items() if "igemm_kernel" in k and ", 9, 0>" in k for x in v]
+c3 = [x for k, v in iv.items() if ("igemm_kernel" in k and ", 9, 0" in k) or "igemm16_kernel<9" in k for x in v]
 class_line = ("all 3x3 igemm kernels (bench.py class conv3x3_mfma): %d launches in %d forwards, union %.3f ms per forward"
               " = %.4f ms per launch\n" % (len(c3), nfwd, union_ms(c3) / nfwd, union_ms(c3) / max(len(c3), 1)))
 with open(out + "/pmc_summary.txt", "w") as fo:
@@ -80,14 +80,17 @@ with open(out + "/pmc_summary.txt", "w") as fo:
             fo.write("    mfma_util=%.3f (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs))\n" % (m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8 * 1024)))
         for c in sorted(m):
             fo.write("    %-28s %.6g\n" % (c, m[c]))
-# traffic of the dominant kernel (3x3 implicit GEMM) for bench.py's roofline.traffic
-dom = [k for k in agg if "igemm_kernel<2, 2, 2, 2, 9" in k]
+# traffic of the dominant kernel for bench.py's roofline.traffic: the 256x256-tile f16x3 kernel when the run
+# used it (bench.py's default mode), else the exact-fp32 3x3 implicit GEMM; merged into one file by mode
+dom16 = [k for k in agg if "igemm16_kernel<9" in k]
+dom32 = [k for k in agg if "igemm_kernel<2, 2, 2, 2, 9, 0, 0" in k or k.rstrip().endswith("igemm_kernel<2, 2, 2, 2, 9, 0>")]
+mode, dom = ("f16x3", dom16) if dom16 else ("f32", dom32)
 if dom and "FETCH_SIZE" in agg[dom[0]] and "WRITE_SIZE" in agg[dom[0]]:
     f = agg[dom[0]]["FETCH_SIZE"]; w = agg[dom[0]]["WRITE_SIZE"]
     t = {"kernel": dom[0], "hbm_bytes_per_launch": (2 * sum(f) / len(f) + sum(w) / len(w)) * 1024,
          "launches_averaged": len(f), "correction": "FETCH_SIZE x2 (gfx950), KB -> bytes",
-         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py"}
-    json.dump(t, open(out + "/traffic.json", "w"), indent=1)
+         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py --precision " + mode}
+    json.dump({mode: t}, open(out + "/traffic.json", "w"), indent=1)
     print(t)
 print(open(out + "/pmc_summary.txt").read()[:3000])
 if os.path.exists(out + "/bench.json"):

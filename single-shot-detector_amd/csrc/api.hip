@@ -119,7 +119,7 @@ static int pick_tile(int CoutP)
 }
 
 // w: HWIO [k,k,Cin_l,Cout_l] -> wt [taps][CoutPad][CinP]
-#define SSD_NCLS 7                   // profile classes (include/ssd_hip.h)
+#define SSD_NCLS 8                   // profile classes (include/ssd_hip.h)
 // Conv2d_1..4 as one depthwise+pointwise launch: 751.9 -> 760.6 img/s at B=32 (masks 0x3 / 0x5 / 0x7 / 0xf:
 // 754.6 / 757.2 / 760.2 / 760.6); from Conv2d_5 on (K >= 256) the two-kernel pair is faster.
 #define SSD_FUSE_DW_DEFAULT 0xfu
@@ -256,7 +256,7 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
         inb += (double)B * L.H * L.W * cw.Cin_l * 4.0;
     }
     Op op;
-    op.cls = cw.taps == 9 ? 0 : 1;
+    op.cls = cw.taps == 9 ? (tile == IGEMM16_TILE ? 7 : 0) : 1;
     op.flops = 2.0 * rows * cw.taps * cw.Cin_l * cw.Cout_l;
     op.bytes = inb + rows * cw.Cout_l * 4.0 + (double)cw.taps * cw.Cin_l * cw.Cout_l * 4.0;
     op.run = [a, tile, tiles](hipStream_t s) { return tile == IGEMM16_TILE ? launch_igemm16(a, tiles, s) : launch_igemm(tile, a, tiles, s); };
@@ -782,7 +782,7 @@ static Pyr make_pyr(int B, int H, int W, int C)
     return p;
 }
 
-static Op make_dw_op(const DwW &d, const float *in, int B, int H, int W, int stride, int act, float *out, int Cl)
+static Op make_dw_op(const DwW &d, const float *in, int B, int H, int W, int stride, int act, float *out, int Cl, int out16 = 0)
 {
     const int OH = H / stride, OW = W / stride, pad = stride == 1 ? 1 : 0;
     Op op;
@@ -791,7 +791,7 @@ static Op make_dw_op(const DwW &d, const float *in, int B, int H, int W, int str
     op.bytes = ((double)B * H * W + (double)B * OH * OW) * Cl * 4.0;
     const DwW dd = d;
     op.run = [=](hipStream_t s) {
-        return launch_depthwise(in, B, H, W, dd.Cp, dd.w, stride, pad, OH, OW, dd.mean, dd.sf, dd.beta, act, out, s);
+        return launch_depthwise(in, B, H, W, dd.Cp, dd.w, stride, pad, OH, OW, dd.mean, dd.sf, dd.beta, act, out, s, out16);
     };
     return op;
 }
@@ -916,7 +916,10 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             float *dwo = (cur == X) ? Y : X;
             const ConvW &cw = h->pw[i];
             const bool fuse = ((fuse_mask >> i) & 1) && dwpw_eligible(h->dw[i], cw, B, ch, cwid, s);
-            if (!fuse) pl.ops.push_back(make_dw_op(h->dw[i], cur, B, ch, cwid, s, SSD_ACT_RELU6, dwo, h->pw[i].Cin_l));
+            // f16x3: an unfused pair hands the depthwise result (exact fp32, in [0, 6]) to its pointwise
+            // convolution in split-fp16 rows, and the pointwise product runs as 3 x f16 MFMA
+            const int pw16 = X16 && !fuse && (h->dw[i].Cp % 32 == 0) ? 1 : 0;
+            if (!fuse) pl.ops.push_back(make_dw_op(h->dw[i], cur, B, ch, cwid, s, SSD_ACT_RELU6, dwo, h->pw[i].Cin_l, pw16));
             const int dh = ch, dwid = cwid;
             ch /= s; cwid /= s;
             float *pwo;
@@ -932,7 +935,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 pl.ops.push_back(make_dwpw_op(h->dw[i], cw, cur, B, dh, dwid, s, SSD_ACT_RELU6, SSD_ACT_RELU6, pwo));
             else   // c5 feeds only the FPN (lateral5, p6): in f16x3 mode it is written in split-fp16 rows
                 pl.ops.push_back(make_conv_op(cw, dwo, pwo, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU6,
-                                              {dense_level(ch, cwid, ch, cwid, cw.CoutP)}, true, 0, (i == 12 && X16) ? 1 : 0, 0, h->flags_dev));
+                                              {dense_level(ch, cwid, ch, cwid, cw.CoutP)}, true, pw16, (i == 12 && X16) ? 1 : 0, 0, h->flags_dev));
             if (i == 12 && X16) pl.retained["c5"].fmt = 1;
             cur = pwo;
         }
@@ -1201,7 +1204,9 @@ static int make_plans(ssd_handle *h, int B, int H, int W)
     {   // every tensor an MFMA launch reads must stay < 2 GiB (32-bit buffer offsets): the largest is
         // the first depthwise / max-pool output [B, H/2, W/2, 32] -> split very large batches
         const ResizeDims rd = resize_dims(H, W, h->cfg.min_dimension, 128);
-        const long long per_img = (long long)((rd.nh + rd.ph) / 2) * ((rd.nw + rd.pw) / 2) * 32 * 4;
+        // (MobileNet: Conv2d_1_pointwise doubles the channels at the same resolution)
+        const int cmax = h->cfg.backbone == SSD_BACKBONE_MOBILENET && !h->pw.empty() ? std::max(h->firstCp, h->pw[0].CoutP) : h->firstCp;
+        const long long per_img = (long long)((rd.nh + rd.ph) / 2) * ((rd.nw + rd.pw) / 2) * cmax * 4;
         const long long bmax = ((1LL << 31) - 1) / per_img;
         if (bmax < 1) return fail(SSD_ERR_INVALID, "ssd_forward: image too large for one launch");
         const int need = (int)((B + bmax - 1) / bmax);

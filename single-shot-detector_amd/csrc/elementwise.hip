@@ -134,7 +134,9 @@ hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int 
 // row instead of 12) and every output keeps its own (ky,kx)-ordered fmaf chain.  An
 // out-of-image tap contributes fmaf(0, w, acc) == acc, so zero filling is exact.
 #define DW_PX 4
-template <int STRIDE>
+// OUT16: the result rows are written in split-fp16 form (h | l per octet, igemm.hip) for a pointwise
+// convolution that runs in precision mode f16x3; the values are exact fp32 results, rounded to h + l.
+template <int STRIDE, int OUT16 = 0>
 __global__ __launch_bounds__(256) void depthwise_kernel(const float *__restrict__ in, int B, int H, int W, int C,
                                                          const float *__restrict__ w, int pad, int OH, int OW,
                                                          const float *mean, const float *sf, const float *beta,
@@ -178,27 +180,54 @@ __global__ __launch_bounds__(256) void depthwise_kernel(const float *__restrict_
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[p][i] = fmaf(x[p * STRIDE + kx][i], wv[ky * 3 + kx][i], acc[p][i]);
         }
+        if constexpr (OUT16) {
+            typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            // 4 channels = half an octet: h at (octet * 8 + half * 2) floats, l 4 floats further
+            float *o = out + (((long long)b * OH + oy) * OW + ox0) * C + (c >> 3) * 8 + ((c >> 2) & 1) * 2;
+#pragma unroll
+            for (int p = 0; p < DW_PX; ++p)
+                if (ox0 + p < OW) {
+                    const v4f v = bn_act4(acc[p], mean, sf, beta, c, act);
+                    v4h h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = fminf(fmaxf(v[e], -65504.0f), 65504.0f);
+                        h[e] = (_Float16)x;
+                        l[e] = (_Float16)(x - (float)h[e]);
+                    }
+                    *(v2u *)(o + (long long)p * C) = __builtin_bit_cast(v2u, h);
+                    *(v2u *)(o + (long long)p * C + 4) = __builtin_bit_cast(v2u, l);
+                }
+        } else {
         float *o = out + (((long long)b * OH + oy) * OW + ox0) * C + c;
 #pragma unroll
         for (int p = 0; p < DW_PX; ++p)
             if (ox0 + p < OW) *(v4f *)(o + (long long)p * C) = bn_act4(acc[p], mean, sf, beta, c, act);
+        }
     }
 }
 
 hipError_t launch_depthwise(const float *in, int B, int H, int W, int C, const float *w, int stride, int pad, int OH,
                             int OW, const float *mean, const float *sf, const float *beta, int act, float *out,
-                            hipStream_t s)
+                            hipStream_t s, int out16)
 {
-    if (C % 4 || (stride != 1 && stride != 2)) return hipErrorInvalidValue;
+    if (C % 4 || (stride != 1 && stride != 2) || (out16 && C % 8)) return hipErrorInvalidValue;
     const long long total = (long long)B * OH * ((OW + DW_PX - 1) / DW_PX) * (C / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (blocks < 1) blocks = 1;
-    if (stride == 1)
+    if (stride == 1 && !out16)
         hipLaunchKernelGGL(depthwise_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, in, B, H, W, C, w, pad, OH, OW,
                            mean, sf, beta, act, out);
-    else
+    else if (!out16)
         hipLaunchKernelGGL(depthwise_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, in, B, H, W, C, w, pad, OH, OW,
+                           mean, sf, beta, act, out);
+    else if (stride == 1)
+        hipLaunchKernelGGL((depthwise_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, s, in, B, H, W, C, w, pad, OH, OW,
+                           mean, sf, beta, act, out);
+    else
+        hipLaunchKernelGGL((depthwise_kernel<2, 1>), dim3((unsigned)blocks), dim3(256), 0, s, in, B, H, W, C, w, pad, OH, OW,
                            mean, sf, beta, act, out);
     return hipGetLastError();
 }

@@ -106,7 +106,11 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
     const int KS = TAPS * KC;           // host: KS >= 3
     // The A half and the B half of a K-step's DMA are issued in different phases; each keeps its own
     // (tap, channel-block) cursor.
-    int atap = 0, akc = 0, bso = 0, bkc = 0;
+    // K order: channel block outer, filter tap INNER (this mode is not tied to the oracle's summation order).
+    // The nine taps of one 32-channel block touch the same 128-B lines of the tile's positions and their halo
+    // (256 + 2W + 2 positions instead of 9 x 256), nine K-steps apart instead of a whole K loop apart: the
+    // re-reads are L2 hits (tap-major order: 3.8 GB of L2 fills per tower launch against 0.76 GB algorithmic).
+    int atap = 0, akc = 0, btap = 0, bkc = 0;
     auto dma_a = [&](int stage) {
         const int so = akc * 128;
         unsigned char *abuf = lds + stage * STAGE + wave * 64 * 128;
@@ -114,20 +118,17 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
         for (int u = 0; u < 8; ++u)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_ptr_t)(abuf + u * 1024), 16, (int)offc[u], so, 0, 0);
     };
-    auto adv_a = [&]() {                // uniform branch once per tap, kept out of the MFMA phases
-        if (++akc == KC) {
-            akc = 0;
-            ++atap;
-            tap_offsets(atap < TAPS ? atap : TAPS - 1);
-        }
+    auto adv_a = [&]() {                // offsets of the next K-step's tap (VALU work for the MFMA gaps)
+        if (++atap == TAPS) { atap = 0; ++akc; }
+        if (TAPS > 1) tap_offsets(atap);
     };
     auto dma_b = [&](int stage) {
+        const int bso = btap * b_tapstride + bkc * 128;
         unsigned char *bbuf = lds + stage * STAGE + A_BYTES + wave * 64 * 128;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (lds_ptr_t)(bbuf + u * 1024), 16, boff[u], bso, 0, 0);
-        bso += 128;
-        if (++bkc == KC) { bkc = 0; bso += b_tapstride - KC * 128; }
+        if (++btap == TAPS) { btap = 0; ++bkc; }
     };
 
     // ---- fragments: g = 2*s + hl (16-channel step s, h / l chunk); lane group (lane >> 5) takes octet 2s + group
@@ -182,7 +183,11 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
             if (i % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     auto sched_post = [&]() {
@@ -213,7 +218,8 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
     dma_b(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    dma_a(1); adv_a();                  // K-step 1 -> stage 1 (its B half follows in the first top phase)
+    dma_a(1);                           // K-step 1 -> stage 1 (its B half follows in the first top phase); the A
+                                        // cursor advances at the top of every iteration, to K-step ks+2
     rd16(0, 0, ah0, al0, bh0, bl0);
     __builtin_amdgcn_sched_barrier(0);
     mark(1);
@@ -222,6 +228,7 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
         const int cur = ks & 1, nxt = cur ^ 1;
         if (ABL < 2) rd16(cur, 1, ah1, al1, bh1, bl1);
         if (ABL < 1) dma_b(nxt);        // B half of K-step ks+1
+        adv_a();                        // A offsets of K-step ks+2 (used behind the barrier)
         mf(al0, bh0);
         mf(ah0, bl0);
         mf(ah0, bh0);
@@ -234,7 +241,6 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
         mf(ah1, bl1);
         mf(ah1, bh1);
         sched_post();
-        adv_a();
     }
     {   // K-step KS-2: stages K-step KS-1's B half, nothing beyond
         const int cur = ks & 1, nxt = cur ^ 1;

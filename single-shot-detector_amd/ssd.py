@@ -359,7 +359,7 @@ class Engine:
 
     def profile_read(self):
         names = ["conv3x3_mfma", "pointwise_mfma", "depthwise", "first_conv", "postprocess", "other",
-                 "depthwise_pointwise_fused"]
+                 "depthwise_pointwise_fused", "conv3x3_f16x3_tile256"]
         out = {}
         for i, n in enumerate(names):
             ms, cnt = ctypes.c_double(), ctypes.c_int64()
