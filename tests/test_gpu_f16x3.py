@@ -250,3 +250,34 @@ def test_golden_tiny_f16x3(cuda, ssd):
     compare_outputs(out, z, "golden tiny f16x3")
     assert np.abs(eng.get_tensor("encoded_boxes").reshape(2, -1, 4) - z["encoded_boxes"]).max() <= TOL
     eng.close()
+
+
+def test_detector_f16x3_and_overflow_fallback(cuda, ssd, oracle_graph):
+    """Detector(precision="f16x3"): the drop-in API in the fast mode; and the safety net -- weights that push
+    an FPN activation beyond the fp16 range make the status word non-zero, the Detector warns, switches to
+    f32 and returns exactly what an f32 detector returns."""
+    params = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
+              "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
+    Wt = ssd.synthetic_weights(params, seed=3, logits_bias=-4.0)
+    img = np.random.default_rng(9).integers(0, 256, (128, 128, 3), dtype=np.uint8)
+    det = ssd.Detector(Wt, config=params, precision="f16x3")
+    boxes, labels, scores = det(img, score_threshold=0.2)
+    rb, rl, rs = oracle_graph.detector_call(oracle_graph.forward(img[None], Wt, ssd.load_config(params)), 0.2)
+    assert np.array_equal(labels, rl) and len(labels) > 0
+    assert np.abs(scores - rs).max() <= TOL and np.abs(boxes - rb).max() <= TOL
+    assert det.engine.precision == "f16x3"
+    # x5 = lateral5(c5) blown up by 1e6: |x5| > 65504
+    big = dict(Wt)
+    big["fpn/lateral5/kernel"] = Wt["fpn/lateral5/kernel"] * np.float32(1e6)
+    det2 = ssd.Detector(big, config=params, precision="f16x3")
+    with pytest.warns(UserWarning, match="fp16 range"):
+        b2, l2, s2 = det2(img, score_threshold=0.2)
+    assert det2.engine.precision == "f32"
+    det3 = ssd.Detector(big, config=params, precision="f32")
+    b3, l3, s3 = det3(img, score_threshold=0.2)
+    assert np.array_equal(b2, b3) and np.array_equal(l2, l3) and np.array_equal(s2, s3)
+    # the engine API reports the same condition without acting on it
+    eng = ssd.Engine(params, big, precision="f16x3")
+    eng.forward(cuda.from_numpy(img[None].copy()).cuda())
+    assert eng.status() == 1 and eng.status() == 0      # read-and-clear
+    eng.close()
