@@ -102,6 +102,8 @@ static void bn_pack(const float *gamma, const float *beta, const float *mean, co
 struct ConvW {
     float *wt = nullptr, *mean = nullptr, *sf = nullptr, *beta = nullptr, *bias = nullptr;
     float *wt16 = nullptr;     // the same rows in split-fp16 form, scaled by 2^s (precision mode f16x3)
+    float *wt16w = nullptr;    // wide outputs whose width 256 does not divide (480 class logits): the S16 rows again,
+    int CoutPad16 = 0;         //   padded to CoutPad16 = a multiple of 256 rows per tap for the 256x256-tile kernel
     float scale16 = 1.0f;      // 2^-s
     int CinP = 0, CoutP = 0, CoutPad = 0, taps = 1, tile = IGEMM_128x128;
     int Cin_l = 0, Cout_l = 0;
@@ -167,6 +169,17 @@ static int pack_conv(DevPool &pool, const float *w, int k, int Cin_l, int Cout_l
     uint16_t *d16 = nullptr;
     SSDCHK(pool.upload(&d16, t16));
     cw.wt16 = (float *)d16;
+    cw.CoutPad16 = cw.CoutPad;
+    if (cw.CoutP >= 256 && cw.CoutPad % 256 != 0) {
+        cw.CoutPad16 = round_up(cw.CoutP, 256);
+        const size_t rowh = (size_t)cw.CinP * 2;        // halves per row
+        std::vector<uint16_t> w16((size_t)cw.taps * cw.CoutPad16 * rowh, 0);
+        for (int tap = 0; tap < cw.taps; ++tap)
+            memcpy(&w16[(size_t)tap * cw.CoutPad16 * rowh], &t16[(size_t)tap * cw.CoutPad * rowh], (size_t)cw.CoutPad * rowh * 2);
+        uint16_t *dw = nullptr;
+        SSDCHK(pool.upload(&dw, w16));
+        cw.wt16w = (float *)dw;
+    }
     return SSD_OK;
 }
 
@@ -229,15 +242,24 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
     // Large S16 -> S16 batch-norm launches (head towers, FPN outputs at serving batch sizes) take the
     // 256 x 256-tile kernel of igemm16.hip once there are at least two full rounds of tiles for the 256 CUs;
     // SSD_IGEMM16=0 / 1 pins the choice (tests, A/B runs).
-    if (in_fmt && out_fmt && dense && cw.mean && !cw.bias && !res && cw.CoutPad % 256 == 0 && cw.CoutP == cw.CoutPad &&
-        cw.taps * (cw.CinP / 32) >= 3 && g_force_tile < 0) {
+    // Its second epilogue form (bias, fp32 rows: the class logits, 6 * num_classes wide) pads the width to a multiple of 256.
+    const bool bnform = out_fmt && dense && cw.mean && !cw.bias && cw.CoutPad % 256 == 0 && cw.CoutP == cw.CoutPad;
+    bool biasform = !out_fmt && !out2 && cw.bias && !cw.mean && act == SSD_ACT_NONE && cw.CoutP >= 256 && cw.CoutP % 8 == 0 &&
+                    (cw.wt16w || cw.CoutPad % 256 == 0);
+    for (size_t i = 0; i < lv.size(); ++i)
+        if ((lv[i].out_rstride | lv[i].out_bstride | lv[i].out_off) & 3 || lv[i].OH * lv[i].OW < 4) biasform = false;
+    if (in_fmt && !res && (bnform || biasform) && cw.taps * (cw.CinP / 32) >= 3 && g_force_tile < 0) {
         long long t256 = 0;
         for (size_t i = 0; i < lv.size(); ++i) t256 += ((long long)B * lv[i].OH * lv[i].OW + 255) / 256;
-        bool use16 = t256 * (cw.CoutPad / 256) >= 2 * 256;
+        bool use16 = t256 * (cw.CoutPad16 / 256) >= 2 * 256;
         if (const char *e = getenv("SSD_IGEMM16")) use16 = atoi(e) != 0;
-        if (use16) tile = IGEMM16_TILE;
+        if (use16) {
+            tile = IGEMM16_TILE;
+            a.CoutPad = cw.CoutPad16;
+            if (cw.wt16w) a.wt = cw.wt16w;
+        }
     }
-    a.n_tiles_n = cw.CoutPad / (tile == IGEMM16_TILE ? 256 : igemm_tile_bn(tile));
+    a.n_tiles_n = a.CoutPad / (tile == IGEMM16_TILE ? 256 : igemm_tile_bn(tile));
     a.dense_out = dense ? 1 : 0;
     int tiles = 0;
     double rows = 0, inb = 0;

@@ -311,9 +311,21 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
     // Batch norm folded to one fused multiply-add per value, y = raw * (2^-s * sf) + (beta - mean * sf): this
     // mode is bounded by a tolerance, not bit-identical to the oracle's three separately rounded operations,
     // and the epilogue of a block that has its CU to itself is pure VALU time (no other block's MFMAs hide it).
+    // Second form (class logits): bias instead of batch norm, fp32 rows at their anchor offset (igemm.hip MODE 4).
     typedef float v2f __attribute__((ext_vector_type(2)));
     v2f ka[4], kb[4];
-    {
+    const bool f32out = a.out_fmt == 0;
+    const bool colok = col < a.Cout;                        // columns of the padded last column tile
+    if (a.bias) {
+        v4f b0v = {0.f, 0.f, 0.f, 0.f}, b1v = {0.f, 0.f, 0.f, 0.f};
+        if (colok) { b0v = *(const v4f *)(a.bias + poff); b1v = *(const v4f *)(a.bias + poff + 4); }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            ka[e] = ka[2 + e] = v2f{a.acc_scale, a.acc_scale};
+            kb[e] = v2f{b0v[2 * e], b0v[2 * e + 1]};
+            kb[2 + e] = v2f{b1v[2 * e], b1v[2 * e + 1]};
+        }
+    } else {
         const v4f m0v = *(const v4f *)(a.mean + poff), m1v = *(const v4f *)(a.mean + poff + 4);
         const v4f s0v = *(const v4f *)(a.sf + poff), s1v = *(const v4f *)(a.sf + poff + 4);
         const v4f b0v = *(const v4f *)(a.beta + poff), b1v = *(const v4f *)(a.beta + poff + 4);
@@ -325,10 +337,12 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
             kb[2 + e] = v2f{b1v[2 * e] - m1v[2 * e] * s1v[2 * e], b1v[2 * e + 1] - m1v[2 * e + 1] * s1v[2 * e + 1]};
         }
     }
+    asm volatile("" : "+v"(ka[0]), "+v"(ka[1]), "+v"(ka[2]), "+v"(ka[3]), "+v"(kb[0]), "+v"(kb[1]), "+v"(kb[2]), "+v"(kb[3]));
     constexpr unsigned OOBS = 0x80000000u;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + L.out_off), 0, (int)OOBS, 0x00020000);
     const __amdgpu_buffer_rsrc_t o2rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.out2 ? a.out2 : a.out) + L.out_off), 0, (int)OOBS, 0x00020000);
-    const int rstride = L.out_rstride;                      // dense output: row m at m * rstride floats
+    const int rstride = L.out_rstride;                      // row (image b, position p) at b * bstride + p * rstride floats
+    const int bstride = (int)L.out_bstride;
     const bool second = a.out2 != nullptr;
     float vmax = 0.0f;                                      // largest magnitude written (fp16 range check)
     auto split8 = [&](const v2f (&v)[4], v4u &hi, v4u &lo) {
@@ -355,6 +369,9 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
                 reg[row * 128 + j * 32 + (lane & 31)] = acc[i][j][r];
             }
         __syncthreads();
+        // rows of this pass: m = mp + 4 * it, i.e. (b, p) advancing by 4 positions with at most one wrap (P >= 4)
+        const int mp = m0 + wave_m * 128 + i * 32 + (lane >> 4);
+        int rb = mp / P, rp = mp - rb * P;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row = it * 4 + (lane >> 4);
@@ -369,10 +386,17 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
                 if (act == 2) y = __builtin_elementwise_min(y, v2f{6.0f, 6.0f});
                 v[e] = y;
             }
-            const int m = m0 + wave_m * 128 + i * 32 + row;
-            const unsigned o = m < M ? (unsigned)(m * rstride + col) * 4u : OOBS;
+            const int m = mp + 4 * it;
+            const unsigned o = (m < M && colok) ? (unsigned)(rb * bstride + rp * rstride + col) * 4u : OOBS;
+            rp += 4;
+            if (rp >= P) { rp -= P; ++rb; }
             v4u hi, lo;
-            split8(v, hi, lo);
+            if (f32out) {
+                hi = __builtin_bit_cast(v4u, v4f{v[0][0], v[0][1], v[1][0], v[1][1]});
+                lo = __builtin_bit_cast(v4u, v4f{v[2][0], v[2][1], v[3][0], v[3][1]});
+            } else {
+                split8(v, hi, lo);
+            }
             __builtin_amdgcn_raw_buffer_store_b128(hi, orsrc, (int)o, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(lo, orsrc, (int)(o == OOBS ? OOBS : o + 16u), 0, 0);
             if (second) {                                   // relu(raw) (fpn p6 -> p7 input)
@@ -423,17 +447,22 @@ static hipError_t launch16_t(const IgemmArgs &a, int total_tiles_m, hipStream_t 
 // Host-side checks of everything the kernel assumes (shapes, formats, 32-bit offsets).
 hipError_t launch_igemm16(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 {
-    if (!a.in_fmt || !a.out_fmt || !a.dense_out) return hipErrorInvalidValue;
-    if (!a.mean || !a.sf || !a.beta || a.bias || a.res) return hipErrorInvalidValue;
-    if (a.Cin % 32 != 0 || a.CoutPad % 256 != 0 || a.Cout != a.CoutPad || (a.taps != 1 && a.taps != 9)) return hipErrorInvalidValue;
+    // two epilogue forms: batch norm -> S16 rows (dense), or bias -> fp32 rows at any row / image stride
+    if (!a.in_fmt || a.res) return hipErrorInvalidValue;
+    const bool bnform = a.mean && a.sf && a.beta && !a.bias && a.out_fmt && a.dense_out && a.Cout == a.CoutPad;
+    const bool biasform = a.bias && !a.mean && !a.sf && !a.beta && !a.out_fmt && !a.out2 && a.act == 0 && a.Cout % 8 == 0 && a.Cout <= a.CoutPad;
+    if (!bnform && !biasform) return hipErrorInvalidValue;
+    if (a.Cin % 32 != 0 || a.CoutPad % 256 != 0 || (a.taps != 1 && a.taps != 9)) return hipErrorInvalidValue;
     if (a.n_tiles_n * 256 != a.CoutPad || a.nlevels < 1 || a.nlevels > SSD_MAX_LEVELS) return hipErrorInvalidValue;
     if (a.taps * (a.Cin / 32) < 3) return hipErrorInvalidValue;      // the software pipeline is three K-steps deep
     if ((long long)a.taps * a.CoutPad * a.Cin * 4 >= (1LL << 31)) return hipErrorInvalidValue;
     for (int i = 0; i < a.nlevels; ++i) {
         const IgemmLevel &L = a.lv[i];
         if ((long long)a.B * L.H * L.W * a.Cin * 4 >= (1LL << 31)) return hipErrorInvalidValue;
-        if (L.out_rstride != a.Cout || L.out_bstride != (long long)L.OH * L.OW * L.out_rstride) return hipErrorInvalidValue;
-        if ((long long)L.M * L.out_rstride * 4 >= (1LL << 31)) return hipErrorInvalidValue;
+        if (bnform && (L.out_rstride != a.Cout || L.out_bstride != (long long)L.OH * L.OW * L.out_rstride)) return hipErrorInvalidValue;
+        if (biasform && ((L.out_rstride | L.out_bstride | L.out_off) & 3)) return hipErrorInvalidValue;      // 16-B stores
+        if ((long long)L.OH * L.OW < 4 || L.out_bstride <= 0) return hipErrorInvalidValue;
+        if ((long long)a.B * L.out_bstride * 4 >= (1LL << 31)) return hipErrorInvalidValue;
     }
     if (a.ts && a.taps == 9) return launch16_t<9, 7>(a, total_tiles_m, s);     // ssd_bench_conv tile 17: phase stamps
     if (const char *e = getenv("SSD_IGEMM16_DBG")) {     // timing experiments (scripts/bench_f16x3.py), 3x3 only
