@@ -281,3 +281,47 @@ def test_detector_f16x3_and_overflow_fallback(cuda, ssd, oracle_graph):
     eng.forward(cuda.from_numpy(img[None].copy()).cuda())
     assert eng.status() == 1 and eng.status() == 0      # read-and-clear
     eng.close()
+
+
+def _same_within_tolerance(a, b, what):
+    """f16x3 engine outputs against the f32 engine's (which other tests pin bit for bit to the oracle):
+    identical num_boxes / labels, scores within TOL; boxes slot by slot, except a few slots where exactly
+    tying candidates were ordered the other way (see compare_outputs)."""
+    ab, al, as_, an = a
+    bb, bl, bs, bn = b
+    assert np.array_equal(an, bn), (what, an, bn)
+    assert np.array_equal(al, bl), what
+    assert np.abs(as_ - bs).max() <= TOL, (what, float(np.abs(as_ - bs).max()))
+    d = np.abs(ab - bb).max(axis=2)
+    bad = int((d > TOL).sum())
+    total = int(bn.sum())
+    print("%s: %d detections, max score diff %.3g, slots with another box %d" % (what, total, float(np.abs(as_ - bs).max()), bad))
+    assert bad <= max(8, total // 500), (what, bad, total)
+
+
+@pytest.mark.parametrize("backbone,B,H,W,env", [
+    ("mobilenet", 40, 256, 384, {}),                       # 40 images: the 256x256-tile kernel carries towers, p3 and logits
+    ("mobilenet", 40, 256, 384, {"SSD_IGEMM16": "0"}),     # the same on the 128x128 kernel's S16 path
+    ("mobilenet", 5, 256, 128, {"SSD_NSUB": "3"}),         # staggered sub-batch plans
+    ("mobilenet", 2, 300, 500, {}),                        # resize_keeping_aspect_ratio path (min_dimension 256)
+    ("mobilenet", 1, 256, 256, {"SSD_GRAPH": "1"}),        # hipGraph replay of the two-stream forward
+    ("shufflenet", 6, 256, 256, {}),
+])
+def test_f16x3_against_f32_engine(cuda, ssd, monkeypatch, backbone, B, H, W, env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    params = {"backbone": backbone, "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
+              "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 256}
+    Wt = ssd.synthetic_weights(params, seed=17, logits_bias=-6.0)
+    img = np.random.default_rng(B + H).integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    e32 = ssd.Engine(params, Wt, precision="f32")
+    ref = [t.cpu().numpy() for t in e32.forward(cuda.from_numpy(img).cuda())]
+    e32.close()
+    e16 = ssd.Engine(params, Wt, precision="f16x3")
+    out = None
+    for rep in range(3 if env.get("SSD_GRAPH") else 1):    # graph capture happens at the second repetition
+        out = [t.cpu().numpy() for t in e16.forward_cached(img)]
+    assert e16.status() == 0
+    assert ref[3].sum() > 0
+    _same_within_tolerance(out, ref, "%s B=%d %dx%d %s" % (backbone, B, H, W, env))
+    e16.close()
