@@ -1095,16 +1095,19 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         push(make_conv_op(h->pconv[2], X5, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 1, {id_l5});
     }
     // x4 = up(x5) + lateral4(c4); p4;  x3 = up(x4) + lateral3(c3); p3
-    // lateral4 / lateral3 read c4 / c3 in fp32 (exact-fp32 MFMA, 1.2 % of the work); the upsampled operand and the
+    // lateral4 / lateral3 read c4 / c3, which stay fp32 rows for the depthwise layer that also consumes them: in
+    // f16x3 mode the rows are split into halves while they are staged (in_fmt 2); the upsampled operand and the
     // output follow the mode
-    const int id_l4 = push(make_conv_op(h->lat[1], C4, X4, nullptr, X5, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true, 0, X16, X16, FL), 0);
+    int LF = X16 && h->lat[1].tile == IGEMM_128x128 && h->lat[0].tile == IGEMM_128x128 ? 2 : 0;
+    if (const char *e = getenv("SSD_LATERAL_SPLIT")) { if (!atoi(e)) LF = 0; }       // A/B runs: 0 keeps them on the exact MFMA
+    const int id_l4 = push(make_conv_op(h->lat[1], C4, X4, nullptr, X5, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true, LF, X16, X16, FL), 0);
     int id_p4, id_p3;
     {
         LevelDesc d = lvl(1, 256);
         d.out_off = py.off[1];
         id_p4 = push(make_conv_op(h->pconv[1], X4, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 1, {id_l4});
     }
-    push(make_conv_op(h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true, 0, X16, X16, FL), 0);
+    push(make_conv_op(h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true, LF, X16, X16, FL), 0);
     {
         LevelDesc d = lvl(0, 256);
         d.out_off = py.off[0];

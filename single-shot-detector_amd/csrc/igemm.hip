@@ -195,10 +195,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
             }
         }
     };
+    // S16 == 2: the A rows in memory are fp32 (a tensor that an fp32 consumer also reads: c3 / c4 under the FPN
+    // laterals); the split into halves happens here, on the way into the S16 LDS image.  A thread's 16 bytes
+    // are 4 channels = half an octet: h into chunk 2o, l into chunk 2o+1, 8 bytes each.
+    const int woff_h = (tid >> 3) * 128 + ((((tid & 6)) ^ ((tid >> 4) & 7)) << 4) + (tid & 1) * 8;
+    const int woff_l = (tid >> 3) * 128 + ((((tid & 6) + 1) ^ ((tid >> 4) & 7)) << 4) + (tid & 1) * 8;
     auto lstore = [&](int stage) {
         unsigned char *base = lds + stage * STAGE;
 #pragma unroll
-        for (int u = 0; u < NA; ++u) *(v4f *)(base + woff + u * (RPP * 128)) = ra[u];
+        for (int u = 0; u < NA; ++u) {
+            if constexpr (S16 == 2) {
+                v4h hh, ll;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = __builtin_fminf(__builtin_fmaxf(ra[u][e], -65504.0f), 65504.0f);
+                    hh[e] = (_Float16)x;
+                    ll[e] = (_Float16)(x - (float)hh[e]);
+                }
+                *(v2u *)(base + woff_h + u * (RPP * 128)) = __builtin_bit_cast(v2u, hh);
+                *(v2u *)(base + woff_l + u * (RPP * 128)) = __builtin_bit_cast(v2u, ll);
+            } else {
+                *(v4f *)(base + woff + u * (RPP * 128)) = ra[u];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < NB; ++u) *(v4f *)(base + A_BYTES + woff + u * (RPP * 128)) = rb[u];
     };
@@ -619,6 +638,11 @@ template <int WAVES_M, int WAVES_N, int WM, int WN, int DBG = 0>
 static hipError_t launch_t(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 {
     if constexpr (DBG == 0) {
+        if (a.in_fmt == 2) {     // fp32 rows split in the loader: the 1x1 convolutions under the FPN laterals
+            if (a.taps != 1) return hipErrorInvalidValue;
+            if constexpr ((WAVES_M == 2 && WAVES_N == 2 && WM == WN) ) return launch_tt<WAVES_M, WAVES_N, WM, WN, 1, 0, 2>(a, total_tiles_m, s);
+            else return hipErrorInvalidValue;
+        }
         if (a.in_fmt)
             return a.taps == 9 ? launch_tt<WAVES_M, WAVES_N, WM, WN, 9, 0, 1>(a, total_tiles_m, s)
                                : launch_tt<WAVES_M, WAVES_N, WM, WN, 1, 0, 1>(a, total_tiles_m, s);

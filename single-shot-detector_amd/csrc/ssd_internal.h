@@ -47,7 +47,8 @@ struct IgemmArgs {
     int n_tiles_n;
     int dense_out;         // 1: out_bstride == OH*OW*out_rstride for every level
     // precision mode f16x3 (igemm.hip, "S16"): formats of the activations this launch touches
-    int in_fmt;            // 1: `in` rows and `wt` rows are split-fp16 (h|l per octet), MFMA f16 x3
+    int in_fmt;            // 1: `in` rows and `wt` rows are split-fp16 (h|l per octet), MFMA f16 x3;
+                           // 2: `wt` rows split-fp16, `in` rows fp32 and split while staged (1x1, 128x128 / 64x64 tiles)
     int out_fmt;           // 1: `out` (and `out2`) rows are written split-fp16
     int res_fmt;           // 1: `res` rows are split-fp16
     float acc_scale;       // in_fmt = 1: 2^-s undoing the power-of-two scale of the packed weights
