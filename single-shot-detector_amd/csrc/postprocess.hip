@@ -181,7 +181,10 @@ __global__ __launch_bounds__(64) void post_nms_small_kernel(const PostArgs p)
     const int lane = threadIdx.x;
     int n = p.counts[bc];
     if (n > p.N) n = p.N;
-    if (n > p.fast_max) return;             // handled by post_nms_big_kernel
+    if (n > p.fast_max) {                   // handled by post_nms_big_kernel: put the pair on its work list
+        if (lane == 0) p.big_list[atomicAdd(p.big_n, 1)] = bc;
+        return;
+    }
     const u64 *keys = p.keys + (long long)bc * p.N;
     const float *dec = p.dec + (long long)b * p.N * 4;
     float *ob = p.cls_boxes + (long long)bc * p.max_per_class * 4;
@@ -230,15 +233,19 @@ __global__ __launch_bounds__(64) void post_nms_small_kernel(const PostArgs p)
 // K9c, longer lists: 1024 threads per (image, class).  Up to 1024*NMS_R candidates live in
 // registers (same scheme, block-wide arg-max through LDS); beyond that the keys stay in
 // global memory and dead candidates are zeroed there.
+// The blocks take their (image, class) pairs from the work list the small kernel filled: most lists are short
+// and never come here, and a block of 1024 threads with 80 KB of LDS that only looks at its count and leaves
+// still costs its launch -- one block per pair made this kernel 0.31 ms of a 32-image step for 64 long lists.
 __global__ __launch_bounds__(NMS_BIG) void post_nms_big_kernel(const PostArgs p)
 {
     __shared__ u64 wbest[2][NMS_BIG / 64];
-    const int bc = blockIdx.x;
-    const int b = bc / p.C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbig = *p.big_n;
+    for (int item = blockIdx.x; item < nbig; item += gridDim.x) {
+    const int bc = p.big_list[item];
+    const int b = bc / p.C;
     int n = p.counts[bc];
     if (n > p.N) n = p.N;
-    if (n <= p.fast_max) return;            // whole block leaves: handled by the small kernel
     u64 *keys = p.keys + (long long)bc * p.N;
     const float *dec = p.dec + (long long)b * p.N * 4;
     float *ob = p.cls_boxes + (long long)bc * p.max_per_class * 4;
@@ -358,6 +365,8 @@ restart:
         goto restart;
     }
     if (tid == 0) p.cls_counts[bc] = kept;
+    __syncthreads();                         // the shared arrays are reused by the next pair
+    }
 }
 
 __global__ __launch_bounds__(256) void post_pack_kernel(const PostArgs p)
@@ -405,6 +414,7 @@ size_t post_workspace_bytes(int B, int N, int C, int mp)
     s += align_up((size_t)B * C * mp * 4 * sizeof(float));
     s += align_up((size_t)B * C * mp * sizeof(float));
     s += align_up((size_t)B * C * sizeof(int));
+    s += align_up(((size_t)B * C + 1) * sizeof(int));      // work list of the long-list NMS kernel, its length first
     return s;
 }
 
@@ -417,7 +427,9 @@ void post_carve(PostArgs &p, void *ws)
     p.dec = (float *)q;         q += align_up(B * N * 4 * sizeof(float));
     p.cls_boxes = (float *)q;   q += align_up(B * C * mp * 4 * sizeof(float));
     p.cls_scores = (float *)q;  q += align_up(B * C * mp * sizeof(float));
-    p.cls_counts = (int *)q;
+    p.cls_counts = (int *)q;    q += align_up(B * C * sizeof(int));
+    p.big_n = (int *)q;
+    p.big_list = (int *)q + 1;
 }
 
 hipError_t launch_postprocess(const PostArgs &pin, hipStream_t s)
@@ -429,12 +441,15 @@ hipError_t launch_postprocess(const PostArgs &pin, hipStream_t s)
     if ((long long)p.B * p.N * p.C >= (1LL << 32)) return hipErrorInvalidValue;   // 32-bit element index in the scan queue
     hipError_t e = hipMemsetAsync(p.counts, 0, (size_t)p.B * p.C * sizeof(int), s);
     if (e != hipSuccess) return e;
+    e = hipMemsetAsync(p.big_n, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
     const long long units = (long long)p.B * p.N * ((p.C & 3) ? p.C : p.C / 4);
     long long blocks = (units + 256 * SCAN_U - 1) / (256 * SCAN_U);
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(post_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
     hipLaunchKernelGGL(post_nms_small_kernel, dim3((unsigned)(p.B * p.C)), dim3(64), 0, s, p);
-    hipLaunchKernelGGL(post_nms_big_kernel, dim3((unsigned)(p.B * p.C)), dim3(NMS_BIG), 0, s, p);
+    const int big_blocks = p.B * p.C < 512 ? p.B * p.C : 512;     // two resident blocks per CU
+    hipLaunchKernelGGL(post_nms_big_kernel, dim3((unsigned)big_blocks), dim3(NMS_BIG), 0, s, p);
     hipLaunchKernelGGL(post_pack_kernel, dim3((unsigned)p.B), dim3(256), (p.C + 1) * sizeof(int), s, p);
     return hipGetLastError();
 }

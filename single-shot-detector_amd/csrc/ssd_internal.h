@@ -121,6 +121,7 @@ struct PostArgs {
     float *cls_boxes;           // [B][C][max][4]
     float *cls_scores;          // [B][C][max]
     int *cls_counts;            // [B][C]
+    int *big_n, *big_list;      // work list of (image, class) pairs whose candidate list is longer than fast_max
 };
 size_t post_workspace_bytes(int B, int N, int C, int max_per_class);
 void post_carve(PostArgs &p, void *ws);
