@@ -61,6 +61,42 @@ __global__ __launch_bounds__(256, IDENT ? 4 : 2) void first_conv_kernel(const ui
         const int oy = (int)(pix % OH);
         const int b = (int)(pix / OH);
         v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (IDENT) {
+            // The 3 pixels x 3 channels under one filter row are 9 contiguous bytes at byte (..*W + 2*ox)*3, i.e.
+            // 0 or 2 bytes past a dword boundary (W is even): three aligned dword loads through a range-checked
+            // buffer resource and a byte alignment replace nine byte loads (the kernel was bound by the rate of
+            // its 27 byte-load instructions per thread, not by HBM).  Bytes past the image edge are masked below.
+            const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, (int)((long long)B * H * W * 3), 0x00020000);
+            const int sh = (ox & 1) * 2;                       // byte offset of the row's first pixel inside its dword
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = 2 * oy + ky;
+                const bool yok = iy < H;
+                const int a0 = (((b * H + (yok ? iy : 0)) * W + 2 * ox) * 3) & ~3;
+                const unsigned w0 = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 0, 0);
+                const unsigned w1 = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0 + 4, 0, 0);
+                const unsigned w2 = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0 + 8, 0, 0);
+                const unsigned d0 = __builtin_amdgcn_alignbyte(w1, w0, sh);
+                const unsigned d1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                const unsigned d2 = w2 >> (8 * sh);
+                const unsigned char px[9] = {(unsigned char)d0, (unsigned char)(d0 >> 8), (unsigned char)(d0 >> 16), (unsigned char)(d0 >> 24),
+                                             (unsigned char)d1, (unsigned char)(d1 >> 8), (unsigned char)(d1 >> 16), (unsigned char)(d1 >> 24),
+                                             (unsigned char)d2};
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const bool ok = yok && 2 * ox + kx < W;
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) {
+                        float x = (float)px[kx * 3 + ci] * inv255;
+                        x = 2.0f * x - 1.0f;
+                        if (!ok) x = 0.0f;
+                        const v4f wv = *(const v4f *)(wl + ((ky * 3 + kx) * 3 + ci) * Cout + c4 * 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] = fmaf(x, wv[i], acc[i]);
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = 2 * oy + ky;
@@ -103,6 +139,7 @@ __global__ __launch_bounds__(256, IDENT ? 4 : 2) void first_conv_kernel(const ui
                 }
             }
         }
+        }
         acc = bn_act4(acc, mean, sf, beta, c4 * 4, act);
         *(v4f *)(out + idx * 4) = acc;
     }
@@ -112,6 +149,7 @@ hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int 
                              const float *w, int Cout, const float *mean, const float *sf, const float *beta, int act,
                              float *out, hipStream_t s)
 {
+    if ((long long)B * srcH * srcW * 3 >= (1LL << 31)) return hipErrorInvalidValue;      // 32-bit byte offsets into the image
     if (Cout % 4 || (H & 1) || (W & 1) || 27 * Cout * 4 > 65536 || nh < 1 || nw < 1 || nh > H || nw > W || srcH < 1 || srcW < 1)
         return hipErrorInvalidValue;
     const float hs = (float)srcH / (float)nh, ws = (float)srcW / (float)nw;
