@@ -211,9 +211,11 @@ struct LevelDesc {
 };
 
 // in_fmt / out_fmt / res_fmt: 0 fp32 rows, 1 split-fp16 rows (ssd_internal.h); flags: the handle's status word
+static float conservative_logit_bound(float thr);
+
 static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2, const float *res, int B, int stride,
                        int pad, int act, const std::vector<LevelDesc> &lv, bool dense, int in_fmt = 0, int out_fmt = 0,
-                       int res_fmt = 0, int *flags = nullptr)
+                       int res_fmt = 0, int *flags = nullptr, unsigned *scan_bits = nullptr, float scan_lo = 0.0f)
 {
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
@@ -257,6 +259,7 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
             tile = IGEMM16_TILE;
             a.CoutPad = cw.CoutPad16;
             if (cw.wt16w) a.wt = cw.wt16w;
+            if (scan_bits && biasform) { a.scan_lo = scan_lo; a.scan_bits = scan_bits; }
         }
     }
     a.n_tiles_n = a.CoutPad / (tile == IGEMM16_TILE ? 256 : igemm_tile_bn(tile));
@@ -1129,6 +1132,23 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     float *logits, *codes;
     SSDCHK(falloc(&logits, (long long)B * N * C));
     SSDCHK(falloc(&codes, (long long)B * N * 4));
+    // ---------------- anchors + post-processing
+    std::vector<float> anc((size_t)N * 4);
+    SSDCHK(ssd_anchors(H, W, anc.data()));
+    float *anc_dev;
+    SSDCHK(ap.upload(&anc_dev, anc));
+    void *ws;
+    const size_t wsb = post_workspace_bytes(B, (int)N, C, h->cfg.max_boxes_per_class);
+    SSDCHK(ap.alloc(&ws, wsb));
+    PostArgs &p = pl.post;
+    memset(&p, 0, sizeof(p));
+    p.logits = logits; p.codes = codes; p.anchors = anc_dev;
+    p.B = B; p.N = (int)N; p.C = C;
+    p.score_thr = h->cfg.score_threshold; p.iou_thr = h->cfg.iou_threshold;
+    p.max_per_class = h->cfg.max_boxes_per_class;
+    for (int k = 0; k < 4; ++k) p.box_scaler[k] = rd.box_scaler[k];    // model.py:67-68
+    post_carve(p, ws);
+    HIPCHK(hipMemset(p.scan_bits, 0, post_scan_bitmap_bytes(B, (int)N, C)));
     std::vector<Op> tower_ops[2];
     for (int t = 0; t < 2; ++t) {
         float *TA, *TB;
@@ -1153,7 +1173,13 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             d.param_off = 0;
             lv.push_back(d);
         }
-        tower_ops[t].push_back(make_conv_op(h->final_[t], in, t == 0 ? codes : logits, nullptr, nullptr, B, 1, 1, SSD_ACT_NONE, lv, false, X16, 0, 0, FL));
+        // class logits: when they run on the 256x256-tile kernel its epilogue also marks the octets that hold a
+        // candidate (p.scan_bits) and post_scan_kernel reads the bitmap instead of all logits
+        const bool can_mark = t == 1 && ((long long)N * C) % 8 == 0 && (6 * C) % 8 == 0;
+        Op fop = make_conv_op(h->final_[t], in, t == 0 ? codes : logits, nullptr, nullptr, B, 1, 1, SSD_ACT_NONE, lv, false, X16, 0, 0, FL,
+                              can_mark ? p.scan_bits : nullptr, conservative_logit_bound(h->cfg.score_threshold));
+        if (t == 1) p.scan_fused = (can_mark && fop.cls == 7) ? 1 : 0;
+        tower_ops[t].push_back(fop);
     }
     // enqueue order interleaved so both hardware queues stay fed.  The first box-tower layer
     // (main) needs p4..p7 from the second stream, the first class-tower layer (second stream)
@@ -1171,22 +1197,6 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     pl.retained["encoded_boxes"] = Retained{codes, B, 1, (int)N, 4, 4, false};
     pl.retained["class_predictions"] = Retained{logits, B, 1, (int)N, C, C, false};
 
-    // ---------------- anchors + post-processing
-    std::vector<float> anc((size_t)N * 4);
-    SSDCHK(ssd_anchors(H, W, anc.data()));
-    float *anc_dev;
-    SSDCHK(ap.upload(&anc_dev, anc));
-    void *ws;
-    const size_t wsb = post_workspace_bytes(B, (int)N, C, h->cfg.max_boxes_per_class);
-    SSDCHK(ap.alloc(&ws, wsb));
-    PostArgs &p = pl.post;
-    memset(&p, 0, sizeof(p));
-    p.logits = logits; p.codes = codes; p.anchors = anc_dev;
-    p.B = B; p.N = (int)N; p.C = C;
-    p.score_thr = h->cfg.score_threshold; p.iou_thr = h->cfg.iou_threshold;
-    p.max_per_class = h->cfg.max_boxes_per_class;
-    for (int k = 0; k < 4; ++k) p.box_scaler[k] = rd.box_scaler[k];    // model.py:67-68
-    post_carve(p, ws);
     return SSD_OK;
 }
 

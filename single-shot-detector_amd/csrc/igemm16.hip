@@ -394,6 +394,17 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
             if (f32out) {
                 hi = __builtin_bit_cast(v4u, v4f{v[0][0], v[0][1], v[1][0], v[1][1]});
                 lo = __builtin_bit_cast(v4u, v4f{v[2][0], v[2][1], v[3][0], v[3][1]});
+                if (a.scan_bits && o != OOBS) {
+                    // first half of the post-processing's score filter, here where the logits are in registers: mark
+                    // the octets that hold a value at or above the conservative logit bound (rare), so the scan reads
+                    // a bitmap and those octets instead of every logit.  (Fire-and-forget atomic: nothing to wait for.)
+                    const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0][0], v[0][1]), __builtin_fmaxf(v[1][0], v[1][1])),
+                                                     __builtin_fmaxf(__builtin_fmaxf(v[2][0], v[2][1]), __builtin_fmaxf(v[3][0], v[3][1])));
+                    if (mx >= a.scan_lo) {
+                        const unsigned oct = ((unsigned)L.out_off + (o >> 2)) >> 3;      // octet index in [B][N][C]
+                        atomicOr(a.scan_bits + (oct >> 5), 1u << (oct & 31));
+                    }
+                }
             } else {
                 split8(v, hi, lo);
             }

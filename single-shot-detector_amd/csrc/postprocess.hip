@@ -120,6 +120,30 @@ __global__ __launch_bounds__(256) void post_scan_kernel(const PostArgs p)
         q_elem[slot] = elem;
         q_val[slot] = v;
     };
+    if (p.scan_fused) {
+        // The logits convolution marked the octets that hold a candidate (igemm16.hip): read the bitmap (B*N*C/64
+        // bytes) and the marked octets only.  Same filter, same emit_candidate: the per-class lists hold the same set.
+        const long long nwords = ((long long)p.B * p.N * C / 8 + 31) / 32;
+        for (long long w0 = (long long)blockIdx.x * 256; w0 < nwords; w0 += (long long)gridDim.x * 256) {
+            const long long w = w0 + threadIdx.x;
+            unsigned bits = w < nwords ? p.scan_bits[w] : 0u;
+            while (bits) {
+                const int k = __builtin_ctz(bits);
+                bits &= bits - 1;
+                const long long e0 = (w * 32 + k) * 8;
+                const v4f x0 = *(const v4f *)(p.logits + e0), x1 = *(const v4f *)(p.logits + e0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (x0[j] >= p.logit_lo) push((unsigned)(e0 + j), x0[j]);
+                    if (x1[j] >= p.logit_lo) push((unsigned)(e0 + 4 + j), x1[j]);
+                }
+            }
+            __syncthreads();
+            if (q_n > 2048) drain();
+        }
+        drain();
+        return;
+    }
     const long long stride = (long long)gridDim.x * 256 * SCAN_U;
     for (long long base = (long long)blockIdx.x * 256 * SCAN_U; base < total; base += stride) {
         if (vec) {
@@ -404,6 +428,7 @@ __global__ __launch_bounds__(256) void post_pack_kernel(const PostArgs p)
 }
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+size_t post_scan_bitmap_bytes(int B, int N, int C) { return (((size_t)B * N * C / 8 + 31) / 32) * 4 + 4; }
 
 size_t post_workspace_bytes(int B, int N, int C, int mp)
 {
@@ -415,6 +440,7 @@ size_t post_workspace_bytes(int B, int N, int C, int mp)
     s += align_up((size_t)B * C * mp * sizeof(float));
     s += align_up((size_t)B * C * sizeof(int));
     s += align_up(((size_t)B * C + 1) * sizeof(int));      // work list of the long-list NMS kernel, its length first
+    s += align_up(post_scan_bitmap_bytes(B, N, C));        // candidate-octet bitmap of the fused scan
     return s;
 }
 
@@ -429,7 +455,8 @@ void post_carve(PostArgs &p, void *ws)
     p.cls_scores = (float *)q;  q += align_up(B * C * mp * sizeof(float));
     p.cls_counts = (int *)q;    q += align_up(B * C * sizeof(int));
     p.big_n = (int *)q;
-    p.big_list = (int *)q + 1;
+    p.big_list = (int *)q + 1;  q += align_up((B * C + 1) * sizeof(int));
+    p.scan_bits = (unsigned *)q;
 }
 
 hipError_t launch_postprocess(const PostArgs &pin, hipStream_t s)
@@ -451,5 +478,9 @@ hipError_t launch_postprocess(const PostArgs &pin, hipStream_t s)
     const int big_blocks = p.B * p.C < 512 ? p.B * p.C : 512;     // two resident blocks per CU
     hipLaunchKernelGGL(post_nms_big_kernel, dim3((unsigned)big_blocks), dim3(NMS_BIG), 0, s, p);
     hipLaunchKernelGGL(post_pack_kernel, dim3((unsigned)p.B), dim3(256), (p.C + 1) * sizeof(int), s, p);
+    if (p.scan_fused) {          // clean bitmap for the next forward's logits convolution (ordered behind this stream)
+        e = hipMemsetAsync(p.scan_bits, 0, post_scan_bitmap_bytes(p.B, p.N, p.C), s);
+        if (e != hipSuccess) return e;
+    }
     return hipGetLastError();
 }

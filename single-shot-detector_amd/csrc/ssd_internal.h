@@ -53,6 +53,10 @@ struct IgemmArgs {
     int res_fmt;           // 1: `res` rows are split-fp16
     float acc_scale;       // in_fmt = 1: 2^-s undoing the power-of-two scale of the packed weights
     int *flags;            // nullable: bit 0 set when an S16 output had to be clamped to the fp16 range
+    // igemm16 bias form (class logits): the first half of the post-processing's threshold scan, fused into the
+    // epilogue -- one bit per octet of 8 consecutive logits that holds a value >= scan_lo (postprocess.hip); nullable
+    float scan_lo;
+    unsigned *scan_bits;
     long long *ts;         // diagnostics (ssd_bench_conv tile 17): per-block phase timestamps, else null
     IgemmLevel lv[SSD_MAX_LEVELS];
 };
@@ -122,7 +126,13 @@ struct PostArgs {
     float *cls_scores;          // [B][C][max]
     int *cls_counts;            // [B][C]
     int *big_n, *big_list;      // work list of (image, class) pairs whose candidate list is longer than fast_max
+    // scan_fused: the logits convolution's epilogue (igemm16.hip) has marked in scan_bits (one bit per 8 consecutive
+    // elements of [B][N][C]) every octet that holds a logit >= logit_lo; post_scan_kernel then reads the bitmap and
+    // the marked octets instead of all logits.  The bitmap is cleared again at the end of the post-processing.
+    unsigned *scan_bits;
+    int scan_fused;
 };
 size_t post_workspace_bytes(int B, int N, int C, int max_per_class);
+size_t post_scan_bitmap_bytes(int B, int N, int C);
 void post_carve(PostArgs &p, void *ws);
 hipError_t launch_postprocess(const PostArgs &p, hipStream_t s);
