@@ -473,6 +473,11 @@ hipError_t launch_postprocess(const PostArgs &pin, hipStream_t s)
     const long long units = (long long)p.B * p.N * ((p.C & 3) ? p.C : p.C / 4);
     long long blocks = (units + 256 * SCAN_U - 1) / (256 * SCAN_U);
     if (blocks > 256 * 32) blocks = 256 * 32;
+    if (p.scan_fused) {          // bitmap walk: one resident round of blocks (48 KB of LDS each: three per CU)
+        const long long nwords = ((long long)p.B * p.N * p.C / 8 + 31) / 32;
+        blocks = (nwords + 255) / 256;
+        if (blocks > 768) blocks = 768;
+    }
     hipLaunchKernelGGL(post_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
     hipLaunchKernelGGL(post_nms_small_kernel, dim3((unsigned)(p.B * p.C)), dim3(64), 0, s, p);
     const int big_blocks = p.B * p.C < 512 ? p.B * p.C : 512;     // two resident blocks per CU
