@@ -325,3 +325,25 @@ def test_f16x3_against_f32_engine(cuda, ssd, monkeypatch, backbone, B, H, W, env
     assert ref[3].sum() > 0
     _same_within_tolerance(out, ref, "%s B=%d %dx%d %s" % (backbone, B, H, W, env))
     e16.close()
+
+
+def test_igemm16_repeatable(cuda, ssd, monkeypatch):
+    """Race screen for the LDS-DMA pipeline of igemm16.hip (the DMA of a stage is ordered for its readers only
+    by the issuing wave's vmcnt wait plus a barrier): the same launch repeated must give the same bits, on a
+    shape with many 256-row tiles per CU so that blocks start and finish at different phases."""
+    monkeypatch.setenv("SSD_IGEMM16", "1")
+    rng = np.random.default_rng(77)
+    x = dev(cuda, rng.standard_normal((24, 40, 56, 256)).astype(np.float32))
+    w = (rng.standard_normal((3, 3, 256, 256)) * np.sqrt(2.0 / 2304)).astype(np.float32)
+    g, b, m, v = bn_params(rng, 256)
+    bn = (m, g / np.sqrt(v + 1e-3), b)
+    first = ssd.ssd.conv2d(x, w, 1, "SAME", bn=bn, act="relu", precision="f16x3")
+    for _ in range(25):
+        again = ssd.ssd.conv2d(x, w, 1, "SAME", bn=bn, act="relu", precision="f16x3")
+        assert cuda.equal(first, again)
+    # and the class-logits form (bias, fp32 rows, 480 of 512 columns)
+    wl = (rng.standard_normal((3, 3, 256, 480)) * np.sqrt(2.0 / 2304)).astype(np.float32)
+    bias = rng.standard_normal(480).astype(np.float32)
+    first = ssd.ssd.conv2d(x, wl, 1, "SAME", bias=bias, precision="f16x3")
+    for _ in range(10):
+        assert cuda.equal(first, ssd.ssd.conv2d(x, wl, 1, "SAME", bias=bias, precision="f16x3"))
