@@ -25,6 +25,9 @@ names = ["prologue (offsets, first stage landed)", "K loop", "epilogue until las
 d = np.diff(st, axis=1)
 for i, n in enumerate(names):
     print("   %-42s mean %8.2f us  p10 %8.2f  p50 %8.2f  p90 %8.2f" % (n, d[:, i].mean(), *np.percentile(d[:, i], [10, 50, 90])))
+ep = t[:, 5:8].astype(np.float64) * 0.01
+print("   inside the epilogue, from the end of the K loop: parameters arrived +%.2f us, first transpose in LDS +%.2f us, first of 4 passes stored +%.2f us"
+      % tuple((ep[:, i] - st[:, 2]).mean() for i in range(3)))
 life = st[:, 4] - st[:, 0]
 print("   %-42s mean %8.2f us  p10 %8.2f  p50 %8.2f  p90 %8.2f" % ("block lifetime", life.mean(), *np.percentile(life, [10, 50, 90])))
 print("   sum of lifetimes / span = %.1f blocks resident on average (256 CUs)" % (life.sum() / span))

@@ -35,7 +35,7 @@ template <int TAPS, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
 {
     constexpr int ABL = DBG == 7 ? 0 : DBG;   // ablation level (4: see below)
-    long long stamp[5] = {0, 0, 0, 0, 0};     // DBG 7 (results right): 100 MHz wall-clock stamps of thread 0
+    long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // DBG 7 (results right): 100 MHz wall-clock stamps of thread 0
     auto mark = [&](int i) {
         if constexpr (DBG == 7) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[i] = wall_clock64(); }
     };
@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
         }
     }
     asm volatile("" : "+v"(ka[0]), "+v"(ka[1]), "+v"(ka[2]), "+v"(ka[3]), "+v"(kb[0]), "+v"(kb[1]), "+v"(kb[2]), "+v"(kb[3]));
+    mark(5);                                                // parameters arrived
     constexpr unsigned OOBS = 0x80000000u;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + L.out_off), 0, (int)OOBS, 0x00020000);
     const __amdgpu_buffer_rsrc_t o2rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.out2 ? a.out2 : a.out) + L.out_off), 0, (int)OOBS, 0x00020000);
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
         hi = __builtin_bit_cast(v4u, h);
         lo = __builtin_bit_cast(v4u, l);
     };
-    const int act = a.act;
+    const float act_lo = a.act >= 1 ? 0.0f : -INFINITY, act_hi = a.act == 2 ? 6.0f : INFINITY;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
                 reg[row * 128 + j * 32 + (lane & 31)] = acc[i][j][r];
             }
         __syncthreads();
+        if (i == 0) mark(6);                                // first transpose in LDS
         // rows of this pass: m = mp + 4 * it, i.e. (b, p) advancing by 4 positions with at most one wrap (P >= 4)
         const int mp = m0 + wave_m * 128 + i * 32 + (lane >> 4);
         int rb = mp / P, rp = mp - rb * P;
@@ -382,8 +384,8 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 v2f y = __builtin_elementwise_fma(raw[e], ka[e], kb[e]);
-                if (act >= 1) y = __builtin_elementwise_max(y, v2f{0.0f, 0.0f});
-                if (act == 2) y = __builtin_elementwise_min(y, v2f{6.0f, 6.0f});
+                y = __builtin_elementwise_max(y, v2f{act_lo, act_lo});       // activation as two clamps with uniform
+                y = __builtin_elementwise_min(y, v2f{act_hi, act_hi});       // bounds: no per-value selects
                 v[e] = y;
             }
             const int m = mp + 4 * it;
@@ -420,6 +422,7 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
             }
         }
         __syncthreads();
+        if (i == 0) mark(7);                                // first pass stored
     }
     const bool ovf = !(vmax <= 65504.0f);                   // out of the fp16 range (or NaN): h = inf, rows invalid
     if (ovf && a.flags) atomicOr(a.flags, 1);
@@ -431,8 +434,7 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             long long *t = a.ts + (long long)blockIdx.x * 9;
-            for (int i = 0; i < 5; ++i) t[i] = stamp[i];
-            t[5] = t[6] = t[7] = 0;
+            for (int i = 0; i < 8; ++i) t[i] = stamp[i];
             t[8] = ((long long)xcc << 32) | hw;
         }
     }
