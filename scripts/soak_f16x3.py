@@ -1,0 +1,25 @@
+"""Race screen at full size: N forwards of the bench workload (32 frames of 640x896, precision f16x3, two
+streams, 256x256-tile kernel with LDS-DMA staging and the fused candidate bitmap) on the same input must all
+give the same bits as the first.  usage: python scripts/soak_f16x3.py [N]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import ssd_amd
+import bench
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+Wt = ssd_amd.synthetic_weights(bench.PARAMS, seed=0, logits_bias=bench.LOGITS_BIAS)
+eng = ssd_amd.Engine(bench.PARAMS, Wt, precision="f16x3")
+g = torch.Generator().manual_seed(1234)
+frames = torch.randint(0, 256, (32, bench.H, bench.W, 3), dtype=torch.uint8, generator=g).cuda()
+first = [t.clone() for t in eng.forward(frames)]
+bad = 0
+for i in range(N):
+    out = eng.forward(frames)
+    if not all(torch.equal(a, b) for a, b in zip(first, out)):
+        bad += 1
+        print("forward %d differs from the first" % i, flush=True)
+torch.cuda.synchronize()
+print("%d forwards, %d different from the first; status %d; detections per image %.1f"
+      % (N, bad, eng.status(), float(first[3].float().mean())))
+sys.exit(1 if bad else 0)

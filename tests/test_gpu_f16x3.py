@@ -347,3 +347,22 @@ def test_igemm16_repeatable(cuda, ssd, monkeypatch):
     first = ssd.ssd.conv2d(x, wl, 1, "SAME", bias=bias, precision="f16x3")
     for _ in range(10):
         assert cuda.equal(first, ssd.ssd.conv2d(x, wl, 1, "SAME", bias=bias, precision="f16x3"))
+
+
+@pytest.mark.parametrize("backbone,dm,classes,H,W", [("mobilenet", 0.5, 20, 128, 256), ("mobilenet", 0.75, 3, 256, 128),
+                                                     ("shufflenet", 0.5, 20, 128, 128), ("shufflenet", 1.5, 80, 128, 256)])
+def test_f16x3_other_widths_and_class_counts(cuda, ssd, backbone, dm, classes, H, W):
+    """depth_multiplier / num_classes variants in mode f16x3: padded channel counts (24 -> 32, 88 -> 96 ...), head
+    widths 18 / 120 / 480 (rows that are not 16-byte aligned take the per-element store path) against the f32 engine."""
+    params = {"backbone": backbone, "depth_multiplier": dm, "num_classes": classes, "score_threshold": 0.15,
+              "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
+    Wt = ssd.synthetic_weights(params, seed=21, logits_bias=-4.0)
+    img = np.random.default_rng(7).integers(0, 256, (3, H, W, 3), dtype=np.uint8)
+    e32 = ssd.Engine(params, Wt, precision="f32")
+    ref = [t.cpu().numpy() for t in e32.forward(cuda.from_numpy(img).cuda())]
+    e32.close()
+    e16 = ssd.Engine(params, Wt, precision="f16x3")
+    out = [t.cpu().numpy() for t in e16.forward(cuda.from_numpy(img).cuda())]
+    assert e16.status() == 0 and out[0].shape == (3, classes * 25, 4)
+    _same_within_tolerance(out, ref, "%s x%.2f C=%d" % (backbone, dm, classes))
+    e16.close()
