@@ -304,6 +304,7 @@ struct Plan {
     std::map<std::string, Retained> retained;
     hipStream_t s_main = nullptr;       // null: the caller's stream (sub-batch 0)
     hipStream_t s_aux = nullptr;        // class tower beside the box tower (box_predictor.py:47-59)
+    hipStream_t s_bb[2] = {nullptr, nullptr};   // further backbone chains (Op::stream 2, 3)
     hipEvent_t ev_fpn = nullptr, ev_join = nullptr, ev_done = nullptr, ev_begin = nullptr;
     int last_aux = -1;                  // index of the last op on the second stream
 };
@@ -361,6 +362,7 @@ static void free_plans(ssd_handle *h)
         pl->pool.free_all();
         if (pl->s_main) (void)hipStreamDestroy(pl->s_main);
         if (pl->s_aux) (void)hipStreamDestroy(pl->s_aux);
+        for (int i = 0; i < 2; ++i) if (pl->s_bb[i]) (void)hipStreamDestroy(pl->s_bb[i]);
         if (pl->ev_fpn) (void)hipEventDestroy(pl->ev_fpn);
         if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
         if (pl->ev_done) (void)hipEventDestroy(pl->ev_done);
@@ -903,7 +905,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     // ---------------- backbone
     float *C3 = nullptr, *C4 = nullptr, *C5 = nullptr;
     const int h2 = H / 2, w2 = W / 2;
-    int id_bb_last[2] = {-1, -1};     // last backbone op of each half (MobileNet split), -1: no such half
+    int id_bb_last[4] = {-1, -1, -1, -1};     // last backbone op of each chain (MobileNet split), -1: no such chain
     if (h->cfg.backbone == SSD_BACKBONE_MOBILENET) {
         // The backbone is a chain of ~30 short, latency-bound kernels (two blocks per CU each waiting for one
         // round of loads).  From 4 images on it runs as two half-batch chains on the plan's two streams, so that
@@ -911,7 +913,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         // Measured (f16x3, same box): +2.1 % at 32 images, +3.8 % at 16, +3.2 % at 8, +4.5 % at 4; mode f32 +0.3 %.
         // SSD_BACKBONE_SPLIT=1 keeps one chain.
         int nhalf = B >= 4 ? 2 : 1;
-        if (const char *e = getenv("SSD_BACKBONE_SPLIT")) { if (atoi(e) == 1) nhalf = 1; }
+        if (const char *e = getenv("SSD_BACKBONE_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4 && v <= B) nhalf = v; }
         // retained outputs c3 / c4 / c5: full-batch tensors, each half writes its images
         {
             int hh = h2, ww = w2;
@@ -929,9 +931,9 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         // depthwise -> pointwise pairs that run as one launch (bit i = Conv2d_{i+1}); SSD_FUSE_DW overrides
         unsigned fuse_mask = SSD_FUSE_DW_DEFAULT;
         if (const char *e = getenv("SSD_FUSE_DW")) fuse_mask = (unsigned)strtoul(e, nullptr, 0);
-        std::vector<Op> half_ops[2];
+        std::vector<Op> half_ops[4];
         for (int hf = 0; hf < nhalf; ++hf) {
-            const int b0 = hf == 0 ? 0 : B / 2, nb = nhalf == 1 ? B : (hf == 0 ? B / 2 : B - B / 2);
+            const int b0 = (int)((long long)B * hf / nhalf), nb = (int)((long long)B * (hf + 1) / nhalf) - b0;
             std::vector<Op> &ops = half_ops[hf];
             long long maxf = (long long)nb * h2 * w2 * h->firstCp;
             {
@@ -989,7 +991,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             }
         }
         // enqueue order interleaved so that both queues are fed
-        for (size_t i = 0; i < half_ops[0].size() || i < half_ops[1].size(); ++i)
+        for (size_t i = 0; i < half_ops[0].size(); ++i)
             for (int hf = 0; hf < nhalf; ++hf)
                 if (i < half_ops[hf].size()) {
                     Op op = half_ops[hf][i];
@@ -1120,12 +1122,14 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     // second stream: the main stream's first FPN op waits for it
     const int id_c5 = id_bb_last[0] >= 0 ? id_bb_last[0] : (int)pl.ops.size() - 1;
     std::vector<int> l5_deps;
-    if (id_bb_last[1] >= 0) l5_deps.push_back(id_bb_last[1]);
+    for (int c = 1; c < 4; ++c) if (id_bb_last[c] >= 0) l5_deps.push_back(id_bb_last[c]);
     const int id_l5 = push(make_conv_op(h->lat[2], C5, X5, nullptr, nullptr, B, 1, 0, SSD_ACT_NONE, {lvl(2, 256)}, true, X16, X16, 0, FL), 0, l5_deps);
+    std::vector<int> p6_deps = {id_c5};             // c5 of every backbone chain that is not on p6's own stream
+    for (int c = 2; c < 4; ++c) if (id_bb_last[c] >= 0) p6_deps.push_back(id_bb_last[c]);
     {   // p6 = conv s2 (c5): BN+ReLU -> P6, ReLU(raw) -> T6 (input of p7, :60)
         LevelDesc d = dense_level(py.h[2], py.w[2], py.h[3], py.w[3], 256);
         d.out_off = py.off[3];
-        push(make_conv_op(h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 1, {id_c5});
+        push(make_conv_op(h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 1, p6_deps);
         LevelDesc d7 = dense_level(py.h[3], py.w[3], py.h[4], py.w[4], 256);
         d7.out_off = py.off[4];
         push(make_conv_op(h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true, X16, X16, 0, FL), 1);
@@ -1293,6 +1297,7 @@ static int make_plans(ssd_handle *h, int B, int H, int W)
         h->plans.push_back(pl);
         if (k > 0) HIPCHK(hipStreamCreateWithFlags(&pl->s_main, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&pl->s_aux, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&pl->s_bb[i], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&pl->ev_fpn, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&pl->ev_done, hipEventDisableTiming));
@@ -1328,11 +1333,12 @@ static int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxe
             HIPCHK(hipStreamWaitEvent(sm, h->plans[k - 1]->ev_fpn, 0));
         }
         HIPCHK(hipEventRecord(pl.ev_begin, sm));
-        bool aux_used = false;
+        bool aux_used = false, started[4] = {true, false, false, false};
         for (const Op &op : pl.ops) {
-            hipStream_t st = op.stream == 1 ? pl.s_aux : sm;
-            if (op.stream == 1 && !aux_used && op.deps.empty())     // a chain that starts on the second stream:
-                HIPCHK(hipStreamWaitEvent(st, pl.ev_begin, 0));                        // behind the plan's own start
+            hipStream_t st = op.stream == 0 ? sm : (op.stream == 1 ? pl.s_aux : pl.s_bb[op.stream - 2]);
+            if (!started[op.stream] && op.deps.empty())             // a chain that starts on another stream:
+                HIPCHK(hipStreamWaitEvent(st, pl.ev_begin, 0));     // behind the plan's own start
+            started[op.stream] = true;
             for (int d : op.deps) HIPCHK(hipStreamWaitEvent(st, pl.ops[d].done, 0));
             HIPCHK(run_op(h, op, st));
             if (op.done) HIPCHK(hipEventRecord(op.done, st));
