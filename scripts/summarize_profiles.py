@@ -60,7 +60,7 @@ def union_ms(intervals):
     return tot / 1e6
 
 
-nfwd = max(1, sum(len(v) for k, v in iv.items() if "first_conv" in k))
+nfwd = max(1, sum(len(v) for k, v in iv.items() if "post_pack" in k))      # one per forward (the backbone may run as two chains)
 c3 = [x for k, v in iv.items() if ("igemm_kernel" in k and ", 9, 0" in k) or "igemm16_kernel<9" in k for x in v]
 class_line = ("all 3x3 igemm kernels (bench.py class conv3x3_mfma): %d launches in %d forwards, union %.3f ms per forward"
               " = %.4f ms per launch\n" % (len(c3), nfwd, union_ms(c3) / nfwd, union_ms(c3) / max(len(c3), 1)))
