@@ -1252,6 +1252,16 @@ static float conservative_logit_bound(float thr)
 
 static hipError_t run_op(ssd_handle *h, const Op &op, hipStream_t s)
 {
+    static const int dbg_sync = getenv("SSD_DEBUG_SYNC") ? atoi(getenv("SSD_DEBUG_SYNC")) : 0;
+    if (dbg_sync) {      // fault localisation: announce every op, run it alone, wait for it
+        fprintf(stderr, "[ssd] op class %d stream %d flops %.3g bytes %.3g ...", op.cls, op.stream, op.flops, op.bytes);
+        fflush(stderr);
+        (void)hipDeviceSynchronize();
+        hipError_t r = op.run(s);
+        hipError_t r2 = hipDeviceSynchronize();
+        fprintf(stderr, " %s\n", r == hipSuccess && r2 == hipSuccess ? "ok" : "FAILED");
+        return r != hipSuccess ? r : r2;
+    }
     if (!h->profiling) return op.run(s);
     EvPair e;
     e.cls = op.cls;

@@ -127,19 +127,23 @@ __global__ __launch_bounds__(256) void post_scan_kernel(const PostArgs p)
         for (long long w0 = (long long)blockIdx.x * 256; w0 < nwords; w0 += (long long)gridDim.x * 256) {
             const long long w = w0 + threadIdx.x;
             unsigned bits = w < nwords ? p.scan_bits[w] : 0u;
-            while (bits) {
-                const int k = __builtin_ctz(bits);
-                bits &= bits - 1;
-                const long long e0 = (w * 32 + k) * 8;
-                const v4f x0 = *(const v4f *)(p.logits + e0), x1 = *(const v4f *)(p.logits + e0 + 4);
+            // one marked octet per thread and round: at most 256 * 8 pushes between two looks at the queue
+            // (capacity 2048 + 4096), however dense the marks are (saturated logits mark every octet)
+            while (__syncthreads_or(bits != 0)) {
+                if (bits) {
+                    const int k = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    const long long e0 = (w * 32 + k) * 8;
+                    const v4f x0 = *(const v4f *)(p.logits + e0), x1 = *(const v4f *)(p.logits + e0 + 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (x0[j] >= p.logit_lo) push((unsigned)(e0 + j), x0[j]);
-                    if (x1[j] >= p.logit_lo) push((unsigned)(e0 + 4 + j), x1[j]);
+                    for (int j = 0; j < 4; ++j) {
+                        if (x0[j] >= p.logit_lo) push((unsigned)(e0 + j), x0[j]);
+                        if (x1[j] >= p.logit_lo) push((unsigned)(e0 + 4 + j), x1[j]);
+                    }
                 }
+                __syncthreads();
+                if (q_n > 2048) drain();
             }
-            __syncthreads();
-            if (q_n > 2048) drain();
         }
         drain();
         return;

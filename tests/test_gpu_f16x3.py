@@ -366,3 +366,21 @@ def test_f16x3_other_widths_and_class_counts(cuda, ssd, backbone, dm, classes, H
     assert e16.status() == 0 and out[0].shape == (3, classes * 25, 4)
     _same_within_tolerance(out, ref, "%s x%.2f C=%d" % (backbone, dm, classes))
     e16.close()
+
+
+def test_f16x3_dense_candidates(cuda, ssd):
+    """Every logit above the threshold (bias +1): the candidate-octet bitmap of the fused score filter is all ones,
+    the scan's LDS queue must be drained between rounds, and every (image, class) list is longer than the register
+    capacity of the NMS kernels.  Against the f32 engine (whose scan reads the logits themselves)."""
+    params = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
+              "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 256}
+    Wt = ssd.synthetic_weights(params, seed=23, logits_bias=1.0)
+    img = np.random.default_rng(40).integers(0, 256, (40, 256, 384, 3), dtype=np.uint8)
+    e32 = ssd.Engine(params, Wt, precision="f32")
+    ref = [t.cpu().numpy() for t in e32.forward(cuda.from_numpy(img).cuda())]
+    e32.close()
+    e16 = ssd.Engine(params, Wt, precision="f16x3")
+    out = [t.cpu().numpy() for t in e16.forward(cuda.from_numpy(img).cuda())]
+    assert e16.status() == 0 and (ref[3] == 2000).all()
+    _same_within_tolerance(out, ref, "dense candidates")
+    e16.close()
