@@ -384,3 +384,20 @@ def test_f16x3_dense_candidates(cuda, ssd):
     assert e16.status() == 0 and (ref[3] == 2000).all()
     _same_within_tolerance(out, ref, "dense candidates")
     e16.close()
+
+
+def test_f16x3_batch_independence_full_size(cuda, ssd):
+    """Images are independent end to end (nms.py:96-101), and an output element's arithmetic does not depend on which
+    tile computes it: the first 32 images of a 70-image batch (two sub-batch plans: the 2 GiB rule) and of a 33-image
+    batch give the bits of the 32-image batch, at the bench's size, in mode f16x3."""
+    import bench
+    Wt = ssd.synthetic_weights(bench.PARAMS, seed=0, logits_bias=bench.LOGITS_BIAS)
+    eng = ssd.Engine(bench.PARAMS, Wt, precision="f16x3")
+    g = cuda.Generator().manual_seed(7)
+    frames = cuda.randint(0, 256, (70, bench.H, bench.W, 3), dtype=cuda.uint8, generator=g).cuda()
+    ref = [t.clone() for t in eng.forward(frames[:32].contiguous())]
+    for B in (70, 33):
+        out = eng.forward(frames[:B].contiguous())
+        assert all(cuda.equal(a[:32], b) for a, b in zip(out, ref)), B
+    assert eng.status() == 0 and float(ref[3].float().mean()) > 50
+    eng.close()
