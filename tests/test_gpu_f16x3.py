@@ -401,3 +401,15 @@ def test_f16x3_batch_independence_full_size(cuda, ssd):
         assert all(cuda.equal(a[:32], b) for a, b in zip(out, ref)), B
     assert eng.status() == 0 and float(ref[3].float().mean()) > 50
     eng.close()
+
+
+def test_igemm16_overflow_is_reported(cuda, ssd, monkeypatch):
+    """The 256x256-tile kernel's own range check (a running maximum instead of per-value clamps)."""
+    monkeypatch.setenv("SSD_IGEMM16", "1")
+    x = cuda.full((1, 8, 8, 256), 100.0, dtype=cuda.float32, device="cuda")
+    w = np.full((1, 1, 256, 256), 1.0, np.float32)                    # sums of 25 600
+    ones, zeros = np.ones(256, np.float32), np.zeros(256, np.float32)
+    ok = ssd.ssd.conv2d(x, w, 1, "SAME", bn=(zeros, ones, zeros), act="relu", precision="f16x3")
+    assert float(ok.max()) == 25600.0
+    with pytest.raises(ssd.SsdError, match="fp16 range"):
+        ssd.ssd.conv2d(x, w, 1, "SAME", bn=(zeros, ones * 3.0, zeros), act="relu", precision="f16x3")   # 76 800
