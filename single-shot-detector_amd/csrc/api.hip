@@ -1400,10 +1400,11 @@ extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, 
     // hipGraph replay (launch-bound regime: batch 1 is ~35 short kernels on two streams).  A
     // forward whose pointers, shape and stream repeat is captured on the handle's own stream at
     // its second occurrence and replayed from then on; profiling or SSD_GRAPH=0 keep it eager.
-    static int use_graph = -1;
+    int use_graph = -1;      // read per call (a getenv): tests switch it inside one process
     // Measured (batch 1, 640x896): replay 2.49 ms vs eager 2.33 ms p50 -- the forward is GPU-bound
     // (host enqueue 0.9 ms < 2.3 ms of kernels), so replay is OFF unless SSD_GRAPH=1.
-    if (use_graph < 0) { const char *e = getenv("SSD_GRAPH"); use_graph = e ? atoi(e) : 0; }
+    static bool capture_broken = false;      // a failed capture is not retried
+    if (use_graph < 0) { const char *e = getenv("SSD_GRAPH"); use_graph = e && !capture_broken ? atoi(e) : 0; }
     if (!use_graph || h->profiling || h->plans.size() != 1)
         return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, s);
     GraphKey key{images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, B, H, W};
@@ -1422,7 +1423,7 @@ extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, 
         if (rc != SSD_OK || ce != hipSuccess || !graph) {
             if (graph) (void)hipGraphDestroy(graph);
             (void)hipGetLastError();
-            use_graph = 0;                       // capture unsupported here: stay eager from now on
+            capture_broken = true;               // capture unsupported here: stay eager from now on
             return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, s);
         }
         HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));

@@ -305,6 +305,8 @@ def _same_within_tolerance(a, b, what):
     ("mobilenet", 5, 256, 128, {"SSD_NSUB": "3"}),         # staggered sub-batch plans
     ("mobilenet", 2, 300, 500, {}),                        # resize_keeping_aspect_ratio path (min_dimension 256)
     ("mobilenet", 1, 256, 256, {"SSD_GRAPH": "1"}),        # hipGraph replay of the two-stream forward
+    ("mobilenet", 8, 256, 256, {"SSD_GRAPH": "1"}),        # ... with the backbone as two chains and the memsets captured
+    ("mobilenet", 8, 256, 256, {"SSD_BACKBONE_SPLIT": "4"}),   # four backbone chains on four streams
     ("shufflenet", 6, 256, 256, {}),
 ])
 def test_f16x3_against_f32_engine(cuda, ssd, monkeypatch, backbone, B, H, W, env):
