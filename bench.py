@@ -184,6 +184,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_other = float(t.item())
     same_counts = bool((out_o[3] == out[3]).all().item())
+    # agreement of the two modes on this run's frames (mode f32 is bit-identical to the CPU oracle, tests/)
+    agree = {"num_boxes_identical": same_counts,
+             "labels_identical": bool((out_o[1] == out[1]).all().item()),
+             "max_abs_score_diff": float((out_o[2] - out[2]).abs().max().item()),
+             "slots_with_box_diff_over_1e-4": int(((out_o[0] - out[0]).abs().amax(dim=2) > 1e-4).sum().item()),
+             "detections": int(out[3].sum().item())}
     engine.set_precision(args.precision)
 
     # the same step with the boundary's host buffers in the loop (pinned host frames -> HBM,
@@ -250,7 +256,7 @@ def main():
                                 "roofline": {"bound": "mfma", "achieved": o_ach, "peak": o_peak, "unit": "TFLOP/s",
                                              "frac": o_ach / o_peak, "kernel": kernel_names[o_name]},
                                 "kernel_ms_per_step": {k: v["ms"] / n_other for k, v in prof_other.items()},
-                                "same_num_boxes_as_value_run": same_counts},
+                                "same_num_boxes_as_value_run": same_counts, "agreement_with_value_run": agree},
             "pcie_inclusive_img_s_per_gpu": pcie_img_s,
             "whole_net_roofline_frac": (1.113 * B) / ms_step,       # 1.113 ms/img at the per-layer roofline
         }
