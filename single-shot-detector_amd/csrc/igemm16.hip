@@ -1,7 +1,8 @@
 // Large-tile implicit GEMM for split-fp16 (S16) operands -- the throughput form of precision mode
-// f16x3 (see igemm.hip for the format and the arithmetic): the 3x3 head-tower / FPN convolutions and
-// 1x1 convolutions whose input, weights and output are S16 rows and whose epilogue is batch norm +
-// activation (optionally the second relu(raw) output of fpn p6).
+// f16x3 (see igemm.hip for the format and the arithmetic).  Input and weights are S16 rows; two epilogue
+// forms: batch norm + activation -> S16 rows (head towers, FPN outputs incl. the second relu(raw) output of
+// fpn p6, 1x1 convolutions), or bias -> fp32 rows at any row / image stride (the class logits), which also
+// marks the octets holding a score candidate in the post-processing's bitmap.
 //
 //   block     256 threads = 4 waves (2 x 2), ONE block per CU; tile 256 rows x 256 output channels,
 //             each wave a 128 x 128 sub-tile = 4 x 4 MFMA tiles of 32 x 32 -> 256 accumulator registers
@@ -14,12 +15,15 @@
 //             instruction fills 8 rows x 128 B; the XOR swizzle of the LDS image (slot = chunk ^
 //             ((row >> 1) & 7), conflict-free ds_read_b128 fragments) is applied to the per-lane SOURCE
 //             address; the convolution's zero padding is the buffer range check (out-of-range lanes
-//             deliver zeros to the LDS, measured).  Two stages of 64 KB; the DMA of K-step k+2 is issued
-//             right behind the barrier that retires stage k and has a whole K-step (3072 matrix-pipe
-//             cycles) to land.
+//             deliver zeros to the LDS, measured).  Two stages of 64 KB; the A half of K-step k+2 is issued
+//             right behind the barrier that retires stage k, the B half in the first phase of K-step k+1.
+//   K order   channel block outer, filter tap inner (the mode is not tied to the oracle's summation order): the
+//             nine taps of a block re-read the same lines nine K-steps apart -> L2 hits (3.8 -> 0.95 GB of fills).
 //   K-step    two 16-channel steps of 48 MFMAs; fragments double buffered in registers; one barrier per
-//             K-step, placed before the last 16 MFMAs so that the first fragments of the next stage are
+//             K-step, placed before its last 32 MFMAs so that the first fragments of the next stage are
 //             read underneath them.
+//   selected  by make_conv_op (api.hip) for launches with at least 512 of its tiles; smaller launches and
+//             other epilogue forms take the S16 path of igemm.hip.
 #include "ssd_internal.h"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -30,7 +34,8 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
 // DBG (timing experiments only, results are wrong): 1 = no DMA in the K loop, 2 = additionally no fragment
-// reads, 3 = additionally no barrier.  Selected by SSD_IGEMM16_DBG at launch.
+// reads, 3 = additionally no barrier, 4 = bare MFMAs on the 16x16x32 shape; selected by SSD_IGEMM16_DBG at launch.
+// DBG 7 (results right): per-block phase timestamps (ssd_bench_conv tile 17, scripts/ts_igemm16.py).
 template <int TAPS, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
 {
