@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric: images/sec at 896x640 (W x H), MobileNet-v1 RetinaNet,
 on N MI355X of one node (weak scaling: a fixed shard of images per GPU), plus the p50
-per-image latency of the reference's own batch-1 protocol.
+per-image latency of the reference's own batch-1 protocol and, at N = 1, BASELINE config 4
+(ShuffleNet-v2 + FPN, 640x640, batch 64) as a second object on the same line.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 starts itself under `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N` (a child process, before anything touches the GPU) unless it already runs
+inside such a launch (WORLD_SIZE set), so both `python bench.py --gpus 8` and the explicit
+torchrun form work.
 
 One step = one pass of the whole hot path (uint8 frames already resident in HBM -> backbone
 -> FPN -> heads -> decode -> per-class NMS -> padded detections; for N > 1 followed by the
 RCCL all-gather of the detection records) over one batch of synthetic frames per GPU.
-Prints ONE JSON line on rank 0.
+`value` is measured in the reference's arithmetic: every convolution an exact fp32 chain
+(precision mode f32, bit-identical to the CPU oracle).  The opt-in mode f16x3 is reported
+beside it as `other_precision`, never as `value`.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,15 +38,24 @@ PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_
 # precision f16x3: every fp32 product costs three v_mfma_f32_32x32x16_f16 terms (xh*wh + xh*wl + xl*wh), so the
 # algorithmic-FLOP peak of that kernel is the dense F16 MFMA peak (2.5 PFLOP/s = 16 x 157.3) divided by 3
 PEAK_F16X3_TFLOPS = 16 * 157.3 / 3.0
+HBM_PEAK_TBS = 8.0                    # MI355X_MICROARCH.md: spec; 6.29 measured copy
 PARAMS = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80,
           "score_threshold": 0.15, "iou_threshold": 0.6, "max_boxes_per_class": 25,
           "min_dimension": 640}       # config_mobilenet.json:7-12,21
+PARAMS_SHUFFLE = dict(PARAMS, backbone="shufflenet")    # config_shufflenet.json
+# per-layer max(FLOP / 157.3 TFLOP/s, bytes / 8 TB/s) summed, ms per image
+ROOFLINE_MS = {"mobilenet": 1.113, "shufflenet": 0.739}
+GFLOP_PER_IMAGE = {"mobilenet": 169.957, "shufflenet": 113.719}
 # Random-init heads have no trained sparsity: with the tower activations of the seeded weights the
 # logits are ~N(bias, 1.6).  -7.5 puts ~6.5k (anchor, class) scores above score_threshold per
 # image and ~190 detections after NMS -- a busy-scene RetinaNet output.  (The reference's own
 # init, -log(99), would leave 250k candidates / 1600 detections per image: tests/ use such
 # dense settings as an NMS stress, the benchmark does not.)  See DESIGN.md section 6.
-LOGITS_BIAS = -7.5
+LOGITS_BIAS = {"mobilenet": -7.5, "shufflenet": -11.0}
+
+KERNEL_NAMES = {
+    "conv3x3_f16x3_tile256": "igemm16_kernel<9> (3x3 convs of the head towers + fpn p3, 256x256 tiles, 3 x f16 MFMA per product)",
+    "conv3x3_mfma": "igemm_kernel<...,9> (3x3 convs: FPN outputs + head towers + class/box heads)"}
 
 
 def cpu_baseline(budget_s=12.0):
@@ -47,7 +65,7 @@ def cpu_baseline(budget_s=12.0):
     host the batch-1 graph runs fastest well below the full core count."""
     from oracle import graph, ops
     ops.build()
-    Wt = ssd_amd.synthetic_weights(PARAMS, seed=0, logits_bias=LOGITS_BIAS)
+    Wt = ssd_amd.synthetic_weights(PARAMS, seed=0, logits_bias=LOGITS_BIAS["mobilenet"])
     img = np.random.default_rng(0).integers(0, 256, (1, H, W, 3), dtype=np.uint8)
 
     def frame():
@@ -73,11 +91,12 @@ def cpu_baseline(budget_s=12.0):
         times.append(frame())
     med = float(np.median(times))
     return {"value": 1.0 / med, "unit": "img/s", "cores": best_t, "kind": "port",
-            "sample": "%d frames of 640x896, batch 1, C oracle (OpenMP %d threads of %d logical CPUs, AVX2 fmaf "
-                      "chains), median %.3f s/frame" % (len(times), best_t, ncpu, med)}
+            "sample": "%d frames of 640x896, batch 1, C oracle = CPU restatement of the TF1.12 reference path "
+                      "(OpenMP %d threads of %d logical CPUs, AVX2 fmaf chains), median %.3f s/frame"
+                      % (len(times), best_t, ncpu, med)}
 
 
-def latency_batch1(engine, dev):
+def latency_batch1(engine):
     """inference/just_try_detector.ipynb:149-155: 110 calls of the batch-1 detector on one
     host uint8 image (H2D + graph + D2H + score filter), first 10 dropped."""
     img = np.random.default_rng(0).integers(0, 256, (H, W, 3), dtype=np.uint8)
@@ -94,177 +113,286 @@ def latency_batch1(engine, dev):
     return {"p50_ms": float(np.percentile(t, 50)), "mean_ms": float(t.mean()), "std_ms": float(t.std())}
 
 
-def main():
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv, script):
+    """`python bench.py --gpus N` typed as is: re-run this script under torch.distributed.run, one
+    rank per GPU, as a CHILD process (never exec: nothing here has touched the GPU yet, and the
+    parent never does), and return its exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def dominant(prof):
+    # f16x3: the 256x256-tile kernel (8 tower launches + fpn p3 per step); f32: the 3x3 implicit-GEMM class
+    k = "conv3x3_f16x3_tile256" if prof.get("conv3x3_f16x3_tile256", {}).get("launches", 0) > 0 else "conv3x3_mfma"
+    return k, prof[k]
+
+
+def roofline_block(prof, precision, steps):
+    """roofline of the dominant kernel class: algorithmic FLOP of its launches / the union of their HIP-event
+    intervals on the forward's own streams inside the timed region (ssd_profile_read)."""
+    name, c = dominant(prof)
+    n = max(c["launches"], 1)
+    avg_ms = c["ms"] / n
+    flop = c["flops"] / n
+    ach = flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    peak = PEAK_FP32_MFMA_TFLOPS if precision == "f32" else PEAK_F16X3_TFLOPS
+    traffic, src = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")    # scripts/collect_profiles.sh: separate --pmc passes
+    if os.path.exists(tpath):
+        t = json.load(open(tpath)).get(precision, {})
+        traffic, src = t.get("hbm_bytes_per_launch"), "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
+            "this command, FETCH x2 per the gfx950 correction; a committed measurement, not re-measured in this run): " + str(t.get("source", ""))
+    return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "traffic": traffic, "traffic_source": src, "kernel": KERNEL_NAMES[name],
+            "peak_note": ("dense exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32)" if precision == "f32"
+                          else "dense F16 MFMA peak 2516.8 TFLOP/s / 3 MFMA terms per product"),
+            "launches_per_step": c["launches"] / steps, "avg_launch_ms": avg_ms,
+            "avg_launch_ms_note": "union of the class's launch intervals / launches (the two head towers run "
+                                  "side by side on two streams)",
+            "algorithmic_gflop_per_launch": flop / 1e9,
+            "algorithmic_gbyte_per_launch": c["bytes"] / n / 1e9}
+
+
+def kernel_tables(prof, steps):
+    ms = {k: v["ms"] / steps for k, v in prof.items()}
+    # per kernel class: algorithmic TFLOP/s and TB/s over the union of its launches' intervals
+    # (MFMA peak 157.3 TFLOP/s; HBM 8.0 TB/s spec, 6.3 measured copy)
+    rates = {k: {"tflops": v["flops"] / max(v["ms"], 1e-9) / 1e9, "tbytes_per_s": v["bytes"] / max(v["ms"], 1e-9) / 1e9,
+                 "frac_of_hbm_8tbs": v["bytes"] / max(v["ms"], 1e-9) / 1e9 / HBM_PEAK_TBS}
+             for k, v in prof.items() if v["launches"] > 0}
+    return ms, rates
+
+
+class Timed:
+    """W warm-up steps, then exactly K steps between two fences (device sync + barrier)."""
+
+    def __init__(self, world, dist, sync, dev):
+        self.world, self.dist, self.sync, self.dev = world, dist, sync, dev
+
+    def fence(self):
+        self.sync()
+        if self.world > 1:
+            self.dist.barrier()
+            self.sync()
+
+    def run(self, engine, step, steps, warmup):
+        out = None
+        for _ in range(warmup):
+            out = step()
+        self.fence()
+        engine.profile_reset()
+        engine.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        engine.profile_enable(False)
+        prof = engine.profile_read()
+        if self.world > 1:      # MAX over ranks
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out, prof
+
+
+def shufflenet_leg(local, timed, steps, warmup, batch):
+    """BASELINE config 4: ShuffleNet-v2 + FPN (config_shufflenet.json), 640x640, batch 64, one GPU."""
+    Wt = ssd_amd.synthetic_weights(PARAMS_SHUFFLE, seed=0, logits_bias=LOGITS_BIAS["shufflenet"])
+    eng = ssd_amd.Engine(PARAMS_SHUFFLE, Wt, device=local, precision="f32")
+    g = torch.Generator().manual_seed(4321)
+    frames = torch.randint(0, 256, (batch, 640, 640, 3), dtype=torch.uint8, generator=g).to("cuda:%d" % local)
+    res = {"workload": "ShuffleNet-v2 1.0x + FPN + RetinaNet heads + decode + per-class NMS, 640x640 uint8 frames, "
+                       "batch %d (BASELINE config 4)" % batch, "batch": batch}
+    outs = {}
+    for mode in ("f32", "f16x3"):
+        eng.set_precision(mode)
+        dt, out, prof = timed.run(eng, lambda: eng.forward(frames), steps, warmup)
+        outs[mode] = [t.clone() for t in out]
+        ms, rates = kernel_tables(prof, steps)
+        leg = {"value": batch * steps / dt, "unit": "img/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+               "roofline": roofline_block(prof, mode, steps), "kernel_ms_per_step": ms, "kernel_rates": rates}
+        leg["roofline"]["traffic"] = None       # no PMC pass of this workload is committed
+        leg["roofline"]["traffic_source"] = None
+        if mode == "f32":
+            leg["whole_net_roofline_frac"] = ROOFLINE_MS["shufflenet"] * batch / (dt / steps * 1e3)
+            leg["detections_per_image"] = float(out[3].float().mean().item())
+            res.update(leg, dtype="f32", precision="f32")
+        else:
+            leg["status_word"] = eng.status()
+            a, b = outs["f32"], outs["f16x3"]
+            leg["agreement_with_f32"] = {
+                "num_boxes_identical": bool((a[3] == b[3]).all().item()), "labels_identical": bool((a[1] == b[1]).all().item()),
+                "max_abs_score_diff": float((a[2] - b[2]).abs().max().item()),
+                "slots_with_box_diff_over_1e-4": int(((a[0] - b[0]).abs().amax(dim=2) > 1e-4).sum().item())}
+            res["other_precision"] = dict(leg, precision="f16x3")
+    eng.close()
+    return res
+
+
+def main(argv=None, engine_factory=None, backend="nccl", script=None):
+    """engine_factory / backend / script are injection points for tests/ (a world-size-2 gloo run of this very
+    launcher and step loop with a stand-in engine on CPU); the product run uses none of them."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step (BASELINE config 5: 256/8)")
-    ap.add_argument("--precision", choices=["f32", "f16x3"], default=os.environ.get("SSD_BENCH_MODE", "f16x3"),
-                    help="arithmetic of the dense convolutions (include/ssd_hip.h SSD_PRECISION_*): f16x3 = fp32 operands "
-                         "carried as split-fp16 pairs, 3 f16 MFMAs per product, fp32 accumulation (outputs within the "
-                         "north-star tolerance of the oracle); f32 = exact-fp32 MFMA, bit-identical to the oracle.  "
-                         "The line reports the other mode beside `value` (other_precision)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="total images per step over all GPUs (default --batch x --gpus); a count the GPUs do not divide "
+                         "gives uneven contiguous shards")
+    ap.add_argument("--precision", choices=["f32", "f16x3"], default="f32",
+                    help="arithmetic of the dense convolutions (include/ssd_hip.h SSD_PRECISION_*).  f32 (default) = the "
+                         "reference's arithmetic, exact-fp32 MFMA, bit-identical to the oracle.  f16x3 = opt-in: fp32 operands "
+                         "carried as split-fp16 pairs, 3 f16 MFMAs per product, fp32 accumulation -- NOT the reference's "
+                         "arithmetic (it does not guarantee identical box indices).  The line reports the other mode beside "
+                         "`value` (other_precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-shufflenet", action="store_true", help="skip the config-4 object (N = 1 only anyway)")
+    ap.add_argument("--no-other-precision", action="store_true")
+    args = ap.parse_args(argv)
+    argv = list(sys.argv[1:] if argv is None else argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # nothing has touched the GPU yet (importing torch / ssd_amd does not)
+        sys.exit(self_launch(args.gpus, argv, script or os.path.abspath(__file__)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
-                             "--nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
-    if not torch.cuda.is_available():
+    stub = engine_factory is not None
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if stub:
+        dev, sync = torch.device("cpu"), (lambda: None)
+    else:
+        torch.cuda.set_device(local)
+        dev, sync = torch.device("cuda", local), torch.cuda.synchronize
+    ranks_seen = [0]
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if stub:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
+        ids = torch.empty((world,), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int32, device=dev))
+        ranks_seen = [int(v) for v in ids.cpu()]
 
     B = args.batch
-    Wt = ssd_amd.synthetic_weights(PARAMS, seed=0, logits_bias=LOGITS_BIAS)
-    engine = ssd_amd.Engine(PARAMS, Wt, device=local, precision=args.precision)
-    peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16X3_TFLOPS
+    total = args.global_batch or B * world
+    Wt = ssd_amd.synthetic_weights(PARAMS, seed=0, logits_bias=LOGITS_BIAS["mobilenet"])
+    engine = engine_factory(PARAMS, Wt, local) if stub else ssd_amd.Engine(PARAMS, Wt, device=local, precision=args.precision)
     # this rank's shard of the global batch, resident in HBM before the timed region
-    lo, hi = ssd_amd.shard_range(B * world, rank, world)
+    lo, hi = ssd_amd.shard_range(total, rank, world)
     g = torch.Generator().manual_seed(1234 + rank)
     frames = torch.randint(0, 256, (hi - lo, H, W, 3), dtype=torch.uint8, generator=g).to(dev)
+    timed = Timed(world, dist, sync, dev)
 
     def step():
-        return ssd_amd.detect_sharded(engine, frames)
+        return ssd_amd.detect_sharded(engine, frames, total=total)
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        out = step()
-    fence()
-    engine.profile_reset()
-    engine.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    dt = time.perf_counter() - t0
-    engine.profile_enable(False)
-    prof = engine.profile_read()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert out[0].shape[0] == B * world
+    dt, out, prof = timed.run(engine, step, args.steps, args.warmup)
+    assert out[0].shape[0] == total, (out[0].shape, total)
     det_per_image = float(out[3].float().mean().item())
+    status_value = engine.status()            # bit 0: an f16x3 activation left the fp16 range (0 in mode f32)
 
     # the same workload in the other precision mode, same process, same frames (shorter run)
     other = "f32" if args.precision == "f16x3" else "f16x3"
-    engine.set_precision(other)
-    for _ in range(2):
-        step()
-    fence()
-    engine.profile_reset()
-    engine.profile_enable(True)
-    n_other = max(3, args.steps // 2)
-    t2 = time.perf_counter()
-    for _ in range(n_other):
-        out_o = step()
-    fence()
-    dt_other = time.perf_counter() - t2
-    engine.profile_enable(False)
-    prof_other = engine.profile_read()
-    if world > 1:
-        t = torch.tensor([dt_other], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_other = float(t.item())
-    same_counts = bool((out_o[3] == out[3]).all().item())
-    # agreement of the two modes on this run's frames (mode f32 is bit-identical to the CPU oracle, tests/)
-    agree = {"num_boxes_identical": same_counts,
-             "labels_identical": bool((out_o[1] == out[1]).all().item()),
-             "max_abs_score_diff": float((out_o[2] - out[2]).abs().max().item()),
-             "slots_with_box_diff_over_1e-4": int(((out_o[0] - out[0]).abs().amax(dim=2) > 1e-4).sum().item()),
-             "detections": int(out[3].sum().item())}
-    engine.set_precision(args.precision)
+    other_res = None
+    if not args.no_other_precision and not stub:
+        engine.set_precision(other)
+        n_other = max(3, args.steps // 2)
+        dt_o, out_o, prof_o = timed.run(engine, step, n_other, 2)
+        status_other = engine.status()
+        # agreement of the two modes on this run's frames (mode f32 is bit-identical to the CPU oracle, tests/)
+        agree = {"num_boxes_identical": bool((out_o[3] == out[3]).all().item()),
+                 "labels_identical": bool((out_o[1] == out[1]).all().item()),
+                 "max_abs_score_diff": float((out_o[2] - out[2]).abs().max().item()),
+                 "slots_with_box_diff_over_1e-4": int(((out_o[0] - out[0]).abs().amax(dim=2) > 1e-4).sum().item()),
+                 "detections": int(out[3].sum().item())}
+        ms_o, rates_o = kernel_tables(prof_o, n_other)
+        other_res = {"precision": other, "value": total * n_other / dt_o, "unit": "img/s",
+                     "ms_per_step": dt_o / n_other * 1e3, "steps": n_other,
+                     "dtype": "f32" if other == "f32" else "f32 carried as split f16 pairs (3 x f16 MFMA, f32 accumulate)",
+                     "note": None if other == "f32" else "opt-in mode, narrower than the reference's arithmetic: labels / num_boxes "
+                             "are not guaranteed identical to the oracle's (see agreement_with_value_run); never the headline",
+                     "status_word": status_other,
+                     "roofline": roofline_block(prof_o, other, n_other), "kernel_ms_per_step": ms_o, "kernel_rates": rates_o,
+                     "agreement_with_value_run": agree}
+        engine.set_precision(args.precision)
 
-    # the same step with the boundary's host buffers in the loop (pinned host frames -> HBM,
-    # detections -> host); reported beside `value`, never as `value`
-    host_frames = frames.cpu().pin_memory()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(max(2, args.steps // 2)):
-        d = host_frames.to(dev, non_blocking=True)
-        o = engine.forward(d)
-        _ = [t.cpu() for t in o]
-    torch.cuda.synchronize()
-    pcie_img_s = (hi - lo) * max(2, args.steps // 2) / (time.perf_counter() - t1)
+    pcie_img_s = None
+    if not stub:
+        # the same step with the boundary's host buffers in the loop (pinned host frames -> HBM,
+        # detections -> host); reported beside `value`, never as `value`
+        host_frames = frames.cpu().pin_memory()
+        sync()
+        n_p = max(2, args.steps // 2)
+        t1 = time.perf_counter()
+        for _ in range(n_p):
+            d = host_frames.to(dev, non_blocking=True)
+            o = engine.forward(d)
+            _ = [t.cpu() for t in o]
+        sync()
+        pcie_img_s = (hi - lo) * n_p / (time.perf_counter() - t1)
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        def dominant(pr):
-            # f16x3: the 256x256-tile kernel (8 tower launches + fpn p3 per step); f32: the 3x3 implicit-GEMM class
-            k = "conv3x3_f16x3_tile256" if pr["conv3x3_f16x3_tile256"]["launches"] > 0 else "conv3x3_mfma"
-            return k, pr[k]
-        dom_name, c3 = dominant(prof)
-        avg_ms = c3["ms"] / max(c3["launches"], 1)
-        flops_per_launch = c3["flops"] / max(c3["launches"], 1)
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # from scripts/collect_profiles.sh (separate PMC passes)
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(args.precision, {}).get("hbm_bytes_per_launch")
-        kernel_names = {"conv3x3_f16x3_tile256": "igemm16_kernel<9> (3x3 convs of the head towers + fpn p3, 256x256 tiles, 3 x f16 MFMA per product)",
-                        "conv3x3_mfma": "igemm_kernel<...,9> (3x3 convs: FPN outputs + head towers + class/box heads)"}
-        o_name, o3 = dominant(prof_other)
-        o_avg = o3["ms"] / max(o3["launches"], 1)
-        o_ach = o3["flops"] / max(o3["launches"], 1) / (o_avg * 1e-3) / 1e12 if o_avg > 0 else 0.0
-        o_peak = PEAK_FP32_MFMA_TFLOPS if other == "f32" else PEAK_F16X3_TFLOPS
         res = {
             "metric": "images/sec at 896x640, MobileNet-v1 RetinaNet (whole hot path incl. decode + per-class NMS)",
-            "value": B * world * args.steps / dt, "unit": "img/s", "n_gpus": world,
+            "value": total * args.steps / dt, "unit": "img/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "f32 carried as split f16 pairs (3 x f16 MFMA, f32 accumulate)",
-            "precision": args.precision,
-            "data": "synthetic",
+            "precision": args.precision, "status_word": status_value,
+            "data": "synthetic" if not stub else "STAND-IN ENGINE (launcher test, no GPU work)",
+            "ranks_seen": ranks_seen,
             "config": {"workload": "MobileNet-v1 + FPN + RetinaNet heads + decode + per-class NMS, 640x896 (HxW) "
                                    "uint8 frames, %d per GPU (BASELINE config 5 shard; config 2 = same graph at batch 1, "
-                                   "see latency_batch1)" % B,
-                       "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W,
-                       "parallelism": "dp%d" % world, "weights": "random-init (seed 0), logits bias %.1f" % LOGITS_BIAS,
+                                   "see latency_batch1; config 4 = the shufflenet_config4 object)" % B,
+                       "per_gpu_batch": B, "global_batch": total, "height": H, "width": W,
+                       "shards": [list(ssd_amd.shard_range(total, r, world)) for r in range(world)],
+                       "parallelism": "dp%d" % world,
+                       "weights": "random-init (seed 0), logits bias %.1f" % LOGITS_BIAS["mobilenet"],
                        "detections_per_image": det_per_image},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
-                         "kernel": kernel_names[dom_name],
-                         "peak_note": ("dense F16 MFMA peak 2516.8 TFLOP/s / 3 MFMA terms per product" if args.precision == "f16x3"
-                                       else "dense exact-fp32 MFMA peak"),
-                         "launches_per_step": c3["launches"] / args.steps, "avg_launch_ms": avg_ms,
-                         "algorithmic_gflop_per_launch": flops_per_launch / 1e9,
-                         "algorithmic_gbyte_per_launch": c3["bytes"] / max(c3["launches"], 1) / 1e9},
-            "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
-            # per kernel class: algorithmic TFLOP/s and TB/s over the union of its launches' intervals
-            # (MFMA peak 157.3 TFLOP/s; HBM 8.0 TB/s spec, 6.3 measured copy)
-            "kernel_rates": {k: {"tflops": v["flops"] / max(v["ms"], 1e-9) / 1e9, "tbytes_per_s": v["bytes"] / max(v["ms"], 1e-9) / 1e9}
-                             for k, v in prof.items() if v["launches"] > 0},
-            "other_precision": {"precision": other, "value": B * world * n_other / dt_other, "unit": "img/s",
-                                "ms_per_step": dt_other / n_other * 1e3, "steps": n_other,
-                                "roofline": {"bound": "mfma", "achieved": o_ach, "peak": o_peak, "unit": "TFLOP/s",
-                                             "frac": o_ach / o_peak, "kernel": kernel_names[o_name]},
-                                "kernel_ms_per_step": {k: v["ms"] / n_other for k, v in prof_other.items()},
-                                "same_num_boxes_as_value_run": same_counts, "agreement_with_value_run": agree},
-            "pcie_inclusive_img_s_per_gpu": pcie_img_s,
-            "whole_net_roofline_frac": (1.113 * B) / ms_step,       # 1.113 ms/img at the per-layer roofline
         }
-        if not args.no_latency:
-            res["latency_batch1"] = latency_batch1(engine, dev)
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+        if not stub:
+            ms, rates = kernel_tables(prof, args.steps)
+            res["roofline"] = roofline_block(prof, args.precision, args.steps)
+            res["kernel_ms_per_step"], res["kernel_rates"] = ms, rates
+            res["pcie_inclusive_img_s_per_gpu"] = pcie_img_s
+            # SURVEY 8d: 1.113 ms/img at the per-layer roofline of the exact-fp32 arithmetic
+            res["whole_net_roofline_frac"] = ROOFLINE_MS["mobilenet"] * (hi - lo) / ms_step if args.precision == "f32" else None
+            if other_res:
+                res["other_precision"] = other_res
+            if not args.no_latency:
+                lat = {}
+                for mode in ("f32", "f16x3"):
+                    engine.set_precision(mode)
+                    lat[mode] = latency_batch1(engine)
+                engine.set_precision(args.precision)
+                res["latency_batch1"] = dict(lat[args.precision], precision=args.precision,
+                                             roofline_ms=ROOFLINE_MS["mobilenet"], by_precision=lat)
+            if world == 1 and not args.no_shufflenet:
+                engine.close()
+                res["shufflenet_config4"] = shufflenet_leg(local, timed, max(3, args.steps // 2), 2, 64)
+            if world == 1 and not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -19,10 +19,15 @@
  *   - layout NHWC fp32, conv kernels HWIO, exactly the reference's TF variable layout.
  *   - return value: 0 (SSD_OK) or a negative code; ssd_last_error() gives the text for
  *     the calling thread.  Nothing throws across the ABI.
- *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  ssd_forward and
- *     ssd_postprocess only enqueue work: no hidden synchronisation.  The stage entry
- *     points that take host weights (ssd_conv2d, ssd_depthwise3x3, ssd_first_conv)
- *     are test conveniences and synchronise before returning.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  ssd_postprocess only
+ *     enqueues work.  ssd_forward only enqueues work for a (B,H,W) it has a layer plan for; the
+ *     FIRST call with a new (B,H,W) -- and the first call after ssd_set_precision -- builds that
+ *     plan: it waits for the device (hipDeviceSynchronize), frees the previous arena, allocates
+ *     and uploads (anchor table), then enqueues.  A serving loop sees this once per shape.
+ *     ssd_status, ssd_get_tensor and ssd_set_precision synchronise (documented at each).  The
+ *     stage entry points that take host weights (ssd_conv2d, ssd_depthwise3x3, ssd_dw_pw,
+ *     ssd_first_conv, ssd_concat_shuffle_split) are test conveniences and synchronise before
+ *     returning.
  *   - one handle per device; calls on one handle must be serialised by the caller.
  */
 #ifndef SSD_HIP_H
@@ -48,8 +53,12 @@ extern "C" {
 #define SSD_BACKBONE_MOBILENET 0   /* detector/backbones/mobilenet_v1.py  */
 #define SSD_BACKBONE_SHUFFLENET 1  /* detector/backbones/shufflenet_v2.py */
 
-/* Arithmetic of the dense FPN / head convolutions (ssd_set_precision).  The reference graph is
- * fp32 end to end (tf.float32 everywhere, model.py:13-77).
+/* Arithmetic of the dense convolutions (ssd_set_precision): FPN laterals and 3x3 outputs, head
+ * towers, class / box heads, and the MobileNet pointwise layers that are not fused with their
+ * depthwise convolution (Conv2d_5..13).  Depthwise layers, the first convolution, the fused
+ * depthwise+pointwise blocks and the ShuffleNet backbone are exact fp32 in both modes.  The
+ * reference graph is fp32 end to end (tf.float32 everywhere, model.py:13-77): F32 is the default
+ * and the mode every parity statement and the benchmark's headline refer to; F16X3 is opt-in.
  *   F32    every product on the exact-fp32 matrix instruction, one k-ordered fmaf chain per
  *          output: bit-identical to the CPU oracle.
  *   F16X3  each fp32 operand is carried as two halves x = h + l (22 significand bits) and a
@@ -80,7 +89,7 @@ int ssd_create(const ssd_config *cfg, ssd_handle **out);
 void ssd_destroy(ssd_handle *h);
 const char *ssd_last_error(void);
 
-/* Selects the arithmetic of the dense FPN / head convolutions for the following ssd_forward
+/* Selects the arithmetic of the dense convolutions (list above) for the following ssd_forward
  * calls (synchronises and drops the cached layer plan when the mode changes).  A new handle
  * takes its mode from the environment variable SSD_PRECISION ("f32" | "f16x3"), default f32. */
 int ssd_set_precision(ssd_handle *h, int32_t mode /* SSD_PRECISION_* */);
@@ -214,20 +223,6 @@ int ssd_postprocess(const float *logits_dev, const float *codes_dev, const float
                     float *boxes_dev, int32_t *labels_dev, float *scores_dev,
                     int32_t *num_boxes_dev, void *workspace_dev, size_t workspace_bytes,
                     void *stream);
-
-/* Diagnostics (scripts/bench_conv.py): average milliseconds of `reps` launches of one dense
- * convolution with BN + ReLU on random data, with an explicit implicit-GEMM tile variant
- * (0: 128x128, 1: 128x64, 2: 128x32, 5: 64x64, 6: 128x96; -1: the library's choice).
- * pyramid != 0 runs the five-level head-tower launch shape (H,W halved per level). */
-int ssd_bench_conv(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t k,
-                   int32_t stride, int32_t tile, int32_t reps, int32_t pyramid, double *avg_ms,
-                   double *gflop);
-
-/* Diagnostics (scripts/bench_dwpw.py): average milliseconds of `reps` launches of one depthwise +
- * pointwise block (BN + ReLU6 after each) on random data: fused != 0 as the single ssd_dw_pw
- * kernel, else as the depthwise kernel followed by the implicit-GEMM kernel. */
-int ssd_bench_dwpw(int32_t B, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t stride,
-                   int32_t fused, int32_t reps, double *avg_ms);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@ import ssd_amd
 from ssd_amd._lib import check
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 sel = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 3, 4, 5, 6]
+ssd_amd._lib.use_diag()        # libssd_hip_diag.so: the -DSSD_DIAG build (include/ssd_hip_diag.h)
 L = ssd_amd.lib()
 # layer: (H, W of the depthwise input, C, Cout, stride)
 LAYERS = {1: (320, 448, 32, 64, 1), 2: (320, 448, 64, 128, 2), 3: (160, 224, 128, 128, 1), 4: (160, 224, 128, 256, 2),

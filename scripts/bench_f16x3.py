@@ -8,6 +8,7 @@ import ssd_amd
 from ssd_amd._lib import check
 assert torch.cuda.is_available()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+ssd_amd._lib.use_diag()        # libssd_hip_diag.so: the -DSSD_DIAG build (include/ssd_hip_diag.h)
 L = ssd_amd.lib()
 TILES = {-1: "auto", 0: "128x128", 1: "128x64", 2: "128x32", 5: "64x64", 6: "128x96"}
 

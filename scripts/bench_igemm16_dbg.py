@@ -9,6 +9,7 @@ import ssd_amd
 from ssd_amd._lib import check
 assert torch.cuda.is_available()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+ssd_amd._lib.use_diag()        # libssd_hip_diag.so: the -DSSD_DIAG build (include/ssd_hip_diag.h)
 L = ssd_amd.lib()
 os.environ["SSD_BENCH_PRECISION"] = "f16x3"
 for rnd in range(2):

@@ -9,6 +9,7 @@ from ssd_amd._lib import check
 tile = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 shape = sys.argv[3] if len(sys.argv) > 3 else "tower"
+ssd_amd._lib.use_diag()        # libssd_hip_diag.so: the -DSSD_DIAG build (include/ssd_hip_diag.h)
 L = ssd_amd.lib()
 ms, gf = ctypes.c_double(), ctypes.c_double()
 if shape == "tower":

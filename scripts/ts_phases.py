@@ -14,6 +14,7 @@ B = int(sys.argv[6]) if len(sys.argv) > 6 else 32
 pyr = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 path = "/tmp/ts_dump.bin"
 os.environ["SSD_TS_DUMP"] = path
+ssd_amd._lib.use_diag()        # libssd_hip_diag.so: the -DSSD_DIAG build (include/ssd_hip_diag.h)
 L = ssd_amd.lib()
 ms, gf = ctypes.c_double(), ctypes.c_double()
 check(L.ssd_bench_conv(B, H, W, Cin, Cout, k, 1, 17, 3, pyr, ctypes.byref(ms), ctypes.byref(gf)))

@@ -10,7 +10,7 @@ raises if the HIP library is missing or no GPU is present.
 from .config import load_config, INFERENCE_KEYS                       # noqa: F401
 from .variables import (variable_shapes, synthetic_weights, save_weights,   # noqa: F401
                         load_weights)
-from .pb_import import read_frozen_graph, load_pb_weights, write_frozen_graph  # noqa: F401
+from .pb_import import read_frozen_graph, load_pb_weights             # noqa: F401
 from ._lib import build, lib, lib_path, SsdError                       # noqa: F401
 from .ssd import (SSD, AnchorGenerator, batch_multiclass_non_max_suppression,  # noqa: F401
                   Engine)

@@ -11,7 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _SOURCES = ["api.hip", "igemm.hip", "igemm16.hip", "dwpw.hip", "elementwise.hip", "postprocess.hip"]
 _LIB_PATH = os.path.join(_CSRC, "libssd_hip.so")
+_DIAG_PATH = os.path.join(_CSRC, "libssd_hip_diag.so")       # -DSSD_DIAG build, scripts/ only
 _lib = None
+_diag = False
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 
@@ -24,16 +26,32 @@ def lib_path():
     return _LIB_PATH
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source into csrc/libssd_hip.so (cross-compiles without a GPU)."""
+def build(force=False, verbose=False, diag=False):
+    """Compile every HIP source into csrc/libssd_hip.so (cross-compiles without a GPU); returns early
+    when the library is newer than every source.  diag=True builds csrc/libssd_hip_diag.so instead:
+    the same sources with -DSSD_DIAG (ablation kernels, tile overrides, phase stamps, ssd_bench_*;
+    include/ssd_hip_diag.h) for scripts/ -- never loaded by the product."""
     srcs = [os.path.join(_CSRC, s) for s in _SOURCES]
     deps = srcs + [os.path.join(_CSRC, "ssd_internal.h"),
-                   os.path.join(_HERE, "..", "include", "ssd_hip.h")]
+                   os.path.join(_HERE, "..", "include", "ssd_hip.h"),
+                   os.path.join(_HERE, "..", "include", "ssd_hip_diag.h")]
+    target = _DIAG_PATH if diag else _LIB_PATH
+    # freshness by CONTENT (sha256 of sources + headers + flags, kept beside the library), not by mtime: the
+    # snapshot that travels to a GPU box does not promise to preserve modification-time order
+    import hashlib
+    hh = hashlib.sha256(" ".join(HIPCC_FLAGS + (["-DSSD_DIAG"] if diag else [])).encode())
+    for d in deps:
+        with open(d, "rb") as f:
+            hh.update(f.read())
+    digest = hh.hexdigest()
+    stamp = target + ".sha"
     def fresh():
-        return os.path.exists(_LIB_PATH) and \
-            os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(d) for d in deps)
+        if not (os.path.exists(target) and os.path.exists(stamp)):
+            return False
+        with open(stamp) as f:
+            return f.read().strip() == digest
     if not force and fresh():
-        return _LIB_PATH
+        return target
     # one builder at a time (torch.distributed.run starts N ranks at once): lock, re-check,
     # compile beside the target and rename over it, so no rank ever maps a half-written file
     import fcntl
@@ -41,17 +59,46 @@ def build(force=False, verbose=False):
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not force and fresh():
-                return _LIB_PATH
+                return target
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-            tmp = "%s.tmp.%d" % (_LIB_PATH, os.getpid())
-            cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp] + srcs
+            tmp = "%s.tmp.%d" % (target, os.getpid())
+            # one object per source, compiled in parallel and kept (build/ is git-ignored): an edit to one
+            # kernel file recompiles that file only
+            objdir = os.path.join(_CSRC, "build", "diag" if diag else "ship")
+            os.makedirs(objdir, exist_ok=True)
+            hdrs = deps[len(srcs):]
+            cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + (["-DSSD_DIAG"] if diag else [])
+            jobs = []
+            for src in srcs:
+                obj = os.path.join(objdir, os.path.basename(src) + ".o")
+                oh = hashlib.sha256(" ".join(cflags).encode())
+                for d in [src] + hdrs:
+                    with open(d, "rb") as f:
+                        oh.update(f.read())
+                ostamp, odig = obj + ".sha", oh.hexdigest()
+                if force or not os.path.exists(obj) or not os.path.exists(ostamp) or open(ostamp).read().strip() != odig:
+                    jobs.append(([hipcc] + cflags + ["-c", src, "-o", obj], ostamp, odig))
+            if verbose:
+                for j in jobs:
+                    print(" ".join(j[0]))
+            procs = [subprocess.Popen(j[0]) for j in jobs]
+            rcs = [p.wait() for p in procs]
+            if any(rcs):
+                raise subprocess.CalledProcessError(max(rcs), "hipcc -c")
+            for _cmd, ostamp, odig in jobs:
+                with open(ostamp, "w") as f:
+                    f.write(odig)
+            objs = [os.path.join(objdir, os.path.basename(src) + ".o") for src in srcs]
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-            os.replace(tmp, _LIB_PATH)
+            os.replace(tmp, target)
+            with open(stamp, "w") as f:
+                f.write(digest)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
-    return _LIB_PATH
+    return target
 
 
 _f = ctypes.POINTER(ctypes.c_float)
@@ -98,23 +145,38 @@ SIGNATURES = {
     "ssd_first_conv": (ctypes.c_int, [_vp, _i, _i, _i, _f, _i, _f, _f, _f, _i, _vp, _vp]),
     "ssd_maxpool3x3s2": (ctypes.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "ssd_concat_shuffle_split": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _i, _vp, _vp, _vp]),
-    "ssd_bench_conv": (ctypes.c_int, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
-    "ssd_bench_dwpw": (ctypes.c_int, [_i, _i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_double)]),
     "ssd_postprocess_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i, _i]),
     "ssd_postprocess": (ctypes.c_int, [_vp, _vp, _vp, _i, _i, _i, ctypes.c_float, ctypes.c_float,
                                        _i, _f, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
 }
 
 
+# include/ssd_hip_diag.h (libssd_hip_diag.so only)
+DIAG_SIGNATURES = {
+    "ssd_bench_conv": (ctypes.c_int, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "ssd_bench_dwpw": (ctypes.c_int, [_i, _i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_double)]),
+}
+
+
+def use_diag():
+    """scripts/ only: make lib() load the -DSSD_DIAG build.  Must be called before the first lib()."""
+    global _diag
+    if _lib is not None and not _diag:
+        raise RuntimeError("use_diag() after libssd_hip.so was loaded")
+    _diag = True
+
+
 def lib():
-    """Load libssd_hip.so (building it if the sources are newer).  Raises if impossible."""
+    """Load libssd_hip.so, rebuilding it first when any source is newer (build() returns at once when
+    it is fresh; a source tree without hipcc and with a fresh library -- the GPU box -- never compiles).
+    Raises if impossible: there is no fallback."""
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
-        _lib = ctypes.CDLL(_LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        path = build(diag=_diag)
+        _lib = ctypes.CDLL(path)
+        sigs = dict(SIGNATURES, **DIAG_SIGNATURES) if _diag else SIGNATURES
+        for name, (res, args) in sigs.items():
             fn = getattr(_lib, name)
             fn.restype = res
             fn.argtypes = args

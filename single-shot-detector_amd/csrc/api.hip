@@ -126,8 +126,24 @@ static int pick_tile(int CoutP)
 // 754.6 / 757.2 / 760.2 / 760.6); from Conv2d_5 on (K >= 256) the two-kernel pair is faster.
 #define SSD_FUSE_DW_DEFAULT 0xfu
 #define SSD_FUSE_SHUFFLE_DEFAULT true    // ShuffleNet B=64 640x640: depthwise + pointwise 4.19 -> 3.76 ms per step
-static int g_force_tile = -1;   // diagnostics only (ssd_bench_conv)
-static long long *g_dbg_ts = nullptr;   // diagnostics only (ssd_bench_conv tile 17)
+#ifdef SSD_DIAG                      // libssd_hip_diag.so (scripts/): tile override and phase-stamp buffer of ssd_bench_conv
+static int g_force_tile = -1;
+static long long *g_dbg_ts = nullptr;
+#else                                // the shipped library: compile-time constants, no override exists
+static constexpr int g_force_tile = -1;
+static constexpr long long *g_dbg_ts = nullptr;
+#endif
+
+// candidate lists up to this length run in one wave's registers (postprocess.hip); SSD_NMS_FAST_MAX lowers it so that
+// tests can route every list through the 1024-thread kernel (same results).  Read when a plan is built / a stage
+// entry point is called, never per launch.  PostArgs encoding: 0 = default, -1 = "0".
+static int env_fast_max()
+{
+    const char *e = getenv("SSD_NMS_FAST_MAX");
+    if (!e) return 0;
+    const int v = atoi(e);
+    return v == 0 ? -1 : (v > 0 ? v : 0);
+}
 
 static int pack_conv(DevPool &pool, const float *w, int k, int Cin_l, int Cout_l, const std::vector<int> &inmap,
                      const std::vector<int> &outmap, ConvW &cw)
@@ -347,6 +363,8 @@ struct ssd_handle {
     bool profiling = false;
     std::vector<EvPair> evs;
     std::vector<hipEvent_t> ref_evs;     // one reference event per profiled forward
+    std::vector<hipEvent_t> ev_pool;     // timing events, created once and reused (none is created inside a timed region
+                                         // after the first profiled forward)
     double acc_ms[SSD_NCLS] = {0}, acc_flops[SSD_NCLS] = {0}, acc_bytes[SSD_NCLS] = {0};
     long long acc_n[SSD_NCLS] = {0};
 };
@@ -750,6 +768,7 @@ extern "C" void ssd_destroy(ssd_handle *h)
     (void)hipDeviceSynchronize();
     for (auto &e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto r : h->ref_evs) (void)hipEventDestroy(r);
+    for (auto r : h->ev_pool) (void)hipEventDestroy(r);
     free_plans(h);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_gin) (void)hipEventDestroy(h->ev_gin);
@@ -810,7 +829,8 @@ static Pyr make_pyr(int B, int H, int W, int C)
     return p;
 }
 
-static Op make_dw_op(const DwW &d, const float *in, int B, int H, int W, int stride, int act, float *out, int Cl, int out16 = 0)
+static Op make_dw_op(const DwW &d, const float *in, int B, int H, int W, int stride, int act, float *out, int Cl, int out16 = 0,
+                     int *flags = nullptr)
 {
     const int OH = H / stride, OW = W / stride, pad = stride == 1 ? 1 : 0;
     Op op;
@@ -819,7 +839,7 @@ static Op make_dw_op(const DwW &d, const float *in, int B, int H, int W, int str
     op.bytes = ((double)B * H * W + (double)B * OH * OW) * Cl * 4.0;
     const DwW dd = d;
     op.run = [=](hipStream_t s) {
-        return launch_depthwise(in, B, H, W, dd.Cp, dd.w, stride, pad, OH, OW, dd.mean, dd.sf, dd.beta, act, out, s, out16);
+        return launch_depthwise(in, B, H, W, dd.Cp, dd.w, stride, pad, OH, OW, dd.mean, dd.sf, dd.beta, act, out, s, out16, flags);
     };
     return op;
 }
@@ -972,7 +992,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 // f16x3: an unfused pair hands the depthwise result (exact fp32, in [0, 6]) to its pointwise
                 // convolution in split-fp16 rows, and the pointwise product runs as 3 x f16 MFMA
                 const int pw16 = X16 && !fuse && (h->dw[i].Cp % 32 == 0) ? 1 : 0;
-                if (!fuse) ops.push_back(make_dw_op(h->dw[i], cur, nb, ch, cwid, s, SSD_ACT_RELU6, dwo, h->pw[i].Cin_l, pw16));
+                if (!fuse) ops.push_back(make_dw_op(h->dw[i], cur, nb, ch, cwid, s, SSD_ACT_RELU6, dwo, h->pw[i].Cin_l, pw16, FL));
                 const int dh = ch, dwid = cwid;
                 ch /= s; cwid /= s;
                 float *pwo;
@@ -1188,6 +1208,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     p.B = B; p.N = (int)N; p.C = C;
     p.score_thr = h->cfg.score_threshold; p.iou_thr = h->cfg.iou_threshold;
     p.max_per_class = h->cfg.max_boxes_per_class;
+    p.fast_max = env_fast_max();
     for (int k = 0; k < 4; ++k) p.box_scaler[k] = rd.box_scaler[k];    // model.py:67-68
     post_carve(p, ws);
     HIPCHK(hipMemset(p.scan_bits, 0, post_scan_bitmap_bytes(B, (int)N, C)));
@@ -1250,6 +1271,12 @@ static float conservative_logit_bound(float thr)
     return (float)(l - 1e-3 * (1.0 + fabs(l)));
 }
 
+static hipError_t pool_event(ssd_handle *h, hipEvent_t *e)
+{
+    if (!h->ev_pool.empty()) { *e = h->ev_pool.back(); h->ev_pool.pop_back(); return hipSuccess; }
+    return hipEventCreate(e);
+}
+
 static hipError_t run_op(ssd_handle *h, const Op &op, hipStream_t s)
 {
     static const int dbg_sync = getenv("SSD_DEBUG_SYNC") ? atoi(getenv("SSD_DEBUG_SYNC")) : 0;
@@ -1266,9 +1293,9 @@ static hipError_t run_op(ssd_handle *h, const Op &op, hipStream_t s)
     EvPair e;
     e.cls = op.cls;
     e.fwd = (int)h->ref_evs.size() - 1;
-    hipError_t r = hipEventCreate(&e.a);
+    hipError_t r = pool_event(h, &e.a);
     if (r != hipSuccess) return r;
-    r = hipEventCreate(&e.b);
+    r = pool_event(h, &e.b);
     if (r != hipSuccess) return r;
     (void)hipEventRecord(e.a, s);
     r = op.run(s);
@@ -1288,12 +1315,18 @@ static int make_plans(ssd_handle *h, int B, int H, int W)
     // than the overlap returns, so the default is ONE plan; SSD_NSUB keeps the experiment alive.
     int nsub = 1;
     if (const char *e = getenv("SSD_NSUB")) { const int v = atoi(e); if (v >= 1 && v <= 8) nsub = v; }
-    {   // every tensor an MFMA launch reads must stay < 2 GiB (32-bit buffer offsets): the largest is
-        // the first depthwise / max-pool output [B, H/2, W/2, 32] -> split very large batches
+    {   // every tensor a launch addresses with 32-bit byte offsets must stay < 2 GiB -> split very large batches into
+        // consecutive sub-batch plans.  Per image: the largest backbone tensor (first conv / max-pool output
+        // [H/2, W/2, 32]; MobileNet's Conv2d_1_pointwise doubles the channels at that resolution), the concatenated
+        // pyramid of a head tower (256 channels), the class logits [N, C], the box codes, and the uint8 source image.
         const ResizeDims rd = resize_dims(H, W, h->cfg.min_dimension, 128);
-        // (MobileNet: Conv2d_1_pointwise doubles the channels at the same resolution)
+        const int nH = rd.nh + rd.ph, nW = rd.nw + rd.pw;
         const int cmax = h->cfg.backbone == SSD_BACKBONE_MOBILENET && !h->pw.empty() ? std::max(h->firstCp, h->pw[0].CoutP) : h->firstCp;
-        const long long per_img = (long long)((rd.nh + rd.ph) / 2) * ((rd.nw + rd.pw) / 2) * cmax * 4;
+        long long per_img = (long long)(nH / 2) * (nW / 2) * cmax * 4;
+        const Pyr py1 = make_pyr(1, nH, nW, 256);
+        per_img = std::max(per_img, py1.total * 4);
+        per_img = std::max(per_img, (long long)ssd_num_anchors(nH, nW) * std::max(h->cfg.num_classes, 4) * 4);
+        per_img = std::max(per_img, (long long)H * W * 3);
         const long long bmax = ((1LL << 31) - 1) / per_img;
         if (bmax < 1) return fail(SSD_ERR_INVALID, "ssd_forward: image too large for one launch");
         const int need = (int)((B + bmax - 1) / bmax);
@@ -1327,7 +1360,7 @@ static int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxe
     h->cur_images = images_dev;
     if (h->profiling) {
         hipEvent_t ref;
-        HIPCHK(hipEventCreate(&ref));
+        HIPCHK(pool_event(h, &ref));
         HIPCHK(hipEventRecord(ref, s));
         h->ref_evs.push_back(ref);
     }
@@ -1538,12 +1571,12 @@ static int drain_events(ssd_handle *h)
             HIPCHK(hipEventElapsedTime(&t1, e.a, e.b));
         }
         iv[e.cls].push_back({t0, t1});
-        (void)hipEventDestroy(e.a);
-        (void)hipEventDestroy(e.b);
+        h->ev_pool.push_back(e.a);
+        h->ev_pool.push_back(e.b);
     }
     flush();
     h->evs.clear();
-    for (auto r : h->ref_evs) (void)hipEventDestroy(r);
+    for (auto r : h->ref_evs) h->ev_pool.push_back(r);
     h->ref_evs.clear();
     return SSD_OK;
 }
@@ -1839,6 +1872,7 @@ extern "C" int ssd_postprocess(const float *logits_dev, const float *codes_dev, 
     p.score_thr = score_threshold; p.iou_thr = iou_threshold;
     p.logit_lo = conservative_logit_bound(score_threshold);
     p.max_per_class = mp;
+    p.fast_max = env_fast_max();
     for (int k = 0; k < 4; ++k) p.box_scaler[k] = box_scaler_host ? box_scaler_host[k] : 1.0f;
     p.boxes = boxes_dev; p.labels = labels_dev; p.scores = scores_dev; p.num = num_boxes_dev;
     post_carve(p, workspace_dev);
@@ -1847,6 +1881,7 @@ extern "C" int ssd_postprocess(const float *logits_dev, const float *codes_dev, 
 }
 
 // ----------------------------------------------------------------------------- diagnostics
+#ifdef SSD_DIAG   // everything below exists only in libssd_hip_diag.so (include/ssd_hip_diag.h, scripts/)
 // Times `reps` launches of one dense convolution (random data, BN + ReLU epilogue) on the
 // implicit-GEMM kernel with an explicit tile variant; used by scripts/bench_conv.py to A/B
 // kernel variants in one process.  nlev > 1 replicates the level `nlev` times in one launch
@@ -2023,3 +2058,4 @@ extern "C" int ssd_bench_dwpw(int32_t B, int32_t H, int32_t W, int32_t C, int32_
     pool.free_all();
     return rc;
 }
+#endif  // SSD_DIAG

@@ -178,9 +178,10 @@ template <int STRIDE, int OUT16 = 0>
 __global__ __launch_bounds__(256) void depthwise_kernel(const float *__restrict__ in, int B, int H, int W, int C,
                                                          const float *__restrict__ w, int pad, int OH, int OW,
                                                          const float *mean, const float *sf, const float *beta,
-                                                         int act, float *__restrict__ out)
+                                                         int act, float *__restrict__ out, int *flags)
 {
     constexpr int NCOL = (DW_PX - 1) * STRIDE + 3;
+    bool ovf = false;
     const int C4 = C >> 2, XG = (OW + DW_PX - 1) / DW_PX;
     const long long total = (long long)B * OH * XG * C4;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256) void depthwise_kernel(const float *__restrict_
                     v4h h, l;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
+                        ovf |= !(fabsf(v[e]) <= 65504.0f);       // also true for NaN
                         const float x = fminf(fmaxf(v[e], -65504.0f), 65504.0f);
                         h[e] = (_Float16)x;
                         l[e] = (_Float16)(x - (float)h[e]);
@@ -244,11 +246,12 @@ __global__ __launch_bounds__(256) void depthwise_kernel(const float *__restrict_
             if (ox0 + p < OW) *(v4f *)(o + (long long)p * C) = bn_act4(acc[p], mean, sf, beta, c, act);
         }
     }
+    if constexpr (OUT16) { if (ovf && flags) atomicOr(flags, 1); }
 }
 
 hipError_t launch_depthwise(const float *in, int B, int H, int W, int C, const float *w, int stride, int pad, int OH,
                             int OW, const float *mean, const float *sf, const float *beta, int act, float *out,
-                            hipStream_t s, int out16)
+                            hipStream_t s, int out16, int *flags)
 {
     if (C % 4 || (stride != 1 && stride != 2) || (out16 && C % 8)) return hipErrorInvalidValue;
     const long long total = (long long)B * OH * ((OW + DW_PX - 1) / DW_PX) * (C / 4);
@@ -257,16 +260,16 @@ hipError_t launch_depthwise(const float *in, int B, int H, int W, int C, const f
     if (blocks < 1) blocks = 1;
     if (stride == 1 && !out16)
         hipLaunchKernelGGL(depthwise_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, in, B, H, W, C, w, pad, OH, OW,
-                           mean, sf, beta, act, out);
+                           mean, sf, beta, act, out, flags);
     else if (!out16)
         hipLaunchKernelGGL(depthwise_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, in, B, H, W, C, w, pad, OH, OW,
-                           mean, sf, beta, act, out);
+                           mean, sf, beta, act, out, flags);
     else if (stride == 1)
         hipLaunchKernelGGL((depthwise_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, s, in, B, H, W, C, w, pad, OH, OW,
-                           mean, sf, beta, act, out);
+                           mean, sf, beta, act, out, flags);
     else
         hipLaunchKernelGGL((depthwise_kernel<2, 1>), dim3((unsigned)blocks), dim3(256), 0, s, in, B, H, W, C, w, pad, OH, OW,
-                           mean, sf, beta, act, out);
+                           mean, sf, beta, act, out, flags);
     return hipGetLastError();
 }
 

@@ -200,6 +200,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     // are 4 channels = half an octet: h into chunk 2o, l into chunk 2o+1, 8 bytes each.
     const int woff_h = (tid >> 3) * 128 + ((((tid & 6)) ^ ((tid >> 4) & 7)) << 4) + (tid & 1) * 8;
     const int woff_l = (tid >> 3) * 128 + ((((tid & 6) + 1) ^ ((tid >> 4) & 7)) << 4) + (tid & 1) * 8;
+    bool in_ovf = false;               // S16 == 2: a staged fp32 value was outside the fp16 range (or NaN) -> status word
     auto lstore = [&](int stage) {
         unsigned char *base = lds + stage * STAGE;
 #pragma unroll
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
                 v4h hh, ll;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+                    in_ovf |= !(fabsf(ra[u][e]) <= 65504.0f);
                     const float x = __builtin_fminf(__builtin_fmaxf(ra[u][e], -65504.0f), 65504.0f);
                     hh[e] = (_Float16)x;
                     ll[e] = (_Float16)(x - (float)hh[e]);
@@ -409,6 +411,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     // image is plain row-major: a 32-lane ds_write_b32 covers 32 consecutive dwords of one row
     // and a 16-lane ds_read_b128 group covers 16 distinct 16-B chunks -- conflict-free as is.
     mark(2);
+    if constexpr (S16 == 2) { if (in_ovf && a.flags) atomicOr(a.flags, 1); }
     const bool has_bn = a.mean != nullptr;
     constexpr int RW = WN * 32;                  // floats per row of the wave's sub-tile
     constexpr int C4N = RW / 4;                  // 16-B chunks per row
@@ -679,10 +682,12 @@ hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStre
     case IGEMM_128x32: return launch_t<4, 1, 1, 1>(a, total_tiles_m, s);
     case IGEMM_64x64: return launch_t<2, 2, 1, 1>(a, total_tiles_m, s);
     case IGEMM_128x96: return launch_t<4, 1, 1, 3>(a, total_tiles_m, s);
+#ifdef SSD_DIAG   // ablation / phase-stamp instances exist only in libssd_hip_diag.so
     case 10: return launch_t<2, 2, 2, 2, 1>(a, total_tiles_m, s);
     case 11: return launch_t<2, 2, 2, 2, 2>(a, total_tiles_m, s);
     case 12: return launch_t<2, 2, 2, 2, 3>(a, total_tiles_m, s);
     case 17: return launch_t<2, 2, 2, 2, 7>(a, total_tiles_m, s);
+#endif
     }
     return hipErrorInvalidValue;
 }

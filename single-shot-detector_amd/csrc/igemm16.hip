@@ -33,8 +33,8 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
-// DBG (timing experiments only, results are wrong): 1 = no DMA in the K loop, 2 = additionally no fragment
-// reads, 3 = additionally no barrier, 4 = bare MFMAs on the 16x16x32 shape; selected by SSD_IGEMM16_DBG at launch.
+// DBG (timing experiments only, results are wrong; instantiated only in the -DSSD_DIAG build): 1 = no DMA in the K loop,
+// 2 = additionally no fragment reads, 3 = additionally no barrier, 4 = bare MFMAs on the 16x16x32 shape.
 // DBG 7 (results right): per-block phase timestamps (ssd_bench_conv tile 17, scripts/ts_igemm16.py).
 template <int TAPS, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
@@ -355,7 +355,9 @@ __global__ __launch_bounds__(256, 1) void igemm16_kernel(const IgemmArgs a)
         v8h h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(__builtin_fabsf(v[e][0]), __builtin_fabsf(v[e][1])));
+            // fmax drops a NaN operand: a NaN must poison the range check itself
+            const float m2 = __builtin_fmaxf(__builtin_fabsf(v[e][0]), __builtin_fabsf(v[e][1]));
+            vmax = (v[e][0] == v[e][0] && v[e][1] == v[e][1]) ? __builtin_fmaxf(vmax, m2) : INFINITY;
             h[2 * e] = (_Float16)v[e][0];
             h[2 * e + 1] = (_Float16)v[e][1];
             l[2 * e] = (_Float16)(v[e][0] - (float)h[2 * e]);
@@ -482,6 +484,7 @@ hipError_t launch_igemm16(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
         if ((long long)L.OH * L.OW < 4 || L.out_bstride <= 0) return hipErrorInvalidValue;
         if ((long long)a.B * L.out_bstride * 4 >= (1LL << 31)) return hipErrorInvalidValue;
     }
+#ifdef SSD_DIAG   // libssd_hip_diag.so only (scripts/): the shipped library holds no ablation kernels and reads no environment here
     if (a.ts && a.taps == 9) return launch16_t<9, 7>(a, total_tiles_m, s);     // ssd_bench_conv tile 17: phase stamps
     if (const char *e = getenv("SSD_IGEMM16_DBG")) {     // timing experiments (scripts/bench_f16x3.py), 3x3 only
         const int d = atoi(e);
@@ -490,5 +493,6 @@ hipError_t launch_igemm16(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
         if (a.taps == 9 && d == 3) return launch16_t<9, 3>(a, total_tiles_m, s);
         if (a.taps == 9 && d == 4) return launch16_t<9, 4>(a, total_tiles_m, s);
     }
+#endif
     return a.taps == 9 ? launch16_t<9>(a, total_tiles_m, s) : launch16_t<1>(a, total_tiles_m, s);
 }

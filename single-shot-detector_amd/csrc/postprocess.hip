@@ -141,8 +141,7 @@ __global__ __launch_bounds__(256) void post_scan_kernel(const PostArgs p)
                         if (x1[j] >= p.logit_lo) push((unsigned)(e0 + 4 + j), x1[j]);
                     }
                 }
-                __syncthreads();
-                if (q_n > 2048) drain();
+                if (__syncthreads_or(q_n > 2048)) drain();
             }
         }
         drain();
@@ -177,8 +176,9 @@ __global__ __launch_bounds__(256) void post_scan_kernel(const PostArgs p)
                 }
             }
         }
-        __syncthreads();
-        if (q_n > 2048) drain();               // uniform: q_n is stable between the barriers
+        // the decision must be block-uniform AND separated by a barrier from the next iteration's pushes (a fast
+        // wave's atomicAdd on q_n could otherwise flip it for a slow wave: divergent __syncthreads in drain)
+        if (__syncthreads_or(q_n > 2048)) drain();
     }
     drain();
 }
@@ -466,8 +466,9 @@ void post_carve(PostArgs &p, void *ws)
 hipError_t launch_postprocess(const PostArgs &pin, hipStream_t s)
 {
     PostArgs p = pin;
-    p.fast_max = 64 * NMS_R;
-    if (const char *e = getenv("SSD_NMS_FAST_MAX")) { int v = atoi(e); if (v >= 0 && v < p.fast_max) p.fast_max = v; }
+    // lists up to fast_max candidates stay in one wave's registers; the caller may lower it (tests route every
+    // list through the 1024-thread kernel), 0 / out of range = the default
+    if (p.fast_max < 1 || p.fast_max > 64 * NMS_R) p.fast_max = pin.fast_max == -1 ? 0 : 64 * NMS_R;
     if (p.B < 1 || p.N < 1 || p.C < 1 || p.max_per_class < 1) return hipErrorInvalidValue;
     if ((long long)p.B * p.N * p.C >= (1LL << 32)) return hipErrorInvalidValue;   // 32-bit element index in the scan queue
     hipError_t e = hipMemsetAsync(p.counts, 0, (size_t)p.B * p.C * sizeof(int), s);

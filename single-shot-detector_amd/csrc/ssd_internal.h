@@ -97,7 +97,8 @@ hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int 
                              const float *beta, int act, float *out, hipStream_t s);
 hipError_t launch_depthwise(const float *in, int B, int H, int W, int C, const float *w /*[9][C]*/,
                             int stride, int pad, int OH, int OW, const float *mean, const float *sf,
-                            const float *beta, int act, float *out, hipStream_t s, int out16 = 0 /* 1: S16 rows */);
+                            const float *beta, int act, float *out, hipStream_t s, int out16 = 0 /* 1: S16 rows */,
+                            int *flags = nullptr /* out16: bit 0 set when a value left the fp16 range */);
 hipError_t launch_maxpool(const float *in, int B, int H, int W, int C, float *out, hipStream_t s);
 // out[r][j] = (tab[2j]==0 ? x : y)[r][tab[2j+1]] (0 if tab[2j] < 0); tab is device memory
 hipError_t launch_gather_channels(const float *x, int xs, const float *y, int ys, long long rows, const int *tab,

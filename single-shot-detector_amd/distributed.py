@@ -51,16 +51,29 @@ def gather_records(rec, group=None):
     return out
 
 
-def all_gather_detections(boxes, labels, scores, num, group=None):
-    """Every rank contributes the records of its B_local images (equal on all ranks) and
-    receives all world_size*B_local records in rank order."""
+def all_gather_detections(boxes, labels, scores, num, group=None, total=None):
+    """Every rank contributes the records of its B_local images and receives all records in
+    rank order.  `total` = the global image count when the shards are uneven
+    (shard_range(total, rank, world)): the records are padded to the largest shard for the ONE
+    all-gather (fixed-size operands) and the pad rows are dropped afterwards."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return boxes, labels, scores, num
-    return unpack_detections(gather_records(pack_detections(boxes, labels, scores, num), group))
+    world = dist.get_world_size(group)
+    rec = pack_detections(boxes, labels, scores, num)
+    if total is None or total % world == 0:
+        return unpack_detections(gather_records(rec, group))
+    per = -(-total // world)
+    if rec.shape[0] > per:
+        raise ValueError("shard of %d images exceeds ceil(%d / %d)" % (rec.shape[0], total, world))
+    pad = torch.zeros((per, rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    pad[:rec.shape[0]] = rec
+    got = gather_records(pad, group).reshape(world, per, rec.shape[1])
+    rows = [got[r, :shard_range(total, r, world)[1] - shard_range(total, r, world)[0]] for r in range(world)]
+    return unpack_detections(torch.cat(rows, 0))
 
 
-def detect_sharded(engine, images_local, group=None):
+def detect_sharded(engine, images_local, group=None, total=None):
     """One data-parallel step: this rank's shard through the HIP path, then the all-gather.
-    images_local: uint8 CUDA tensor [B_local,H,W,3]."""
+    images_local: uint8 CUDA tensor [B_local,H,W,3]; `total`: see all_gather_detections."""
     boxes, labels, scores, num = engine.forward(images_local)
-    return all_gather_detections(boxes, labels, scores, num, group=group)
+    return all_gather_detections(boxes, labels, scores, num, group=group, total=total)

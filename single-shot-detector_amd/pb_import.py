@@ -9,7 +9,7 @@ present).  Field numbers are those of tensorflow/core/framework/{graph,node_def,
 tensor,tensor_shape}.proto (TF r1.12, third-party, not vendored by the reference).
 
 No pretrained .pb is reachable offline; tests/test_host.py round-trips a synthetic GraphDef
-written by `write_frozen_graph` below (same wire format, plus non-Const nodes to skip).
+written by tests/helpers/pb_writer.py (same wire format, plus non-Const nodes to skip).
 """
 import struct
 
@@ -153,56 +153,3 @@ def load_pb_weights(path_or_bytes, params):
             raise ValueError("Const %r has shape %s dtype %s, expected %s float32" % (name, a.shape, a.dtype, shape))
         W[name] = np.ascontiguousarray(a)
     return W
-
-
-# ----------------------------------------------------------------------------- writer (tests)
-def _enc_varint(v):
-    out = bytearray()
-    v &= (1 << 64) - 1
-    while True:
-        b = v & 0x7F
-        v >>= 7
-        if v:
-            out.append(b | 0x80)
-        else:
-            out.append(b)
-            return bytes(out)
-
-
-def _ld(fn, payload):
-    return _enc_varint((fn << 3) | 2) + _enc_varint(len(payload)) + payload
-
-
-def _vi(fn, v):
-    return _enc_varint(fn << 3) + _enc_varint(v)
-
-
-def write_frozen_graph(weights, path=None, extra_nodes=True, use_float_val=()):
-    """Serialises {name: float32 ndarray} as a GraphDef of Const nodes (plus, like a real frozen
-    graph, `name/read` Identity nodes and a Placeholder that carry no tensor)."""
-    out = bytearray()
-    if extra_nodes:
-        ph = _ld(1, b"images") + _ld(2, b"Placeholder") + _ld(5, _ld(1, b"dtype") + _ld(2, _vi(6, 4)))
-        out += _ld(1, ph)
-    for name, arr in weights.items():
-        a = np.ascontiguousarray(arr, dtype="<f4")
-        shape = b"".join(_ld(2, _vi(1, d)) for d in a.shape)
-        if name in use_float_val:
-            payload = _ld(5, a.tobytes())                               # packed float_val
-        else:
-            payload = _ld(4, a.tobytes())                               # tensor_content
-        tensor = _vi(1, DT_FLOAT) + _ld(2, shape) + payload
-        node = (_ld(1, name.encode()) + _ld(2, b"Const") +
-                _ld(5, _ld(1, b"dtype") + _ld(2, _vi(6, DT_FLOAT))) +
-                _ld(5, _ld(1, b"value") + _ld(2, _ld(8, tensor))))
-        out += _ld(1, node)
-        if extra_nodes:
-            ident = (_ld(1, (name + "/read").encode()) + _ld(2, b"Identity") + _ld(3, name.encode()) +
-                     _ld(5, _ld(1, b"T") + _ld(2, _vi(6, DT_FLOAT))))
-            out += _ld(1, ident)
-    out += _ld(4, _vi(1, 26))                                           # GraphDef.versions.producer
-    data = bytes(out)
-    if path is not None:
-        with open(path, "wb") as f:
-            f.write(data)
-    return data

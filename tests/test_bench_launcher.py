@@ -1,0 +1,49 @@
+"""`python bench.py --gpus N` must work as typed: the launcher starts torch.distributed.run as a child
+process before anything touches the GPU.  Here the same launcher + step loop + all-gather run on CPU
+(gloo, world size 2) with a stand-in engine; even and uneven shards."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB = os.path.join(ROOT, "tests", "helpers", "bench_stub_main.py")
+
+
+def run(args):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, STUB] + args, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout           # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra,total,shards", [([], 6, [[0, 3], [3, 6]]), (["--global-batch", "5"], 5, [[0, 3], [3, 5]])])
+def test_self_launch_world2_gloo(extra, total, shards):
+    res = run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "3"] + extra)
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == [0, 1]
+    assert res["config"]["global_batch"] == total and res["config"]["shards"] == shards
+    assert res["steps"] == 2 and res["warmup"] == 1 and res["scaling"] == "weak"
+    assert res["value"] > 0 and abs(res["value"] - total * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"]
+    assert res["precision"] == "f32" and res["dtype"] == "f32"          # the reference's arithmetic is the headline
+
+
+def test_single_rank_needs_no_launcher():
+    res = run(["--steps", "1", "--warmup", "0", "--batch", "2"])
+    assert res["n_gpus"] == 1 and res["ranks_seen"] == [0] and res["config"]["global_batch"] == 2
+
+
+def test_bench_refuses_without_gpu():
+    # the product bench has no CPU path: without a HIP device it must stop, not fall back
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)

@@ -34,6 +34,17 @@ def _worker(rank, world, port, q):
         for a, b in zip(out, exp):
             ok &= bool(torch.equal(a[r * B:(r + 1) * B], b))
     ok &= out[0].shape == (world * B, T, 4) and out[3].dtype == torch.int32
+    # uneven shards (5 images over 2 ranks = 3 + 2): padded to the largest shard for the one all-gather
+    lo5, hi5 = ssd_amd.shard_range(5, rank, world)
+    mine5 = tuple(t[:hi5 - lo5] for t in _records(rank, B, T))
+    out5 = ssd_amd.all_gather_detections(*mine5, total=5)
+    ok &= out5[0].shape == (5, T, 4)
+    row = 0
+    for r in range(world):
+        l5, h5 = ssd_amd.shard_range(5, r, world)
+        for a, b in zip(out5, _records(r, B, T)):
+            ok &= bool(torch.equal(a[row:row + h5 - l5], b[:h5 - l5]))
+        row += h5 - l5
     lo, hi = ssd_amd.shard_range(7, rank, world)
     q.put((rank, ok, lo, hi))
     dist.destroy_process_group()

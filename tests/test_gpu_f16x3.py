@@ -393,7 +393,7 @@ def test_f16x3_batch_independence_full_size(cuda, ssd):
     tile computes it: the first 32 images of a 70-image batch (two sub-batch plans: the 2 GiB rule) and of a 33-image
     batch give the bits of the 32-image batch, at the bench's size, in mode f16x3."""
     import bench
-    Wt = ssd.synthetic_weights(bench.PARAMS, seed=0, logits_bias=bench.LOGITS_BIAS)
+    Wt = ssd.synthetic_weights(bench.PARAMS, seed=0, logits_bias=bench.LOGITS_BIAS["mobilenet"])
     eng = ssd.Engine(bench.PARAMS, Wt, precision="f16x3")
     g = cuda.Generator().manual_seed(7)
     frames = cuda.randint(0, 256, (70, bench.H, bench.W, 3), dtype=cuda.uint8, generator=g).cuda()

@@ -6,6 +6,9 @@ import sys
 import numpy as np
 import pytest
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers.pb_writer import write_frozen_graph  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
@@ -165,7 +168,7 @@ def test_detector_drop_in(cuda, ssd, oracle_graph, tmp_path):
     with pytest.raises(FileNotFoundError):
         ssd.Detector(str(tmp_path / "nope.npz"))
     # the reference's own container: a frozen GraphDef (.pb), read without TensorFlow
-    ssd.write_frozen_graph(Wt, str(tmp_path / "model.pb"))
+    write_frozen_graph(Wt, str(tmp_path / "model.pb"))
     det_pb = ssd.Detector(str(tmp_path / "model.pb"))
     b3, l3, s3 = det_pb(img, score_threshold=0.2)
     assert np.array_equal(b3, boxes) and np.array_equal(l3, labels) and np.array_equal(s3, scores)

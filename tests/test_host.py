@@ -4,7 +4,12 @@ import os
 import re
 
 import numpy as np
+import sys
+
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers.pb_writer import write_frozen_graph  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -61,17 +66,17 @@ def test_frozen_graph_reader(ssd, tmp_path):
          "iou_threshold": 0.5, "max_boxes_per_class": 5, "min_dimension": 128}
     W = ssd.synthetic_weights(p, seed=4)
     names = list(W)
-    data = ssd.write_frozen_graph(W, str(tmp_path / "model.pb"), use_float_val=set(names[::7]))
+    data = write_frozen_graph(W, str(tmp_path / "model.pb"), use_float_val=set(names[::7]))
     consts = ssd.read_frozen_graph(str(tmp_path / "model.pb"))
     assert set(W) <= set(consts) and "images" not in consts
     L = ssd.load_pb_weights(data, p)
     assert set(L) == set(W) and all(np.array_equal(W[k], L[k]) and L[k].dtype == np.float32 for k in W)
-    pref = ssd.write_frozen_graph({"import/" + k: v for k, v in list(W.items())[:3]}, extra_nodes=False)
+    pref = write_frozen_graph({"import/" + k: v for k, v in list(W.items())[:3]}, extra_nodes=False)
     assert set(ssd.read_frozen_graph(pref)) == set(names[:3])
     broken = dict(W)
     del broken[names[5]]
     with pytest.raises(KeyError):
-        ssd.load_pb_weights(ssd.write_frozen_graph(broken), p)
+        ssd.load_pb_weights(write_frozen_graph(broken), p)
     with pytest.raises(ValueError):
         ssd.read_frozen_graph(data[:len(data) // 2 + 3])
 
@@ -101,6 +106,15 @@ def test_abi_exports_every_declared_symbol(ssd):
     from importlib import import_module
     sigs = import_module("ssd_amd._lib").SIGNATURES
     assert declared == set(sigs)
+    # diagnostics (ablation kernels, tile overrides, timing entry points) live in libssd_hip_diag.so only
+    dh = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ssd_hip_diag.h")).read(), flags=re.S)
+    diag = set(re.findall(r"\b(ssd_[a-z0-9_]+)\s*\(", dh))
+    assert diag == {"ssd_bench_conv", "ssd_bench_dwpw"} == set(import_module("ssd_amd._lib").DIAG_SIGNATURES)
+    for name in diag:
+        assert not hasattr(lib, name), name + " exported by the shipped library"
+    blob = open(ssd.lib_path(), "rb").read()
+    for switch in (b"SSD_IGEMM16_DBG", b"SSD_BENCH_PRECISION", b"SSD_TS_DUMP"):
+        assert switch not in blob, switch
 
 
 def test_anchors_host_side(ssd, oracle_ops):
