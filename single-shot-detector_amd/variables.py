@@ -99,7 +99,13 @@ def synthetic_weights(params, seed=0, logits_bias=None, head_std=0.01):
     (SURVEY.md 8d config 2).  The two final head convs follow the reference's
     initialisers (box_predictor.py:121-130,148-154): N(0, 0.01) kernels, zero box bias,
     logits bias -log(99) unless `logits_bias` is given (a higher bias makes the random
-    net emit detections, which the NMS parity tests need)."""
+    net emit detections, which the NMS parity tests need).
+    ShuffleNet has no clipping activation and its depthwise layers no activation at all
+    (shufflenet_v2.py:121,131,135), so two corrections keep ITS activations O(1) too (without them
+    c5 reaches 1e4 and the logits a standard deviation of 1e3): the 1x1 after a depthwise layer sees
+    an un-rectified input and is drawn with variance 1/fan_in, and every batch-norm gamma is scaled
+    by 0.9167 = 1/sqrt(E[gamma^2] E[1/var]) (unit gain on average).  Both are applied after the draw:
+    the random stream, and with it every MobileNet weight, is unchanged."""
     rng = np.random.default_rng(seed)
     W = {}
     for name, shape in variable_shapes(params).items():
@@ -120,6 +126,11 @@ def synthetic_weights(params, seed=0, logits_bias=None, head_std=0.01):
         else:
             fan_in = shape[0] * shape[1] * shape[2]
             v = rng.normal(0.0, math.sqrt(2.0 / fan_in), shape)
+        if name.startswith("ShuffleNetV2/"):
+            if name.endswith("conv1x1_after/weights"):
+                v = v / math.sqrt(2.0)
+            elif leaf == "gamma":
+                v = v * 0.9167
         W[name] = np.ascontiguousarray(v, dtype=np.float32)
     return W
 

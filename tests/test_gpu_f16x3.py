@@ -226,7 +226,7 @@ def test_forward_f16x3_small(cuda, ssd, oracle_graph, backbone, H, W, B):
 @pytest.mark.parametrize("cfg,H,W", [("config_mobilenet.json", 640, 896), ("config_shufflenet.json", 640, 640)])
 def test_forward_f16x3_full_size(cuda, ssd, oracle_graph, cfg, H, W):
     params = ssd.load_config(os.path.join(HERE, "golden", cfg))
-    Wt = ssd.synthetic_weights(params, seed=0, logits_bias=-4.0 if "mobile" in cfg else -9.0)
+    Wt = ssd.synthetic_weights(params, seed=0, logits_bias=-4.0)
     img = np.random.default_rng(0).integers(0, 256, (1, H, W, 3), dtype=np.uint8)
     keep = {}
     ref = oracle_graph.forward(img, Wt, params, keep)

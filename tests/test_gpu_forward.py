@@ -123,7 +123,7 @@ def test_forward_vs_oracle_full_size(cuda, ssd, oracle_graph, cfg, H, W):
     """BASELINE config 2 (MobileNet-v1 + FPN + heads at 640x896, batch 1) and config 4's
     network (ShuffleNet-v2 + FPN at 640x640) at full size."""
     params = ssd.load_config(os.path.join(HERE, "golden", cfg))
-    Wt = ssd.synthetic_weights(params, seed=0, logits_bias=-4.0 if "mobile" in cfg else -9.0)
+    Wt = ssd.synthetic_weights(params, seed=0, logits_bias=-4.0)
     img = np.random.default_rng(0).integers(0, 256, (1, H, W, 3), dtype=np.uint8)
     keep = {}
     ref = oracle_graph.forward(img, Wt, params, keep)
