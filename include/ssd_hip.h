@@ -186,8 +186,9 @@ int ssd_depthwise3x3(const float *in_dev, int32_t B, int32_t H, int32_t W, int32
 
 /* depthwise_conv + BN + act followed by the 1x1 conv + BN + act that consumes it, as ONE kernel
  * (the MobileNet block, mobilenet_v1.py:59-67; shufflenet_v2.py:118-137 depthwise -> conv1x1_after):
- * the depthwise result stays in LDS.  'SAME' padding; stride 2 needs even H, W.  Limits of the
- * fused kernel (SSD_ERR_INVALID otherwise): C <= 256, OW and OH*OW multiples of 4. */
+ * the depthwise result stays in LDS (input patches staged by LDS-DMA, channels streamed in slices of
+ * 32: any C, any H x W).  'SAME' padding; stride 2 needs even H, W; every tensor below 2 GiB
+ * (SSD_ERR_INVALID otherwise). */
 int ssd_dw_pw(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t C,
               const float *dw_w_host /* [3,3,C,1] */, int32_t stride, const float *dw_mean_host,
               const float *dw_sf_host, const float *dw_beta_host, int32_t dw_act,

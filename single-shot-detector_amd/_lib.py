@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SOURCES = ["api.hip", "igemm.hip", "igemm16.hip", "dwpw.hip", "elementwise.hip", "postprocess.hip"]
+_SOURCES = ["api.hip", "igemm.hip", "igemm16.hip", "dwpw_stream.hip", "elementwise.hip", "postprocess.hip"]
 _LIB_PATH = os.path.join(_CSRC, "libssd_hip.so")
 _DIAG_PATH = os.path.join(_CSRC, "libssd_hip_diag.so")       # -DSSD_DIAG build, scripts/ only
 _lib = None
@@ -93,6 +93,9 @@ def build(force=False, verbose=False, diag=False):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+            # hipcc 7.2 can drop a kernel's host stub without a diagnostic (csrc/dwpw_stream.hip, note in dma_b): an
+            # undefined symbol must fail the BUILD, not the first import on the GPU box
+            ctypes.CDLL(tmp)
             os.replace(tmp, target)
             with open(stamp, "w") as f:
                 f.write(digest)

@@ -206,7 +206,28 @@ static int upload_bn(DevPool &pool, const BnHost &b, ConvW &cw)
     return pool.upload(&cw.beta, b.beta);
 }
 
-struct DwW { float *w = nullptr, *mean = nullptr, *sf = nullptr, *beta = nullptr; int Cp = 0; };
+struct DwW {
+    float *w = nullptr, *mean = nullptr, *sf = nullptr, *beta = nullptr;
+    float *pack = nullptr;      // [Cp/32][12][32]: per 32-channel slice 9 taps, mean, sf, beta (dwpw_stream.hip); Cp % 32 == 0 only
+    int Cp = 0;
+};
+
+// slice-major copy of a depthwise layer's parameters for the streaming fused kernel
+static int pack_dw(DevPool &pool, const std::vector<float> &w9, const std::vector<float> &mean, const std::vector<float> &sf,
+                   const std::vector<float> &beta, DwW &d)
+{
+    if (d.Cp % 32) return SSD_OK;
+    const int KC = d.Cp / 32;
+    std::vector<float> p((size_t)KC * 12 * 32);
+    for (int s = 0; s < KC; ++s)
+        for (int c = 0; c < 32; ++c) {
+            for (int t = 0; t < 9; ++t) p[((size_t)s * 12 + t) * 32 + c] = w9[(size_t)t * d.Cp + s * 32 + c];
+            p[((size_t)s * 12 + 9) * 32 + c] = mean[s * 32 + c];
+            p[((size_t)s * 12 + 10) * 32 + c] = sf[s * 32 + c];
+            p[((size_t)s * 12 + 11) * 32 + c] = beta[s * 32 + c];
+        }
+    return pool.upload(&d.pack, p);
+}
 
 // ----------------------------------------------------------------------------- ops
 struct Op {
@@ -449,7 +470,8 @@ static int load_dw(ssd_handle *h, const std::string &scope, const std::string &b
     SSDCHK(get_bn(h, scope + "/" + bnname, C, map, b));
     SSDCHK(h->wpool.upload(&d.mean, b.mean));
     SSDCHK(h->wpool.upload(&d.sf, b.sf));
-    return h->wpool.upload(&d.beta, b.beta);
+    SSDCHK(h->wpool.upload(&d.beta, b.beta));
+    return pack_dw(h->wpool, t, b.mean, b.sf, b.beta, d);
 }
 
 static int load_first(ssd_handle *h, const std::string &scope, const std::string &bnname, int Cout)
@@ -844,41 +866,48 @@ static Op make_dw_op(const DwW &d, const float *in, int B, int H, int W, int str
     return op;
 }
 
-// depthwise + pointwise in one launch (dwpw.hip) when the shapes allow it
-static bool dwpw_eligible(const DwW &d, const ConvW &cw, int B, int H, int W, int stride)
-{
-    const int OH = H / stride, OW = W / stride;
-    if (cw.taps != 1 || d.Cp != cw.CinP || d.Cp > 256 || !cw.mean || cw.bias) return false;
-    if (OW % 4 != 0 || (OH * OW) % 4 != 0) return false;
-    if ((long long)B * H * W * d.Cp * 4 >= (1LL << 31) || (long long)B * OH * OW * cw.CoutP * 4 >= (1LL << 31)) return false;
-    const int shape = cw.CoutP <= 64 ? DWPW_128x64 : DWPW_64x128;
-    return cw.CoutPad % dwpw_tile_bn(shape) == 0;
-}
-
 // depthwise -> pointwise pair: one fused launch when `fuse` and the shapes allow, else two kernels through `mid`
 static void push_dw_pw(std::vector<Op> &ops, bool fuse, const DwW &d, const ConvW &cw, const float *in, float *mid,
                        float *out, int B, int H, int W, int stride, int dact, int act, int Cl);
 
-static Op make_dwpw_op(const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact,
-                       int act, float *out)
+// depthwise + pointwise on the streaming kernel (dwpw_stream.hip): any K % 32 == 0, any image size.  omap / out_bytes:
+// per-channel destination map (ShuffleNet: concat_shuffle_split folded into the stores), else a dense [M][CoutP] output.
+static bool dwpws_eligible(const DwW &d, const ConvW &cw, int B, int H, int W, int stride)
 {
-    DwPwArgs a;
+    const int OH = H / stride, OW = W / stride;
+    if (cw.taps != 1 || d.Cp != cw.CinP || d.Cp % 32 != 0 || !d.pack || !cw.mean || cw.bias) return false;
+    if ((stride != 1 && stride != 2) || (stride == 2 && ((H | W) & 1))) return false;
+    if ((long long)B * H * W * d.Cp * 4 >= (1LL << 31) || (long long)B * OH * OW * cw.CoutP * 4 >= (1LL << 31)) return false;
+    return (cw.CoutP + dwpws_tile_n(stride, cw.CoutP) - 1) / dwpws_tile_n(stride, cw.CoutP) <= 64;
+}
+
+static Op make_dwpws_op(const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact, int act,
+                        float *out, const int *omap = nullptr, long long out_bytes = 0, int rs0 = 0, int rs1 = 0)
+{
+    DwPwSArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = in; a.wdw = d.w; a.dmean = d.mean; a.dsf = d.sf; a.dbeta = d.beta;
-    a.wt = cw.wt; a.mean = cw.mean; a.sf = cw.sf; a.beta = cw.beta; a.out = out;
+    a.in = in; a.dwpack = d.pack; a.wt = cw.wt; a.mean = cw.mean; a.sf = cw.sf; a.beta = cw.beta; a.out = out; a.omap = omap;
     a.B = B; a.H = H; a.W = W; a.K = d.Cp; a.OH = H / stride; a.OW = W / stride;
-    a.Cout = cw.CoutP; a.CoutPad = cw.CoutPad;
+    a.Cout = cw.CoutP; a.wt_rows = cw.CoutPad;
     a.pad = stride == 1 ? 1 : 0;
     a.dact = dact; a.act = act;
-    const int shape = cw.CoutP <= 64 ? DWPW_128x64 : DWPW_64x128;
-    a.n_tiles_n = cw.CoutPad / dwpw_tile_bn(shape);
-    a.M = B * a.OH * a.OW;
+    const int TY = stride == 1 ? 8 : 4, BN = dwpws_tile_n(stride, cw.CoutP);
+    a.tiles_y = (a.OH + TY - 1) / TY; a.tiles_x = (a.OW + 7) / 8;
+    a.m_tiles = B * a.tiles_y * a.tiles_x;
+    a.n_tiles = (cw.CoutP + BN - 1) / BN;
+    const long long dense = (long long)B * a.OH * a.OW * cw.CoutP * 4;
+    a.out_bytes = (int)(omap ? out_bytes : dense);
+    a.rs0 = rs0; a.rs1 = rs1;
     a.ts = g_dbg_ts;
+#ifdef SSD_DIAG
+    if (const char *e = getenv("SSD_DWPWS_ABL")) a.abl = atoi(e);
+#endif
     Op op;
     op.cls = 6;
-    op.flops = (2.0 * 9 * cw.Cin_l + 2.0 * cw.Cin_l * cw.Cout_l) * (double)a.M;
-    op.bytes = ((double)B * H * W * cw.Cin_l + (double)a.M * cw.Cout_l) * 4.0 + (double)cw.Cin_l * cw.Cout_l * 4.0;
-    op.run = [a, shape, stride](hipStream_t s) { return launch_dwpw(shape, stride, a, s); };
+    const double M = (double)B * a.OH * a.OW;
+    op.flops = (2.0 * 9 * cw.Cin_l + 2.0 * cw.Cin_l * cw.Cout_l) * M;
+    op.bytes = ((double)B * H * W * cw.Cin_l + M * cw.Cout_l) * 4.0 + (double)cw.Cin_l * cw.Cout_l * 4.0;
+    op.run = [a, stride](hipStream_t s) { return launch_dwpw_stream(stride, a, s); };
     return op;
 }
 
@@ -899,8 +928,8 @@ static void push_dw_pw(std::vector<Op> &ops, bool fuse, const DwW &d, const Conv
                        float *out, int B, int H, int W, int stride, int dact, int act, int Cl)
 {
     const int OH = H / stride, OW = W / stride;
-    if (fuse && in != out && dwpw_eligible(d, cw, B, H, W, stride)) {
-        ops.push_back(make_dwpw_op(d, cw, in, B, H, W, stride, dact, act, out));
+    if (fuse && in != out && dwpws_eligible(d, cw, B, H, W, stride)) {
+        ops.push_back(make_dwpws_op(d, cw, in, B, H, W, stride, dact, act, out));
         return;
     }
     ops.push_back(make_dw_op(d, in, B, H, W, stride, dact, mid, Cl));
@@ -949,6 +978,10 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             }
         }
         // depthwise -> pointwise pairs that run as one launch (bit i = Conv2d_{i+1}); SSD_FUSE_DW overrides
+        // (streaming kernel: every pair in mode f32; in mode f16x3 Conv2d_5..13 keep their f16x3 pointwise products)
+        // Measured with the streaming kernel (B = 32, mode f32, one box): masks 0xf / 0x1f / 0x3f / 0x1fff -> 770.7 / 769.4 /
+        // 765.4 / 758.9 img/s: from Conv2d_6 on the pointwise product is MFMA-bound, the exact-fp32 MFMA and the depthwise
+        // VALU work do not overlap on a SIMD, and the two-kernel pair wins.
         unsigned fuse_mask = SSD_FUSE_DW_DEFAULT;
         if (const char *e = getenv("SSD_FUSE_DW")) fuse_mask = (unsigned)strtoul(e, nullptr, 0);
         std::vector<Op> half_ops[4];
@@ -988,7 +1021,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 const int s = MB_STRIDE[i];
                 float *dwo = (cur == X) ? Y : X;
                 const ConvW &cw = h->pw[i];
-                const bool fuse = ((fuse_mask >> i) & 1) && dwpw_eligible(h->dw[i], cw, nb, ch, cwid, s);
+                const bool fuse = ((fuse_mask >> i) & 1) && dwpws_eligible(h->dw[i], cw, nb, ch, cwid, s);
                 // f16x3: an unfused pair hands the depthwise result (exact fp32, in [0, 6]) to its pointwise
                 // convolution in split-fp16 rows, and the pointwise product runs as 3 x f16 MFMA
                 const int pw16 = X16 && !fuse && (h->dw[i].Cp % 32 == 0) ? 1 : 0;
@@ -1003,7 +1036,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                     pwo = fuse ? dwo : ((dwo == X) ? Y : X);    // fused: input `cur` is live until the launch ends
                 }
                 if (fuse)
-                    ops.push_back(make_dwpw_op(h->dw[i], cw, cur, nb, dh, dwid, s, SSD_ACT_RELU6, SSD_ACT_RELU6, pwo));
+                    ops.push_back(make_dwpws_op(h->dw[i], cw, cur, nb, dh, dwid, s, SSD_ACT_RELU6, SSD_ACT_RELU6, pwo));
                 else   // c5 feeds only the FPN (lateral5, p6): in f16x3 mode it is written in split-fp16 rows
                     ops.push_back(make_conv_op(cw, dwo, pwo, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU6,
                                                {dense_level(ch, cwid, ch, cwid, cw.CoutP)}, true, pw16, (i == 12 && X16) ? 1 : 0, 0, h->flags_dev));
@@ -1057,8 +1090,72 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             // unit_1
             const ConvW &before = h->pw[ipw], &after = h->pw[ipw + 1], &after2 = h->pw[ipw + 2];
             const DwW &d1 = h->dw[idw], &d2 = h->dw[idw + 1];
-            ipw += 3; idw += 2;
             const int Dp = after.CoutP, D = after.Cout_l;
+            // ---- concat_shuffle_split (shufflenet_v2.py:94-115) and the stage concat (:89) FOLDED into the stores of the
+            // convolutions that produce the channels: every 1x1 of the stage runs on the streaming depthwise+pointwise
+            // kernel, whose epilogue stores channel by channel through a destination map.  A channel is traced from its
+            // producer (unit_1's two branches, or unit j's conv1x1_after) through the shuffles to the ONE place that
+            // consumes it -- input channel k of a later unit's conv1x1_before (buffer X'_u, standard physical position
+            // of k, so that convolution's k order is untouched and the result stays bit-identical), or channel c of the
+            // stage output -- and is written there directly.  No shuffle, split or concat kernel runs.
+            {
+                const int n_units = units[st], Cc = round_up(2 * D, 32);
+                const long long xbytes = rows * Dp * 4, sbytes = rows * Cc * 4;
+                const long long total = xbytes * (n_units - 1) + sbytes;
+                bool ok = sn_fuse && total < (1LL << 31) && (D & 1) == 0 &&
+                          dwpws_eligible(d1, after, B, ch, cwid, 2) && dwpws_eligible(d2, after2, B, ch, cwid, 2);
+                for (int j = 2; ok && j <= n_units; ++j)
+                    ok = dwpws_eligible(h->dw[idw + j], h->pw[ipw + 3 + 2 * (j - 2) + 1], B, oh, ow, 1);
+                if (ok) {
+                    float *stage, *t1, *U;
+                    SSDCHK(falloc(&stage, total / 4));
+                    HIPCHK(hipMemset(stage, 0, (size_t)total));       // pad channels are never written: they stay zero
+                    SSDCHK(falloc(&t1, (long long)B * ch * cwid * before.CoutP));
+                    SSDCHK(falloc(&U, rows * Dp));
+                    // buffer u (2..n) at (u - 2) * xbytes, the stage output at (n - 1) * xbytes
+                    struct Src { int prod, col; };
+                    std::vector<Src> x(D), y(D);
+                    for (int d = 0; d < D; ++d) { x[d] = Src{0, d}; y[d] = Src{1, d}; }      // producer 0: second branch (x), 1: main branch (y)
+                    std::vector<std::vector<int>> omap(n_units + 1, std::vector<int>(Dp, -1));
+                    auto place = [&](const Src &v, long long off, int physcol, int sel) {
+                        omap[v.prod][ssd_phys_of_logical(v.col)] = (int)(off + (long long)physcol * 4) | sel;
+                    };
+                    for (int j = 2; j <= n_units; ++j) {
+                        std::vector<Src> z(2 * D);
+                        for (int d = 0; d < D; ++d) { z[2 * d] = x[d]; z[2 * d + 1] = y[d]; }
+                        for (int k = 0; k < D; ++k) place(z[k], (long long)(j - 2) * xbytes, ssd_phys_of_logical(k), 0);
+                        for (int d = 0; d < D; ++d) { x[d] = Src{j, d}; y[d] = z[D + d]; }
+                    }
+                    const long long soff = (long long)(n_units - 1) * xbytes;
+                    for (int c = 0; c < 2 * D; ++c) place(c < D ? x[c] : y[c - D], soff, ssd_phys_of_logical(c), 1);
+                    std::vector<const int *> omap_dev(n_units + 1, nullptr);
+                    for (int p = 0; p <= n_units; ++p) {
+                        int *dv;
+                        SSDCHK(ap.upload(&dv, omap[p]));
+                        omap_dev[p] = dv;
+                    }
+                    const int rs0 = Dp * 4, rs1 = Cc * 4;
+                    pl.ops.push_back(make_conv_op(before, cur, t1, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+                                                  {dense_level(ch, cwid, ch, cwid, before.CoutP)}, true));
+                    pl.ops.push_back(make_dwpws_op(d1, after, t1, B, ch, cwid, 2, SSD_ACT_NONE, SSD_ACT_RELU, stage, omap_dev[1], total, rs0, rs1));
+                    pl.ops.push_back(make_dwpws_op(d2, after2, cur, B, ch, cwid, 2, SSD_ACT_NONE, SSD_ACT_RELU, stage, omap_dev[0], total, rs0, rs1));
+                    for (int j = 2; j <= n_units; ++j) {
+                        const ConvW &b2 = h->pw[ipw + 3 + 2 * (j - 2)], &a2 = h->pw[ipw + 3 + 2 * (j - 2) + 1];
+                        const DwW &dd = h->dw[idw + j];
+                        const float *xin = stage + (long long)(j - 2) * (xbytes / 4);
+                        pl.ops.push_back(make_conv_op(b2, xin, U, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU, {dense_level(oh, ow, oh, ow, Dp)}, true));
+                        pl.ops.push_back(make_dwpws_op(dd, a2, U, B, oh, ow, 1, SSD_ACT_NONE, SSD_ACT_RELU, stage, omap_dev[j], total, rs0, rs1));
+                    }
+                    float *S = stage + soff / 4;
+                    if (st == 0) { C3 = S; pl.retained["c3"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
+                    if (st == 1) { C4 = S; pl.retained["c4"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
+                    ipw += 3 + 2 * (n_units - 1); idw += 2 + (n_units - 1);
+                    cur = S;
+                    ch = oh; cwid = ow;
+                    continue;
+                }
+            }
+            ipw += 3; idw += 2;
             float *t1, *t2, *t3, *Xa, *Xb, *Ya, *Yb, *U, *V;
             SSDCHK(falloc(&t1, (long long)B * ch * cwid * before.CoutP));
             SSDCHK(falloc(&t2, rows * d1.Cp));
@@ -1755,20 +1852,21 @@ extern "C" int ssd_dw_pw(const float *in_dev, int32_t B, int32_t H, int32_t W, i
                 if (map[p] >= 0) wt[(size_t)t * Cp + p] = dw_w_host[(size_t)t * C + map[p]];
         for (int p : map) { m.push_back(p < 0 ? 0.f : dw_mean[p]); sf.push_back(p < 0 ? 0.f : dw_sf[p]); be.push_back(p < 0 ? 0.f : dw_beta[p]); }
         SSDCHK(pool.upload(&d.w, wt)); SSDCHK(pool.upload(&d.mean, m)); SSDCHK(pool.upload(&d.sf, sf)); SSDCHK(pool.upload(&d.beta, be));
+        SSDCHK(pack_dw(pool, wt, m, sf, be, d));
         ConvW cw;
         SSDCHK(pack_conv(pool, pw_w_host, 1, C, Cout, map, outmap, cw));
         BnHost b;
         for (int p : outmap) { b.mean.push_back(p < 0 ? 0.f : pw_mean[p]); b.sf.push_back(p < 0 ? 0.f : pw_sf[p]); b.beta.push_back(p < 0 ? 0.f : pw_beta[p]); }
         SSDCHK(upload_bn(pool, b, cw));
-        if (!dwpw_eligible(d, cw, B, H, W, stride))
-            return fail(SSD_ERR_INVALID, "ssd_dw_pw: shape not supported by the fused kernel (C <= 256 after padding, OW and OH*OW multiples of 4)");
+        if (!dwpws_eligible(d, cw, B, H, W, stride))
+            return fail(SSD_ERR_INVALID, "ssd_dw_pw: shape not supported by the fused kernel (every tensor below 2 GiB, stride 2 needs even H and W)");
         const int OH = H / stride, OW = W / stride;
         float *tin, *tout;
         const long long rin = (long long)B * H * W, rout = (long long)B * OH * OW;
         SSDCHK(pool.alloc((void **)&tin, (size_t)rin * Cp * 4));
         SSDCHK(pool.alloc((void **)&tout, (size_t)rout * CoutP * 4));
         HIPCHK(launch_permute_channels(in_dev, rin, C, Cp, 1, tin, s));
-        Op op = make_dwpw_op(d, cw, tin, B, H, W, stride, dw_act, pw_act, tout);
+        Op op = make_dwpws_op(d, cw, tin, B, H, W, stride, dw_act, pw_act, tout);
         HIPCHK(op.run(s));
         HIPCHK(launch_permute_channels(tout, rout, Cout, CoutP, 0, out_dev, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -1994,6 +2092,7 @@ extern "C" int ssd_bench_dwpw(int32_t B, int32_t H, int32_t W, int32_t C, int32_
         std::vector<float> wt((size_t)9 * Cp), m(Cp, 0.01f), sf(Cp, 1.01f), be(Cp, 0.02f);
         for (auto &v : wt) v = rnd();
         SSDCHK(pool.upload(&d.w, wt)); SSDCHK(pool.upload(&d.mean, m)); SSDCHK(pool.upload(&d.sf, sf)); SSDCHK(pool.upload(&d.beta, be));
+        SSDCHK(pack_dw(pool, wt, m, sf, be, d));
         std::vector<float> w((size_t)C * Cout);
         for (auto &v : w) v = rnd() * 0.1f;
         ConvW cw;
@@ -2013,21 +2112,16 @@ extern "C" int ssd_bench_dwpw(int32_t B, int32_t H, int32_t W, int32_t C, int32_
             HIPCHK(hipMemcpy(in, hin.data(), hin.size() * 4, hipMemcpyHostToDevice));
         }
         std::vector<Op> ops;
-        long long *ts = nullptr;
-        long long nblk = 0;
-        if (fused) {
-            if (!dwpw_eligible(d, cw, B, H, W, stride)) return fail(SSD_ERR_INVALID, "ssd_bench_dwpw: shape not supported by the fused kernel");
-            ops.push_back(make_dwpw_op(d, cw, in, B, H, W, stride, SSD_ACT_RELU6, SSD_ACT_RELU6, out));
+        if (fused == 1) {          // the streaming kernel (dwpw_stream.hip)
+            if (!dwpws_eligible(d, cw, B, H, W, stride)) return fail(SSD_ERR_INVALID, "ssd_bench_dwpw: shape not supported by the streaming kernel");
+            ops.push_back(make_dwpws_op(d, cw, in, B, H, W, stride, SSD_ACT_RELU6, SSD_ACT_RELU6, out));
+        } else if (fused) {
+            return fail(SSD_ERR_INVALID, "ssd_bench_dwpw: fused must be 0 (two kernels) or 1 (dwpw_stream.hip)");
         } else {
             ops.push_back(make_dw_op(d, in, B, H, W, stride, SSD_ACT_RELU6, mid, C));
             ops.push_back(make_conv_op(cw, mid, out, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU6, {dense_level(OH, OW, OH, OW, CoutP)}, true));
         }
         const char *dump = getenv("SSD_TS_DUMP");
-        if (fused && dump) {   // per-block phase timestamps of one extra launch -> $SSD_TS_DUMP (int64[nblk][5])
-            const int shape = cw.CoutP <= 64 ? DWPW_128x64 : DWPW_64x128;
-            nblk = (long long)((B * OH * OW + dwpw_tile_bm(shape) - 1) / dwpw_tile_bm(shape)) * (cw.CoutPad / dwpw_tile_bn(shape));
-            SSDCHK(pool.alloc((void **)&ts, (size_t)nblk * 5 * 8));
-        }
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0));
         HIPCHK(hipEventCreate(&e1));
@@ -2041,14 +2135,17 @@ extern "C" int ssd_bench_dwpw(int32_t B, int32_t H, int32_t W, int32_t C, int32_
         *avg_ms = ms / reps;
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
-        if (ts) {
-            g_dbg_ts = ts;
-            Op op = make_dwpw_op(d, cw, in, B, H, W, stride, SSD_ACT_RELU6, SSD_ACT_RELU6, out);
+        if (fused == 1 && dump) {   // phase cycle totals of one extra launch of the streaming kernel -> $SSD_TS_DUMP (int64[512][8])
+            long long *t8 = nullptr;
+            SSDCHK(pool.alloc((void **)&t8, 512 * 8 * 8));
+            HIPCHK(hipMemset(t8, 0, 512 * 8 * 8));
+            g_dbg_ts = t8;
+            Op op = make_dwpws_op(d, cw, in, B, H, W, stride, SSD_ACT_RELU6, SSD_ACT_RELU6, out);
             g_dbg_ts = nullptr;
             HIPCHK(op.run(nullptr));
             HIPCHK(hipDeviceSynchronize());
-            std::vector<long long> hts((size_t)nblk * 5);
-            HIPCHK(hipMemcpy(hts.data(), ts, hts.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<long long> hts(512 * 8);
+            HIPCHK(hipMemcpy(hts.data(), t8, hts.size() * 8, hipMemcpyDeviceToHost));
             if (FILE *f = fopen(dump, "wb")) { fwrite(hts.data(), 8, hts.size(), f); fclose(f); }
         }
         return SSD_OK;

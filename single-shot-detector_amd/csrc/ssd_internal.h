@@ -71,24 +71,28 @@ hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStre
 #define IGEMM16_TILE 100
 hipError_t launch_igemm16(const IgemmArgs &a, int total_tiles_m, hipStream_t s);
 
-// depthwise 3x3 (+BN+act) -> pointwise 1x1 (+BN+act) fused (dwpw.hip) ------------------------
-struct DwPwArgs {
-    const float *in;                       // [B,H,W,K] depthwise input, physical channel order
-    const float *wdw;                      // [9][K] depthwise weights
-    const float *dmean, *dsf, *dbeta;      // [K] depthwise batch norm
-    const float *wt;                       // [CoutPad][K] pointwise weights (igemm B layout, taps = 1)
-    const float *mean, *sf, *beta;         // [CoutPad] pointwise batch norm
-    float *out;                            // [B,OH,OW,Cout]
-    int B, H, W, K, OH, OW, Cout, CoutPad;
+// depthwise -> pointwise, K streamed in 32-channel slices, LDS-DMA staged input patches (dwpw_stream.hip) ----------
+struct DwPwSArgs {
+    const float *in;                       // [B,H,W,K] depthwise input, physical channel order, K % 32 == 0
+    const float *dwpack;                   // [K/32][12][32]: per slice 9 taps, mean, sf, beta of the depthwise layer
+    const float *wt;                       // [wt_rows][K] pointwise weights (igemm B layout, taps = 1), wt_rows >= Cout
+    const float *mean, *sf, *beta;         // [>= Cout] pointwise batch norm
+    float *out;                            // base of the destination(s)
+    const int *omap;                       // nullable: per physical output channel n < Cout the byte offset of that channel in
+                                           // row 0 relative to `out` (a multiple of 4) | row-stride selector in bit 0 (rs0 / rs1),
+                                           // or -1 = not stored.  Null: dense [M][Cout] output.
+    int rs0, rs1;                          // omap: the two row strides in bytes
+    int B, H, W, K, OH, OW, Cout, wt_rows; // Cout: physical output channels (incl. pad channels inside octets)
     int pad;                               // depthwise pad_beg (1 for stride 1, 0 for stride 2 on even sizes)
     int dact, act;                         // activation after the depthwise / the pointwise batch norm
-    int n_tiles_n, M;                      // CoutPad / tile width, B*OH*OW
-    long long *ts;                         // diagnostics: per-block phase timestamps [nblk][5], else null
+    int tiles_y, tiles_x, m_tiles, n_tiles;// output tiles per image (8x8 or 4x8 positions), B*tiles_y*tiles_x, ceil(Cout / BN)
+    int out_bytes;                         // extent of the destination allocation from `out` (buffer range check)
+    long long *ts;                         // diagnostics build only: per-block phase cycle totals [blocks][8], else null
+    int abl;                               // diagnostics build only: timing-ablation mask (results wrong), else 0
 };
-enum DwPwShape { DWPW_128x64 = 0, DWPW_64x128 = 1 };   // rows x output channels per block
-int dwpw_tile_bm(int shape);
-int dwpw_tile_bn(int shape);
-hipError_t launch_dwpw(int shape, int stride, const DwPwArgs &a, hipStream_t s);
+int dwpws_tile_m(int stride);
+int dwpws_tile_n(int stride, int CoutP);
+hipError_t launch_dwpw_stream(int stride, const DwPwSArgs &a, hipStream_t s);
 
 // elementwise / memory-bound kernels -----------------------------------------------------
 // source image [B,srcH,srcW,3] is NN-resized to [nh,nw], zero padded to [H,W] (even), normalised and convolved

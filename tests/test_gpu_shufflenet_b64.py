@@ -93,6 +93,26 @@ def test_shufflenet_640_batch64_saturated_logits(cuda, ssd, precision):
     e16.close()
 
 
+def test_shufflenet_forward_has_no_shuffle_or_concat_launches(cuda, ssd):
+    """SURVEY 8(f) row 1, second half: concat_shuffle_split (shufflenet_v2.py:94-115) and the stage concat (:89) are
+    folded into the producing convolutions' stores (dwpw_stream.hip, destination map).  Profile class `other` counts the
+    max pool and every standalone shuffle / concat launch: exactly ONE launch (the max pool) per forward remains, and every
+    depthwise layer runs inside the fused kernel (class `depthwise` empty: 19 depthwise layers in 19 fused launches)."""
+    params = ssd.load_config(os.path.join(HERE, "golden", "config_shufflenet.json"))
+    Wt = ssd.synthetic_weights(params, seed=0, logits_bias=-4.0)
+    eng = ssd.Engine(params, Wt)
+    img = cuda.from_numpy(np.random.default_rng(3).integers(0, 256, (2, 256, 256, 3), dtype=np.uint8)).cuda()
+    eng.forward(img)
+    eng.profile_reset()
+    eng.profile_enable(True)
+    eng.forward(img)
+    eng.profile_enable(False)
+    prof = eng.profile_read()
+    assert prof["other"]["launches"] == 1, prof["other"]
+    assert prof["depthwise"]["launches"] == 0 and prof["depthwise_pointwise_fused"]["launches"] == 19, prof
+    eng.close()
+
+
 def _scaled(Wt, name, factor):
     out = dict(Wt)
     out[name] = Wt[name] * np.float32(factor)

@@ -122,12 +122,24 @@ DWPW_CASES = [
     (3, 4, 4, 24, 58, 1, None, "relu"),             # ShuffleNet unit: odd channels, no act after dw, M tail
     (1, 8, 8, 116, 116, 2, None, "relu"),           # ShuffleNet down-sampling branch
 ]
+# K > 256 (Conv2d_6..13), sizes that the kernel's 8x8 / 4x8 position tiles do not divide (20x28, 10x14, 5x7 ...), odd
+# sizes, several tiles per block and several n-tiles
+DWPW_STREAM_CASES = [
+    (2, 20, 28, 512, 512, 1, "relu6", "relu6"),     # Conv2d_7..11 at 640x896 / 2: 16 slices, ragged tiles, 4 n-tiles
+    (1, 20, 28, 512, 1024, 2, "relu6", "relu6"),    # Conv2d_12: stride 2, 8 n-tiles
+    (1, 10, 14, 1024, 1024, 1, "relu6", "relu6"),   # Conv2d_13: 32 slices
+    (3, 9, 13, 96, 192, 1, "relu6", "relu"),        # odd sizes, width 192 = 1.5 n-tiles
+    (2, 18, 6, 64, 24, 2, None, None),              # narrow output, no activations, OW = 3
+    (5, 40, 56, 32, 64, 1, "relu6", "relu6"),       # many tiles per block sequence (persistent loop), BN = 64
+    (1, 80, 80, 64, 58, 1, None, "relu"),           # ShuffleNet Stage2 unit at 640x640
+]
 
 
-@pytest.mark.parametrize("case", DWPW_CASES, ids=[str(i) for i in range(len(DWPW_CASES))])
+@pytest.mark.parametrize("case", DWPW_CASES + DWPW_STREAM_CASES, ids=[str(i) for i in range(len(DWPW_CASES) + len(DWPW_STREAM_CASES))])
 def test_dw_pw_fused(cuda, ssd, oracle_ops, case):
+    # dwpw_stream.hip: LDS-DMA staged input patches, K streamed in 32-channel slices
     B, H, W, C, Cout, stride, dact, pact = case
-    rng = np.random.default_rng(500 + DWPW_CASES.index(case))
+    rng = np.random.default_rng(500 + (DWPW_CASES + DWPW_STREAM_CASES).index(case))
     x = rng.standard_normal((B, H, W, C)).astype(np.float32)
     wd = rng.standard_normal((3, 3, C, 1)).astype(np.float32)
     wp = (rng.standard_normal((1, 1, C, Cout)) * np.sqrt(2.0 / C)).astype(np.float32)
@@ -145,10 +157,10 @@ def test_dw_pw_fused(cuda, ssd, oracle_ops, case):
 
 
 def test_dw_pw_unsupported_shapes_fail_loudly(cuda, ssd):
-    x = cuda.zeros((1, 6, 6, 32), dtype=cuda.float32, device="cuda")       # OW = 6 is not a multiple of 4
+    x = cuda.zeros((1, 7, 6, 32), dtype=cuda.float32, device="cuda")       # stride 2 on an odd height
     bn32 = (np.zeros(32, np.float32), np.ones(32, np.float32), np.zeros(32, np.float32))
     with pytest.raises(ssd.SsdError):
-        ssd.ssd.dw_pw(x, np.zeros((3, 3, 32, 1), np.float32), 1, bn32, None, np.zeros((1, 1, 32, 32), np.float32), bn32, None)
+        ssd.ssd.dw_pw(x, np.zeros((3, 3, 32, 1), np.float32), 2, bn32, None, np.zeros((1, 1, 32, 32), np.float32), bn32, None)
 
 
 @pytest.mark.parametrize("B,H,W,C,stride,act", [(2, 20, 28, 32, 1, "relu6"), (1, 40, 56, 64, 2, "relu6"),
