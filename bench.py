@@ -256,12 +256,23 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
                          "carried as split-fp16 pairs, 3 f16 MFMAs per product, fp32 accumulation -- NOT the reference's "
                          "arithmetic (it does not guarantee identical box indices).  The line reports the other mode beside "
                          "`value` (other_precision)")
+    ap.add_argument("--config", choices=["mobilenet", "shufflenet"], default="mobilenet",
+                    help="mobilenet (default) = BASELINE.json's metric: config_mobilenet.json at 640x896.  shufflenet = BASELINE config 4 "
+                         "(config_shufflenet.json, 640x640, default --batch 64) as the line's workload: for profiling that network "
+                         "alone; the default run already carries it as the shufflenet_config4 object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-shufflenet", action="store_true", help="skip the config-4 object (N = 1 only anyway)")
     ap.add_argument("--no-other-precision", action="store_true")
     args = ap.parse_args(argv)
     argv = list(sys.argv[1:] if argv is None else argv)
+    net = args.config
+    params = PARAMS if net == "mobilenet" else PARAMS_SHUFFLE
+    Hh, Ww = (H, W) if net == "mobilenet" else (640, 640)
+    if net == "shufflenet":
+        if "--batch" not in " ".join(argv):
+            args.batch = 64
+        args.no_latency = args.no_shufflenet = args.no_cpu_baseline = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # nothing has touched the GPU yet (importing torch / ssd_amd does not)
@@ -293,12 +304,12 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
 
     B = args.batch
     total = args.global_batch or B * world
-    Wt = ssd_amd.synthetic_weights(PARAMS, seed=0, logits_bias=LOGITS_BIAS["mobilenet"])
-    engine = engine_factory(PARAMS, Wt, local) if stub else ssd_amd.Engine(PARAMS, Wt, device=local, precision=args.precision)
+    Wt = ssd_amd.synthetic_weights(params, seed=0, logits_bias=LOGITS_BIAS[net])
+    engine = engine_factory(params, Wt, local) if stub else ssd_amd.Engine(params, Wt, device=local, precision=args.precision)
     # this rank's shard of the global batch, resident in HBM before the timed region
     lo, hi = ssd_amd.shard_range(total, rank, world)
     g = torch.Generator().manual_seed(1234 + rank)
-    frames = torch.randint(0, 256, (hi - lo, H, W, 3), dtype=torch.uint8, generator=g).to(dev)
+    frames = torch.randint(0, 256, (hi - lo, Hh, Ww, 3), dtype=torch.uint8, generator=g).to(dev)
     timed = Timed(world, dist, sync, dev)
 
     def step():
@@ -352,7 +363,8 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         res = {
-            "metric": "images/sec at 896x640, MobileNet-v1 RetinaNet (whole hot path incl. decode + per-class NMS)",
+            "metric": ("images/sec at 896x640, MobileNet-v1 RetinaNet (whole hot path incl. decode + per-class NMS)" if net == "mobilenet"
+                       else "images/sec at 640x640, ShuffleNet-v2 RetinaNet (BASELINE config 4; NOT BASELINE.json's headline metric)"),
             "value": total * args.steps / dt, "unit": "img/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -360,13 +372,15 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
             "precision": args.precision, "status_word": status_value,
             "data": "synthetic" if not stub else "STAND-IN ENGINE (launcher test, no GPU work)",
             "ranks_seen": ranks_seen,
-            "config": {"workload": "MobileNet-v1 + FPN + RetinaNet heads + decode + per-class NMS, 640x896 (HxW) "
-                                   "uint8 frames, %d per GPU (BASELINE config 5 shard; config 2 = same graph at batch 1, "
-                                   "see latency_batch1; config 4 = the shufflenet_config4 object)" % B,
-                       "per_gpu_batch": B, "global_batch": total, "height": H, "width": W,
+            "config": {"workload": ("MobileNet-v1 + FPN + RetinaNet heads + decode + per-class NMS, 640x896 (HxW) "
+                                    "uint8 frames, %d per GPU (BASELINE config 5 shard; config 2 = same graph at batch 1, "
+                                    "see latency_batch1; config 4 = the shufflenet_config4 object)" % B) if net == "mobilenet" else
+                                   ("ShuffleNet-v2 1.0x + FPN + RetinaNet heads + decode + per-class NMS, 640x640 uint8 frames, "
+                                    "%d per GPU (BASELINE config 4)" % B),
+                       "per_gpu_batch": B, "global_batch": total, "height": Hh, "width": Ww,
                        "shards": [list(ssd_amd.shard_range(total, r, world)) for r in range(world)],
                        "parallelism": "dp%d" % world,
-                       "weights": "random-init (seed 0), logits bias %.1f" % LOGITS_BIAS["mobilenet"],
+                       "weights": "random-init (seed 0), logits bias %.1f" % LOGITS_BIAS[net],
                        "detections_per_image": det_per_image},
         }
         if not stub:
@@ -375,7 +389,7 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
             res["kernel_ms_per_step"], res["kernel_rates"] = ms, rates
             res["pcie_inclusive_img_s_per_gpu"] = pcie_img_s
             # 1.113 ms/img at the per-layer roofline of the exact-fp32 arithmetic
-            res["whole_net_roofline_frac"] = ROOFLINE_MS["mobilenet"] * (hi - lo) / ms_step if args.precision == "f32" else None
+            res["whole_net_roofline_frac"] = ROOFLINE_MS[net] * (hi - lo) / ms_step if args.precision == "f32" else None
             if other_res:
                 res["other_precision"] = other_res
             if not args.no_latency:

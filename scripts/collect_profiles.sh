@@ -1,10 +1,11 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): the round's bench line, the rocprofv3 kernel-trace
 # summary of the same command, and separate PMC passes (HBM traffic, MFMA busy) for it.
-#   usage: bash scripts/collect_profiles.sh <tag>      outputs under gpurun_out/<tag>/
+#   usage: BENCH_ARGS="..." bash scripts/collect_profiles.sh <tag>      outputs under gpurun_out/<tag>/
 R=$GRAFT_REPO_ROOT; TAG=${1:-r01}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
-python3 bench.py --steps 10 --warmup 3 $BENCH_ARGS > $OUT/bench.json 2> $OUT/bench.err
+# BENCH_ARGS selects what the traced / counted runs measure, e.g. "--no-other-precision --no-shufflenet" (mode f32 of the
+# headline workload alone) or "--config shufflenet --no-other-precision" (BASELINE config 4 alone)
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-latency $BENCH_ARGS > $OUT/bench_traced.json 2> $OUT/trace.err
 i=0
@@ -15,5 +16,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency $BENCH_ARGS > $OUT/pmc$i.json 2> $OUT/pmc$i.err
   echo "pmc pass $i rc=$?"
 done
+echo "collected $TAG"
 cd $R
 python3 scripts/summarize_profiles.py $OUT
