@@ -136,7 +136,7 @@ def dominant(prof):
     return k, prof[k]
 
 
-def roofline_block(prof, precision, steps):
+def roofline_block(prof, precision, steps, traffic_key=None):
     """roofline of the dominant kernel class: algorithmic FLOP of its launches / the union of their HIP-event
     intervals on the forward's own streams inside the timed region (ssd_profile_read)."""
     name, c = dominant(prof)
@@ -148,7 +148,7 @@ def roofline_block(prof, precision, steps):
     traffic, src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")    # scripts/collect_profiles.sh: separate --pmc passes
     if os.path.exists(tpath):
-        t = json.load(open(tpath)).get(precision, {})
+        t = json.load(open(tpath)).get(traffic_key or precision, {})
         traffic, src = t.get("hbm_bytes_per_launch"), "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
             "this command, FETCH x2 per the gfx950 correction; a committed measurement, not re-measured in this run): " + str(t.get("source", ""))
     return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
@@ -220,9 +220,7 @@ def shufflenet_leg(local, timed, steps, warmup, batch):
         outs[mode] = [t.clone() for t in out]
         ms, rates = kernel_tables(prof, steps)
         leg = {"value": batch * steps / dt, "unit": "img/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-               "roofline": roofline_block(prof, mode, steps), "kernel_ms_per_step": ms, "kernel_rates": rates}
-        leg["roofline"]["traffic"] = None       # no PMC pass of this workload is committed
-        leg["roofline"]["traffic_source"] = None
+               "roofline": roofline_block(prof, mode, steps, "shufflenet_" + mode), "kernel_ms_per_step": ms, "kernel_rates": rates}
         if mode == "f32":
             leg["whole_net_roofline_frac"] = ROOFLINE_MS["shufflenet"] * batch / (dt / steps * 1e3)
             leg["detections_per_image"] = float(out[3].float().mean().item())
@@ -385,7 +383,7 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
         }
         if not stub:
             ms, rates = kernel_tables(prof, args.steps)
-            res["roofline"] = roofline_block(prof, args.precision, args.steps)
+            res["roofline"] = roofline_block(prof, args.precision, args.steps, None if net == "mobilenet" else "shufflenet_" + args.precision)
             res["kernel_ms_per_step"], res["kernel_rates"] = ms, rates
             res["pcie_inclusive_img_s_per_gpu"] = pcie_img_s
             # 1.113 ms/img at the per-layer roofline of the exact-fp32 arithmetic

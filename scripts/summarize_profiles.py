@@ -60,6 +60,22 @@ def union_ms(intervals):
     return tot / 1e6
 
 
+# kernel_stats.csv again with one more column: the union of each kernel's launch intervals per launch (kernels of the
+# two head towers overlap on two streams: their own average duration counts the shared GPU twice)
+if stats:
+    full = collections.defaultdict(list)
+    for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            full[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    rows = list(csv.DictReader(open(out + "/kernel_stats.csv")))
+    with open(out + "/kernel_stats_union.csv", "w", newline="") as fo:
+        wr = csv.writer(fo)
+        wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "UnionNsPerLaunch"])
+        for r in rows:
+            v = full.get(r["Name"], [])
+            wr.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                         "%.1f" % (union_ms(v) * 1e6 / max(len(v), 1)) if v else ""])
+
 nfwd = max(1, sum(len(v) for k, v in iv.items() if "post_pack" in k))      # one per forward (the backbone may run as two chains)
 c3 = [x for k, v in iv.items() if ("igemm_kernel" in k and ", 9, 0" in k) or "igemm16_kernel<9" in k for x in v]
 class_line = ("all 3x3 igemm kernels (bench.py class conv3x3_mfma): %d launches in %d forwards, union %.3f ms per forward"
