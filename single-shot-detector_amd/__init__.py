@@ -12,8 +12,8 @@ from .variables import (variable_shapes, synthetic_weights, save_weights,   # no
                         load_weights)
 from .pb_import import read_frozen_graph, load_pb_weights             # noqa: F401
 from ._lib import build, lib, lib_path, SsdError                       # noqa: F401
-from .ssd import (SSD, AnchorGenerator, batch_multiclass_non_max_suppression,  # noqa: F401
-                  Engine)
+from .ssd import (SSD, AnchorGenerator, RetinaNetFeatureExtractor, RetinaNetBoxPredictor,     # noqa: F401
+                  batch_multiclass_non_max_suppression, network_input_size, Engine)
 from .detector import Detector                                         # noqa: F401
 from . import coco_eval                                                # noqa: F401
 from .distributed import shard_range, all_gather_detections, detect_sharded  # noqa: F401

@@ -1,7 +1,9 @@
 """COCO val2017 evaluation harness around `Detector` -- the product-side mirror of the
-reference's inference/evaluate_on_COCO.ipynb (cells 6-17).  No COCO images, annotations or
-pycocotools exist offline, so only the record construction is exercised by the tests;
-`evaluate` needs pycocotools and the dataset on disk.
+reference's inference/evaluate_on_COCO.ipynb (cells 6-17) -- and the VOC-style AP@IoU
+self-check of the reference's metrics.py:156-282 (`Evaluator`, `evaluate_detector`).
+No COCO images, annotations or pycocotools exist offline, so the tests exercise the record
+construction and the AP self-check on synthetic data; `evaluate` needs pycocotools and the
+dataset on disk.
 
 Label ids: the detector's integer label i is line i of the reference's data/coco_labels.txt,
 which is the standard 80-name COCO order (COCO_NAMES below); the official category ids come
@@ -68,3 +70,99 @@ def evaluate(detector, annotations_json, images_dir, read_image, predictions_jso
     ev.accumulate()
     ev.summarize()
     return ev.stats
+
+
+# ----------------------------------------------------------------------------- VOC-style AP self-check
+def _iou_matrix(det, gt):
+    """IoU of every detection [n,4] with every groundtruth box [m,4] (ymin, xmin, ymax, xmax) as metrics.py:234-246
+    computes it: 0 unless both the overlap's width and height are positive."""
+    w = np.minimum(det[:, None, 3], gt[None, :, 3]) - np.maximum(det[:, None, 1], gt[None, :, 1])
+    h = np.minimum(det[:, None, 2], gt[None, :, 2]) - np.maximum(det[:, None, 0], gt[None, :, 0])
+    inter = np.where((w > 0) & (h > 0), w * h, 0.0)
+    a_d = (det[:, 3] - det[:, 1]) * (det[:, 2] - det[:, 0])
+    a_g = (gt[:, 3] - gt[:, 1]) * (gt[:, 2] - gt[:, 0])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        iou = inter / (a_d[:, None] + a_g[None, :] - inter)
+    return np.where(inter > 0, iou, 0.0)
+
+
+def average_precision(groundtruth, detections, iou_threshold=0.5):
+    """One class.  Semantics of the reference's `evaluate_detector` (metrics.py:156-213):
+      groundtruth: {image: float array [m,4]};  detections: list of (image, box[4], confidence).
+      * detections are visited in decreasing confidence (stable for ties, like list.sort);
+      * a detection's partner is the groundtruth box of its image with the largest IoU (the FIRST such box when IoUs
+        tie, `iou > max_iou` in `match`, metrics.py:249-264); it is a true positive iff that IoU >= iou_threshold and the
+        box has no earlier partner (a second detection of a matched box is a false positive);
+      * precision[k] = TP / (k+1), recall[k] = TP / max(#groundtruth, 1); AP = sum precision[k] * (recall[k] - recall[k-1])
+        (metrics.py:274-282); best threshold = the confidence maximising P*R*(1 - |P - R|) (:216-231).
+    Returns the reference's seven values."""
+    num_gt = max(sum(len(b) for b in groundtruth.values()), 1)
+    conf = np.array([d[2] for d in detections], dtype=np.float64)
+    order = np.argsort(-conf, kind="stable")
+    matched = {img: np.zeros(len(b), bool) for img, b in groundtruth.items()}
+    tp = np.zeros(len(detections), bool)
+    iou_sum = 0.0
+    for k, di in enumerate(order):
+        img, box, _c = detections[di]
+        gt = groundtruth.get(img)
+        if gt is None or len(gt) == 0:
+            continue
+        iou = _iou_matrix(np.asarray(box, np.float64)[None], np.asarray(gt, np.float64))[0]
+        best = int(np.argmax(iou))                      # first maximum, like the strict `>` scan
+        if iou[best] > 0 and iou[best] >= iou_threshold and not matched[img][best]:
+            matched[img][best] = True
+            tp[k] = True
+            iou_sum += float(iou[best])
+    ctp = np.cumsum(tp)
+    n = np.arange(1, len(detections) + 1)
+    precision = ctp / np.maximum(n, 1)
+    recall = ctp / num_gt
+    ap = float(np.sum(precision * np.diff(np.concatenate([[0.0], recall])))) if len(detections) else 0.0
+    if len(detections):
+        best_i = int(np.argmax(precision * recall * (1.0 - np.abs(precision - recall))))
+        best = (float(conf[order][best_i]), float(precision[best_i]), float(recall[best_i]))
+    else:
+        best = (0.0, 0.0, 0.0)
+    ntp = int(ctp[-1]) if len(detections) else 0
+    return {"AP": ap, "precision": best[1], "recall": best[2], "best_threshold": best[0],
+            "mean_iou_for_TP": iou_sum / max(ntp, 1), "total_FP": len(detections) - ntp, "total_FN": num_gt - ntp}
+
+
+class Evaluator:
+    """Mirror of metrics.py:15-131 without the TF plumbing: detections and groundtruth are kept per label, `evaluate`
+    returns the per-label metrics and, for more than one class, their mean AP under the key 'mAP'."""
+
+    def __init__(self, num_classes):
+        assert num_classes > 0
+        self.num_classes = num_classes
+        self.initialize()
+
+    def initialize(self):
+        self.detections = {label: [] for label in range(self.num_classes)}
+        self.groundtruth = {label: {} for label in range(self.num_classes)}
+        self.unique_image_id = 0
+
+    def add_groundtruth(self, image_name, boxes, labels):
+        for box, label in zip(np.asarray(boxes, np.float64).reshape(-1, 4), np.asarray(labels).reshape(-1)):
+            self.groundtruth[int(label)].setdefault(image_name, []).append(box)
+
+    def add_detections(self, image_name, boxes, labels, scores):
+        for box, label, score in zip(np.asarray(boxes, np.float64).reshape(-1, 4), np.asarray(labels).reshape(-1),
+                                     np.asarray(scores).reshape(-1)):
+            self.detections[int(label)].append((image_name, box, float(score)))
+
+    def add_image(self, gt_boxes, gt_labels, boxes, labels, scores):
+        """One image's groundtruth and the detector's (already num_boxes-trimmed) outputs: `update_op_func`, metrics.py:55-59."""
+        name = str(self.unique_image_id)
+        self.unique_image_id += 1
+        self.add_groundtruth(name, gt_boxes, gt_labels)
+        self.add_detections(name, boxes, labels, scores)
+
+    def evaluate(self, iou_threshold=0.5):
+        self.metrics = {}
+        for label in range(self.num_classes):
+            gt = {img: np.array(b, np.float64).reshape(-1, 4) for img, b in self.groundtruth[label].items()}
+            self.metrics[label] = average_precision(gt, self.detections[label], iou_threshold)
+        if self.num_classes > 1:
+            self.metrics["mAP"] = float(np.mean([self.metrics[label]["AP"] for label in range(self.num_classes)]))
+        return self.metrics

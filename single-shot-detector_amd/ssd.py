@@ -370,36 +370,93 @@ class Engine:
         return out
 
 
-class SSD:
-    """Mirror of detector/ssd.py:9-69 (inference part).  The reference wires TF graph
-    builders in __init__; here the network has already been assembled inside `engine`, so
-    __init__ runs it on `images` (uint8 [B,H,W,3] CUDA; the /255 of create_pb.py:47 is
-    fused into the first kernel) and exposes the same attributes:
-      .anchors            [num_anchors, 4]                       (ssd.py:31)
-      .raw_predictions    {'encoded_boxes', 'class_predictions'} (ssd.py:37-40)
-      .get_predictions(score_threshold, iou_threshold, max_boxes_per_class)  (ssd.py:42-69)
-    """
+def network_input_size(height, width, min_dimension, divisor=128):
+    """Size of the tensor the network sees for a [height, width] image, and box_scaler: the size arithmetic of
+    resize_keeping_aspect_ratio (pipeline.py:138-194) -- short side -> min_dimension, long side round-half-even of
+    float32(x) * float32(min_dimension / min(h, w)), padded up to a multiple of `divisor`."""
+    scale = np.float32(min_dimension / min(height, width))
+    if height >= width:
+        nh, nw = int(np.rint(np.float32(height) * scale)), int(min_dimension)
+        ph, pw = -(-nh // divisor) * divisor - nh, 0
+    else:
+        nw, nh = int(np.rint(np.float32(width) * scale)), int(min_dimension)
+        pw, ph = -(-nw // divisor) * divisor - nw, 0
+    box_scaler = np.array([nh / (nh + ph), nw / (nw + pw)] * 2, np.float32)
+    return nh + ph, nw + pw, box_scaler
 
-    def __init__(self, images, engine, num_classes=None):
-        torch = _torch()
+
+class RetinaNetFeatureExtractor:
+    """Mirror of detector/feature_extractor.py:10-37: callable, images -> [p3, p4, p5, p6, p7].  The reference builds
+    the backbone + FPN graph here; this build has ONE fused plan behind `engine`, so the call runs the engine's forward
+    on `images` (uint8 [B,H,W,3] CUDA; the /255 and 2x-1 of create_pb.py:47 / mobilenet_v1.py:34 are inside the first
+    kernel) and returns the retained pyramid tensors of that forward, NHWC float32 on the device."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def __call__(self, images):
+        B, H, W, _ = images.shape
+        self.outputs = self.engine.forward(images)
+        nh, nw, _bs = network_input_size(H, W, self.engine.params["min_dimension"])
+        self.image_size = (nh, nw)
+        return [self.engine.get_tensor_dev("p%d" % l, (B, -(-nh // s), -(-nw // s), 256)) for l, s in zip(range(3, 8), (8, 16, 32, 64, 128))]
+
+
+class RetinaNetBoxPredictor:
+    """Mirror of detector/box_predictor.py:11-64: callable, image_features -> {'encoded_boxes' [B,N,4],
+    'class_predictions' [B,N,C]}.  The head towers ran in the same plan as the features: the call returns the retained
+    head outputs of the engine's last forward (the one `RetinaNetFeatureExtractor.__call__` just ran)."""
+
+    def __init__(self, engine, num_classes=None):
         self.engine = engine
         self.num_classes = engine.params["num_classes"] if num_classes is None else num_classes
         if self.num_classes != engine.params["num_classes"]:
             raise ValueError("num_classes differs from the engine's configuration")
-        B, H, W, _ = images.shape
-        self._default = engine.forward(images)
-        gen = AnchorGenerator()
-        self.anchors = torch.from_numpy(gen(H, W)).to(images.device)
-        self.num_anchors_per_feature_map = gen.num_anchors_per_feature_map
-        N = self.anchors.shape[0]
-        self.raw_predictions = {
-            "encoded_boxes": engine.get_tensor_dev("encoded_boxes", (B, N, 4)),
-            "class_predictions": engine.get_tensor_dev("class_predictions", (B, N, self.num_classes)),
-        }
+
+    def __call__(self, image_features):
+        B = image_features[0].shape[0]
+        N = sum(int(f.shape[1]) * int(f.shape[2]) * 6 for f in image_features)
+        return {"encoded_boxes": self.engine.get_tensor_dev("encoded_boxes", (B, N, 4)),
+                "class_predictions": self.engine.get_tensor_dev("class_predictions", (B, N, self.num_classes))}
+
+
+class SSD:
+    """Mirror of detector/ssd.py:9-69 (inference part), with the reference's constructor:
+
+        SSD(images, feature_extractor, anchor_generator, box_predictor, num_classes)      (ssd.py:10)
+
+    `feature_extractor` / `box_predictor` are the two mirrors above (bound to one Engine), `anchor_generator` an
+    AnchorGenerator.  As in the reference, the anchors are generated for the size of the tensor the NETWORK sees
+    (ssd.py:25-31 reads it from the images tensor, which in the serving graph is already resized and padded,
+    create_pb.py:44-47): for raw frames of any size that is network_input_size(H, W), not (H, W).
+    Attributes: .anchors [N,4], .num_anchors_per_feature_map, .raw_predictions; .get_predictions(...) (ssd.py:42-69).
+    Shorthand kept from round 1: SSD(images, engine) builds the three collaborators itself."""
+
+    def __init__(self, images, feature_extractor, anchor_generator=None, box_predictor=None, num_classes=None):
+        torch = _torch()
+        if isinstance(feature_extractor, Engine):
+            engine = feature_extractor
+            feature_extractor = RetinaNetFeatureExtractor(engine)
+            box_predictor = RetinaNetBoxPredictor(engine, num_classes)
+        if anchor_generator is None:
+            anchor_generator = AnchorGenerator()
+        if box_predictor is None:
+            raise TypeError("SSD(images, feature_extractor, anchor_generator, box_predictor, num_classes)")
+        self.engine = feature_extractor.engine
+        self.num_classes = self.engine.params["num_classes"] if num_classes is None else num_classes
+        if self.num_classes != self.engine.params["num_classes"]:
+            raise ValueError("num_classes differs from the engine's configuration")
+        feature_maps = feature_extractor(images)                       # ssd.py:23
+        image_height, image_width = feature_extractor.image_size      # ssd.py:25-29 (the resized, padded size)
+        self.anchors = torch.from_numpy(anchor_generator(image_height, image_width)).to(images.device)     # ssd.py:31
+        self.num_anchors_per_feature_map = anchor_generator.num_anchors_per_feature_map
+        self.raw_predictions = box_predictor(feature_maps)            # ssd.py:37-40
+        self.box_scaler = network_input_size(images.shape[1], images.shape[2], self.engine.params["min_dimension"])[2]
 
     def get_predictions(self, score_threshold=0.05, iou_threshold=0.5, max_boxes_per_class=20):
+        """ssd.py:42-69 (+ the boxes /= box_scaler of model.py:67-68, which the reference applies right after)."""
         boxes, scores, classes, num = batch_multiclass_non_max_suppression(
             self.raw_predictions["encoded_boxes"], self.anchors,
             self.raw_predictions["class_predictions"], score_threshold=score_threshold,
-            iou_threshold=iou_threshold, max_boxes_per_class=max_boxes_per_class)
+            iou_threshold=iou_threshold, max_boxes_per_class=max_boxes_per_class, box_scaler=self.box_scaler)
         return {"boxes": boxes, "labels": classes, "scores": scores, "num_boxes": num}

@@ -144,3 +144,31 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "libssd_oracle" not in src, f
+
+
+def test_voc_ap_self_check_known_answers(ssd):
+    """coco_eval.average_precision / Evaluator restate metrics.py:156-282; answers worked out by hand from those rules."""
+    ce = ssd.coco_eval
+    gt = {"a": np.array([[0.0, 0.0, 1.0, 1.0], [2.0, 2.0, 3.0, 3.0]]), "b": np.array([[0.0, 0.0, 2.0, 2.0]])}
+    dets = [("a", [0.0, 0.0, 1.0, 1.0], 0.9),        # TP (IoU 1)
+            ("a", [0.0, 0.0, 1.0, 0.9], 0.8),        # same box again: already matched -> FP
+            ("b", [0.0, 0.0, 2.0, 1.0], 0.7),        # IoU exactly 0.5 -> TP (>=)
+            ("a", [2.0, 2.0, 3.0, 2.4], 0.6),        # IoU 0.4 -> FP
+            ("c", [0.0, 0.0, 1.0, 1.0], 0.5)]        # image without groundtruth -> FP
+    m = ce.average_precision(gt, dets, 0.5)
+    # precision by rank: 1, 1/2, 2/3, 2/4, 2/5; recall: 1/3, 1/3, 2/3, 2/3, 2/3; AP = 1 * 1/3 + 2/3 * 1/3
+    assert abs(m["AP"] - (1 / 3 + 2 / 9)) < 1e-12
+    assert m["total_FP"] == 3 and m["total_FN"] == 1 and abs(m["mean_iou_for_TP"] - 0.75) < 1e-12
+    # P*R*(1-|P-R|): rank 0: 1/3 * (1 - 2/3) = 1/9; rank 2: 4/9 * 1 = 4/9 -> best threshold 0.7
+    assert m["best_threshold"] == 0.7 and abs(m["precision"] - 2 / 3) < 1e-12 and abs(m["recall"] - 2 / 3) < 1e-12
+    # ties in confidence keep insertion order (list.sort is stable); ties in IoU pick the first groundtruth box
+    gt2 = {"a": np.array([[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 1.0, 1.0]])}
+    m2 = ce.average_precision(gt2, [("a", [0, 0, 1, 1], 0.5), ("a", [0, 0, 1, 1], 0.5)], 0.5)
+    assert m2["AP"] == 0.5 and m2["total_FP"] == 1 and m2["total_FN"] == 1      # both want box 0; box 1 is never matched
+    # no detections, no groundtruth
+    assert ce.average_precision({}, [], 0.5)["AP"] == 0.0
+    ev = ce.Evaluator(3)
+    ev.add_image([[0, 0, 1, 1], [0, 0, 2, 2]], [0, 2], [[0, 0, 1, 1], [0, 0, 2, 2], [5, 5, 6, 6]], [0, 2, 1], [0.9, 0.8, 0.3])
+    ev.add_image([[1, 1, 2, 2]], [0], [[1, 1, 2, 2]], [0], [0.7])
+    out = ev.evaluate()
+    assert out[0]["AP"] == 1.0 and out[2]["AP"] == 1.0 and out[1]["AP"] == 0.0 and abs(out["mAP"] - 2 / 3) < 1e-12
