@@ -1224,8 +1224,11 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     SSDCHK(falloc(&X3, (long long)B * py.h[0] * py.w[0] * 256));
     SSDCHK(falloc(&T6, (long long)B * py.h[3] * py.w[3] * 256));
     auto lvl = [&](int l, int CoutP) { return dense_level(py.h[l], py.w[l], py.h[l], py.w[l], CoutP); };
-    // Two streams, explicit dependencies.  Main: lateral5 -> lateral4 (+up) -> lateral3 (+up) -> p3
-    // (the critical path); second stream: p6 -> p7 (need only c5), p5 (needs x5), p4 (needs x4).
+    // Three streams, explicit dependencies.  Main: lateral5 -> lateral4 (+up) -> lateral3 (+up) -> p3 (the critical
+    // path); second stream: p5 (needs x5) -> p4 (needs x4); third stream: p6 -> p7 (need only c5).  p6 is a chain of
+    // 288 dependent K-steps on a handful of tiles (K = 9 x 1024, M = B x 140): at batch 1 it takes 0.29 ms whatever
+    // the GPU does beside it, so nothing may queue behind it -- with p7, p5, p4 behind it on one stream the head towers
+    // started 0.12 ms later (batch-1 kernel trace, profiles/r02_batch1_timeline.txt).
     // All of them are the same 3x3 kernel, and two such kernels side by side fill each other's
     // tails (measured: paired tower layers run at 0.91 of the MFMA peak, a lone one at 0.85).
     auto push = [&](Op op, int stream, std::vector<int> deps = {}) {
@@ -1241,15 +1244,21 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     std::vector<int> l5_deps;
     for (int c = 1; c < 4; ++c) if (id_bb_last[c] >= 0) l5_deps.push_back(id_bb_last[c]);
     const int id_l5 = push(make_conv_op(h->lat[2], C5, X5, nullptr, nullptr, B, 1, 0, SSD_ACT_NONE, {lvl(2, 256)}, true, X16, X16, 0, FL), 0, l5_deps);
+    // (hipGraph capture of a forward with this third forked stream crashed inside the ROCm 7.2 runtime, and so did a captured
+    //  wait on an event of the waiting stream itself: with SSD_GRAPH=1 p6 -> p7 stay on the second stream, in front of p5
+    //  and p4, as in round 1; enqueue_forward skips same-stream waits)
+    const char *ge = getenv("SSD_GRAPH");
+    const int s6 = ge && atoi(ge) ? 1 : 2;
     std::vector<int> p6_deps = {id_c5};             // c5 of every backbone chain that is not on p6's own stream
-    for (int c = 2; c < 4; ++c) if (id_bb_last[c] >= 0) p6_deps.push_back(id_bb_last[c]);
+    for (int c = 1; c < 4; ++c) if (c != s6 && id_bb_last[c] >= 0) p6_deps.push_back(id_bb_last[c]);
+    int id_p7;
     {   // p6 = conv s2 (c5): BN+ReLU -> P6, ReLU(raw) -> T6 (input of p7, :60)
         LevelDesc d = dense_level(py.h[2], py.w[2], py.h[3], py.w[3], 256);
         d.out_off = py.off[3];
-        push(make_conv_op(h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 1, p6_deps);
+        push(make_conv_op(h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), s6, p6_deps);
         LevelDesc d7 = dense_level(py.h[3], py.w[3], py.h[4], py.w[4], 256);
         d7.out_off = py.off[4];
-        push(make_conv_op(h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true, X16, X16, 0, FL), 1);
+        id_p7 = push(make_conv_op(h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true, X16, X16, 0, FL), s6);
     }
     {   // p5 = conv(x5)
         LevelDesc d = lvl(2, 256);
@@ -1342,12 +1351,12 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         tower_ops[t].push_back(fop);
     }
     // enqueue order interleaved so both hardware queues stay fed.  The first box-tower layer
-    // (main) needs p4..p7 from the second stream, the first class-tower layer (second stream)
-    // needs p3 from the main stream.
+    // (main) needs p4, p5 from the second stream and p6, p7 from the third, the first class-tower layer (second
+    // stream) needs p3 from the main stream and p6, p7 from the third.
     for (size_t i = 0; i < tower_ops[0].size(); ++i)
         for (int t = 1; t >= 0; --t) {
             std::vector<int> deps;
-            if (i == 0) deps.push_back(t == 0 ? id_p4 : id_p3);
+            if (i == 0) { deps.push_back(t == 0 ? id_p4 : id_p3); deps.push_back(id_p7); }
             push(tower_ops[t][i], t, deps);
         }
     // events for every op another stream waits on
@@ -1479,7 +1488,8 @@ static int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxe
             if (!started[op.stream] && op.deps.empty())             // a chain that starts on another stream:
                 HIPCHK(hipStreamWaitEvent(st, pl.ev_begin, 0));     // behind the plan's own start
             started[op.stream] = true;
-            for (int d : op.deps) HIPCHK(hipStreamWaitEvent(st, pl.ops[d].done, 0));
+            for (int d : op.deps)           // (same stream: already ordered -- and a captured self-wait corrupted the ROCm 7.2 graph runtime's heap)
+                if (pl.ops[d].stream != op.stream) HIPCHK(hipStreamWaitEvent(st, pl.ops[d].done, 0));
             HIPCHK(run_op(h, op, st));
             if (op.done) HIPCHK(hipEventRecord(op.done, st));
             if (op.fpn_end) HIPCHK(hipEventRecord(pl.ev_fpn, sm));
