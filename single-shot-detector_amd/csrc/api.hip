@@ -252,7 +252,8 @@ static float conservative_logit_bound(float thr);
 
 static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2, const float *res, int B, int stride,
                        int pad, int act, const std::vector<LevelDesc> &lv, bool dense, int in_fmt = 0, int out_fmt = 0,
-                       int res_fmt = 0, int *flags = nullptr, unsigned *scan_bits = nullptr, float scan_lo = 0.0f)
+                       int res_fmt = 0, int *flags = nullptr, unsigned *scan_bits = nullptr, float scan_lo = 0.0f,
+                       bool *scan_marked = nullptr)
 {
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
@@ -299,6 +300,16 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
             if (scan_bits && biasform) { a.scan_lo = scan_lo; a.scan_bits = scan_bits; }
         }
     }
+    // Exact-fp32 kernel, bias form with 16-byte stores (the class logits): its epilogue marks the candidate octets too, so
+    // the post-processing's scan reads the bitmap instead of every logit in BOTH precision modes (batch 1: 52 -> ~10 us)
+    if (scan_bits && !a.scan_bits && tile != IGEMM16_TILE && !in_fmt && !out_fmt && !out2 && !res && cw.bias && !cw.mean &&
+        act == SSD_ACT_NONE && cw.CoutP % 4 == 0) {
+        bool aligned = true;
+        for (size_t i = 0; i < lv.size(); ++i)
+            if ((lv[i].out_rstride | lv[i].out_bstride | lv[i].out_off) & 3) aligned = false;
+        if (aligned) { a.scan_lo = scan_lo; a.scan_bits = scan_bits; }
+    }
+    if (scan_marked) *scan_marked = a.scan_bits != nullptr;
     a.n_tiles_n = a.CoutPad / (tile == IGEMM16_TILE ? 256 : igemm_tile_bn(tile));
     a.dense_out = dense ? 1 : 0;
     int tiles = 0;
@@ -343,6 +354,8 @@ struct Plan {
     hipStream_t s_aux = nullptr;        // class tower beside the box tower (box_predictor.py:47-59)
     hipStream_t s_bb[2] = {nullptr, nullptr};   // further backbone chains (Op::stream 2, 3)
     hipEvent_t ev_fpn = nullptr, ev_join = nullptr, ev_done = nullptr, ev_begin = nullptr;
+    hipEvent_t ev_join_bb[2] = {nullptr, nullptr};
+    bool tail_on[2] = {false, false};   // the plan's last ops on stream 2 / 3 are not awaited by any later op: join them before the post-processing
     int last_aux = -1;                  // index of the last op on the second stream
 };
 
@@ -406,6 +419,7 @@ static void free_plans(ssd_handle *h)
         if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
         if (pl->ev_done) (void)hipEventDestroy(pl->ev_done);
         if (pl->ev_begin) (void)hipEventDestroy(pl->ev_begin);
+        for (int i = 0; i < 2; ++i) if (pl->ev_join_bb[i]) (void)hipEventDestroy(pl->ev_join_bb[i]);
         delete pl;
     }
     h->plans.clear();
@@ -1318,7 +1332,15 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     for (int k = 0; k < 4; ++k) p.box_scaler[k] = rd.box_scaler[k];    // model.py:67-68
     post_carve(p, ws);
     HIPCHK(hipMemset(p.scan_bits, 0, post_scan_bitmap_bytes(B, (int)N, C)));
-    std::vector<Op> tower_ops[2];
+    // (Measured and not adopted, batch 1: the two coarse levels -- 175 of 11 935 positions -- as launches of their own on a
+    //  third / fourth stream behind p7, so that the towers of levels 3..5 start when p3..p5 exist: 2.12 -> 2.29 ms per forward;
+    //  ten more launches of 72-step chains beside the big ones cost more than the 0.07 ms earlier start.  SSD_LEVEL_SPLIT=1
+    //  keeps the experiment reachable.)
+    const bool split_levels = B <= 2 && s6 == 2 && getenv("SSD_LEVEL_SPLIT") && atoi(getenv("SSD_LEVEL_SPLIT"));
+    const int ngrp = split_levels ? 2 : 1;
+    const int g_lo[2] = {0, 3}, g_hi[2] = {split_levels ? 3 : 5, 5};
+    std::vector<Op> tower_ops[2][2];            // [tower][level group]
+    bool all_marked = true;
     for (int t = 0; t < 2; ++t) {
         float *TA, *TB;
         SSDCHK(falloc(&TA, py.total));
@@ -1326,39 +1348,52 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         const float *in = P;
         float *out = TA;
         for (int i = 0; i < 4; ++i) {
-            std::vector<LevelDesc> lv;
-            for (int l = 0; l < 5; ++l) lv.push_back(dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, py.off[l], py.off[l], l * 256));
-            tower_ops[t].push_back(make_conv_op(h->tower[t][i], in, out, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true, X16, X16, 0, FL));
+            for (int g = 0; g < ngrp; ++g) {
+                std::vector<LevelDesc> lv;
+                for (int l = g_lo[g]; l < g_hi[g]; ++l) lv.push_back(dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, py.off[l], py.off[l], l * 256));
+                tower_ops[t][g].push_back(make_conv_op(h->tower[t][i], in, out, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true, X16, X16, 0, FL));
+            }
             in = out;
             out = (out == TA) ? TB : TA;
         }
         const int per = t == 0 ? 4 : C;     // values per anchor
-        std::vector<LevelDesc> lv;
-        for (int l = 0; l < 5; ++l) {
-            LevelDesc d = dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 0, py.off[l]);
-            d.out_off = aoff[l] * per;
-            d.out_bstride = N * per;
-            d.out_rstride = A * per;
-            d.param_off = 0;
-            lv.push_back(d);
-        }
-        // class logits: when they run on the 256x256-tile kernel its epilogue also marks the octets that hold a
-        // candidate (p.scan_bits) and post_scan_kernel reads the bitmap instead of all logits
+        // class logits: the convolution's epilogue also marks the octets that hold a candidate (p.scan_bits) and
+        // post_scan_kernel reads the bitmap instead of all logits
         const bool can_mark = t == 1 && ((long long)N * C) % 8 == 0 && (6 * C) % 8 == 0;
-        Op fop = make_conv_op(h->final_[t], in, t == 0 ? codes : logits, nullptr, nullptr, B, 1, 1, SSD_ACT_NONE, lv, false, X16, 0, 0, FL,
-                              can_mark ? p.scan_bits : nullptr, conservative_logit_bound(h->cfg.score_threshold));
-        if (t == 1) p.scan_fused = (can_mark && fop.cls == 7) ? 1 : 0;
-        tower_ops[t].push_back(fop);
+        for (int g = 0; g < ngrp; ++g) {
+            std::vector<LevelDesc> lv;
+            for (int l = g_lo[g]; l < g_hi[g]; ++l) {
+                LevelDesc d = dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 0, py.off[l]);
+                d.out_off = aoff[l] * per;
+                d.out_bstride = N * per;
+                d.out_rstride = A * per;
+                d.param_off = 0;
+                lv.push_back(d);
+            }
+            bool marked = false;
+            Op fop = make_conv_op(h->final_[t], in, t == 0 ? codes : logits, nullptr, nullptr, B, 1, 1, SSD_ACT_NONE, lv, false, X16, 0, 0, FL,
+                                  can_mark ? p.scan_bits : nullptr, conservative_logit_bound(h->cfg.score_threshold), &marked);
+            if (t == 1) all_marked = all_marked && marked;
+            tower_ops[t][g].push_back(fop);
+        }
     }
-    // enqueue order interleaved so both hardware queues stay fed.  The first box-tower layer
-    // (main) needs p4, p5 from the second stream and p6, p7 from the third, the first class-tower layer (second
-    // stream) needs p3 from the main stream and p6, p7 from the third.
-    for (size_t i = 0; i < tower_ops[0].size(); ++i)
+    p.scan_fused = all_marked ? 1 : 0;
+    // enqueue order interleaved so the hardware queues stay fed.  The first box-tower layer (main) needs p4, p5 from the
+    // second stream (and, unless the coarse levels run apart, p6, p7 from the third); the first class-tower layer (second
+    // stream) needs p3 from the main stream (and p6, p7).  Coarse-level chains: box on the third stream (behind p7, same
+    // stream), class on the fourth (waits for p7).
+    for (size_t i = 0; i < tower_ops[0][0].size(); ++i)
         for (int t = 1; t >= 0; --t) {
             std::vector<int> deps;
-            if (i == 0) { deps.push_back(t == 0 ? id_p4 : id_p3); deps.push_back(id_p7); }
-            push(tower_ops[t][i], t, deps);
+            if (i == 0) { deps.push_back(t == 0 ? id_p4 : id_p3); if (!split_levels) deps.push_back(id_p7); }
+            push(tower_ops[t][0][i], t, deps);
+            if (split_levels) {
+                std::vector<int> d2;
+                if (i == 0) d2.push_back(id_p7);
+                push(tower_ops[t][1][i], t == 0 ? 2 : 3, d2);
+            }
         }
+    pl.tail_on[0] = pl.tail_on[1] = split_levels;
     // events for every op another stream waits on
     for (const Op &op : pl.ops)
         for (int d : op.deps)
@@ -1451,6 +1486,7 @@ static int make_plans(ssd_handle *h, int B, int H, int W)
         HIPCHK(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&pl->ev_done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&pl->ev_begin, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&pl->ev_join_bb[i], hipEventDisableTiming));
         SSDCHK(build_plan(h, *pl, bk, H, W, img0));
         img0 += bk;
     }
@@ -1499,6 +1535,11 @@ static int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxe
             HIPCHK(hipEventRecord(pl.ev_join, pl.s_aux));
             HIPCHK(hipStreamWaitEvent(sm, pl.ev_join, 0));
         }
+        for (int c = 2; c < 4; ++c)                 // ... and the third / fourth stream, when the plan ends chains there
+            if (pl.tail_on[c - 2]) {
+                HIPCHK(hipEventRecord(pl.ev_join_bb[c - 2], pl.s_bb[c - 2]));
+                HIPCHK(hipStreamWaitEvent(sm, pl.ev_join_bb[c - 2], 0));
+            }
         PostArgs p = pl.post;
         p.boxes = boxes_dev + (size_t)pl.img0 * T * 4;
         p.labels = labels_dev + (size_t)pl.img0 * T;

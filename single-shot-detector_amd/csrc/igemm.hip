@@ -531,6 +531,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
                     if (a.act == 2) v[e] = v[e] < 6.0f ? v[e] : 6.0f;
                 }
                 const unsigned o = (m < M && colok) ? off : OOBS;
+                if constexpr (MODE == 4 && !O16) {
+                    // bias form = the class logits: first half of the post-processing's score filter, here where the logits
+                    // are in registers (as igemm16.hip): mark the octet of 8 consecutive logits that holds a value at or above
+                    // the conservative logit bound; post_scan_kernel then reads the bitmap and the marked octets only
+                    if (a.scan_bits && o != OOBS) {
+                        const float mx = __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), __builtin_fmaxf(v[2], v[3]));
+                        if (mx >= a.scan_lo) {
+                            const unsigned oct = ((unsigned)L.out_off + (o >> 2)) >> 3;      // octet index in [B][N][C]
+                            atomicOr(a.scan_bits + (oct >> 5), 1u << (oct & 31));
+                        }
+                    }
+                }
                 if constexpr (O16) {
                     v2u hi, lo;
                     split_f16(v, hi, lo, ovf);

@@ -198,10 +198,54 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v)
 #define NMS_R 8      // candidates per thread kept in registers
 #define NMS_BIG 1024 // threads of the large-list kernel
 
-// K9c, lists of up to 64*NMS_R candidates: one wavefront, everything in registers.
-// keys and boxes are immutable; liveness is one bit per register slot.  (A version that
-// zeroed key[r] under `key == best || iou > thr` was miscompiled by hipcc 7.2: the kill of
-// the IoU branch was dropped -- keep this form branch-free.)
+// Greedy NMS of one (image, class) list by ONE wavefront with R candidates per lane in registers.  keys and boxes are
+// immutable; liveness is one bit per register slot.  (A version that zeroed key[r] under `key == best || iou > thr` was
+// miscompiled by hipcc 7.2: the kill of the IoU branch was dropped -- keep this form branch-free.)
+template <int R>
+__device__ __forceinline__ int nms_one_wave(const PostArgs &p, const u64 *keys, const float *dec, int n, int lane, float *ob, float *os)
+{
+    u64 key[R];
+    v4f box[R];
+    unsigned alive = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        const bool ok = i < n;
+        key[r] = ok ? keys[ok ? i : 0] : 0ull;
+        const unsigned anchor = 0xFFFFFFFFu - (unsigned)(key[r] & 0xFFFFFFFFu);
+        box[r] = *(const v4f *)(dec + (long long)(ok ? anchor : 0u) * 4);
+        alive |= ok ? (1u << r) : 0u;
+    }
+    int kept = 0;
+    while (kept < p.max_per_class) {
+        u64 best = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const u64 k = ((alive >> r) & 1u) ? key[r] : 0ull;
+            best = k > best ? k : best;
+        }
+        best = wave_max_u64(best);
+        if (best == 0) break;
+        const v4f wb = *(const v4f *)(dec + (long long)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFu)) * 4);
+        if (lane == 0) {
+            *(v4f *)(ob + kept * 4) = wb;
+            os[kept] = __uint_as_float((unsigned)(best >> 32));
+        }
+        ++kept;
+        unsigned kill = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool k = (key[r] == best) | iou_greater(box[r], wb, p.iou_thr);
+            kill |= k ? (1u << r) : 0u;
+        }
+        alive &= ~kill;
+    }
+    return kept;
+}
+
+// K9c, lists of up to 64*NMS_R candidates: one wavefront, everything in registers.  (Measured and not adopted: the same wave
+// with 32 candidates per lane for lists of 513 .. 2 048 instead of the 1 024-thread kernel -- batch-1 post-processing 0.22 ->
+// 0.28 ms: 32 IoU tests per lane and round cost more than the block kernel's barrier per round.)
 __global__ __launch_bounds__(64) void post_nms_small_kernel(const PostArgs p)
 {
     const int bc = blockIdx.x;              // b*C + c
@@ -218,43 +262,7 @@ __global__ __launch_bounds__(64) void post_nms_small_kernel(const PostArgs p)
     float *ob = p.cls_boxes + (long long)bc * p.max_per_class * 4;
     float *os = p.cls_scores + (long long)bc * p.max_per_class;
     int kept = 0;
-    if (n > 0) {
-        u64 key[NMS_R];
-        v4f box[NMS_R];
-        unsigned alive = 0;
-#pragma unroll
-        for (int r = 0; r < NMS_R; ++r) {
-            const int i = lane + 64 * r;
-            const bool ok = i < n;
-            key[r] = ok ? keys[ok ? i : 0] : 0ull;
-            const unsigned anchor = 0xFFFFFFFFu - (unsigned)(key[r] & 0xFFFFFFFFu);
-            box[r] = *(const v4f *)(dec + (long long)(ok ? anchor : 0u) * 4);
-            alive |= ok ? (1u << r) : 0u;
-        }
-        while (kept < p.max_per_class) {
-            u64 best = 0;
-#pragma unroll
-            for (int r = 0; r < NMS_R; ++r) {
-                const u64 k = ((alive >> r) & 1u) ? key[r] : 0ull;
-                best = k > best ? k : best;
-            }
-            best = wave_max_u64(best);
-            if (best == 0) break;
-            const v4f wb = *(const v4f *)(dec + (long long)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFu)) * 4);
-            if (lane == 0) {
-                *(v4f *)(ob + kept * 4) = wb;
-                os[kept] = __uint_as_float((unsigned)(best >> 32));
-            }
-            ++kept;
-            unsigned kill = 0;
-#pragma unroll
-            for (int r = 0; r < NMS_R; ++r) {
-                const bool k = (key[r] == best) | iou_greater(box[r], wb, p.iou_thr);
-                kill |= k ? (1u << r) : 0u;
-            }
-            alive &= ~kill;
-        }
-    }
+    if (n > 0) kept = nms_one_wave<NMS_R>(p, keys, dec, n, lane, ob, os);
     if (lane == 0) p.cls_counts[bc] = kept;
 }
 

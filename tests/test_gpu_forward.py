@@ -101,6 +101,23 @@ def test_forward_other_widths_and_class_counts(cuda, ssd, oracle_graph, backbone
     eng.close()
 
 
+def test_coarse_levels_as_their_own_launches(cuda, ssd, oracle_graph, monkeypatch):
+    """SSD_LEVEL_SPLIT=1 (a batch-1 latency experiment that measured slower and is off by default): the
+    head towers of levels 6-7 run as separate launches on the third / fourth stream.  Same bits."""
+    monkeypatch.setenv("SSD_LEVEL_SPLIT", "1")
+    params = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
+              "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
+    Wt = ssd.synthetic_weights(params, seed=12, logits_bias=-4.0)
+    img = np.random.default_rng(6).integers(0, 256, (2, 128, 256, 3), dtype=np.uint8)
+    keep = {}
+    ref = oracle_graph.forward(img, Wt, params, keep)
+    eng = ssd.Engine(params, Wt)
+    out = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(img).cuda())]
+    assert stage_check(eng, keep, STAGES, "level split") == 1.0
+    compare_outputs(out, ref, "coarse levels apart")
+    eng.close()
+
+
 def test_sub_batch_plans(cuda, ssd, oracle_graph, monkeypatch):
     """SSD_NSUB splits a batch into staggered sub-batch plans (uneven split 5 = 2+2+1): same
     results, same retained tensors."""

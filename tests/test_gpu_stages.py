@@ -302,16 +302,20 @@ def test_postprocess_fuzz(cuda, ssd, oracle_ops, seed):
 
 
 def test_postprocess_long_lists(cuda, ssd, oracle_ops, monkeypatch):
-    """Candidate lists longer than the register paths: > 512 (block kernel, registers) and
-    > 8192 (block kernel, keys in global memory); and the block kernel forced on short lists."""
+    """Candidate lists longer than the one-wave path: > 512 (block kernel, registers) and > 8192 (block kernel, keys in
+    global memory); and the block kernel forced on shorter lists."""
     rng = np.random.default_rng(7)
     anc = oracle_ops.anchors(640, 896)
     N = anc.shape[0]
     codes, logits = synth_heads(rng, 2, N, 80, frac=0.001)
     codes *= 0.2
-    logits[0, :3000, 11] = rng.uniform(-1.0, 4.0, 3000).astype(np.float32)       # 512 < n <= 8192
+    logits[0, :3000, 11] = rng.uniform(-1.0, 4.0, 3000).astype(np.float32)       # 512 < n <= 8192: block kernel, registers
+    logits[0, 5000:6400, 12] = rng.uniform(-1.0, 4.0, 1400).astype(np.float32)
+    logits[0, 9000:9600, 13] = 4.0                                                # ... all ties (anchor order decides)
     logits[1, 20000:45000, 42] = rng.uniform(-1.5, 4.0, 25000).astype(np.float32)  # n > 8192
     logits[1, :, 3] = 5.0                                                          # every anchor, all ties
+    run_post(cuda, ssd, oracle_ops, codes, logits, anc)
+    monkeypatch.setenv("SSD_NMS_FAST_MAX", "200")          # a lower hand-over point: same results
     run_post(cuda, ssd, oracle_ops, codes, logits, anc)
     monkeypatch.setenv("SSD_NMS_FAST_MAX", "0")
     codes, logits = synth_heads(rng, 2, N, 80, frac=0.002)
