@@ -273,6 +273,19 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
         long long t128 = 0;
         for (size_t i = 0; i < lv.size(); ++i) t128 += ((long long)B * lv[i].OH * lv[i].OW + 127) / 128;
         if (t128 * (cw.CoutPad / 128) < 2 * 256) tile = IGEMM_64x64;
+        else if (cw.taps == 1 && !in_fmt) {
+            // 1x1 convolutions (8 .. 32 K-steps per tile): a launch is a few rounds of tiles over the 512 block slots and
+            // the last, partly filled round costs a whole tile time.  Estimated time = rounds x tile area / efficiency of the
+            // shape (measured, scripts/bench_conv.py at 16 images: 512->512 at 40x56 128x128 / 128x64 / 64x64 = 0.184 / 0.173 /
+            // 0.180 ms; 1024->1024 at 20x28 0.207 / 0.185 / 0.179 ms).
+            long long t64 = 0;
+            for (size_t i = 0; i < lv.size(); ++i) t64 += ((long long)B * lv[i].OH * lv[i].OW + 63) / 64;
+            const double c128 = ceil((double)t128 * (cw.CoutPad / 128) / 512.0) * 16384.0;
+            const double c12864 = ceil((double)t128 * (cw.CoutPad / 64) / 512.0) * 8192.0 / 0.97;
+            const double c64 = ceil((double)t64 * (cw.CoutPad / 64) / 512.0) * 4096.0 / 0.93;
+            if (c12864 < c128 && c12864 <= c64) tile = IGEMM_128x64;
+            else if (c64 < c128) tile = IGEMM_64x64;
+        }
         // tests: SSD_IGEMM_TILE=128 / 64 pins the choice so both variants see every shape
         if (const char *e = getenv("SSD_IGEMM_TILE")) {
             if (atoi(e) == 128) tile = IGEMM_128x128;
