@@ -273,11 +273,12 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
         long long t128 = 0;
         for (size_t i = 0; i < lv.size(); ++i) t128 += ((long long)B * lv[i].OH * lv[i].OW + 127) / 128;
         if (t128 * (cw.CoutPad / 128) < 2 * 256) tile = IGEMM_64x64;
-        else if (cw.taps == 1 && !in_fmt) {
+        else if (cw.taps == 1 && !in_fmt && cw.CinP >= 256) {    // (K < 256: 2 .. 4 K-steps per tile, epilogue-dominated: left on 128x128)
             // 1x1 convolutions (8 .. 32 K-steps per tile): a launch is a few rounds of tiles over the 512 block slots and
             // the last, partly filled round costs a whole tile time.  Estimated time = rounds x tile area / efficiency of the
             // shape (measured, scripts/bench_conv.py at 16 images: 512->512 at 40x56 128x128 / 128x64 / 64x64 = 0.184 / 0.173 /
-            // 0.180 ms; 1024->1024 at 20x28 0.207 / 0.185 / 0.179 ms).
+            // 0.180 ms; 1024->1024 at 20x28 0.207 / 0.185 / 0.179 ms).  Inside the network, where two backbone chains run side by
+            // side, the step time does not move (A/B on one box: 41.4 / 41.4 ms, ShuffleNet 55.3 / 55.4 ms).
             long long t64 = 0;
             for (size_t i = 0; i < lv.size(); ++i) t64 += ((long long)B * lv[i].OH * lv[i].OW + 63) / 64;
             const double c128 = ceil((double)t128 * (cw.CoutPad / 128) / 512.0) * 16384.0;
