@@ -156,6 +156,34 @@ def test_dw_pw_fused(cuda, ssd, oracle_ops, case):
     assert np.array_equal(got, sep)
 
 
+@pytest.mark.parametrize("shape", [(8, 160, 224, 32, 64, 1), (4, 80, 112, 256, 512, 2), (6, 40, 56, 512, 512, 1), (16, 40, 40, 128, 116, 1)])
+def test_dw_pw_fused_repeatable(cuda, ssd, oracle_ops, shape):
+    """Race screen for the LDS-DMA pipeline of dwpw_stream.hip (patch / weight / B slices are ordered for their readers only by
+    the issuing wave's counted vmcnt wait plus a barrier, two iterations ahead of their use): the same launch repeated must give
+    the same bits, on shapes where a block walks many tiles (persistent loop), with 1, 8 and 16 slices per tile, both strides and
+    both column-tile widths -- and beside another stream that keeps the memory system busy."""
+    B, H, W, C, Cout, stride = shape
+    rng = np.random.default_rng(sum(shape))
+    x = dev(cuda, rng.standard_normal((B, H, W, C)).astype(np.float32))
+    wd = rng.standard_normal((3, 3, C, 1)).astype(np.float32)
+    wp = (rng.standard_normal((1, 1, C, Cout)) * np.sqrt(2.0 / C)).astype(np.float32)
+    g1, b1, m1, v1 = bn_params(rng, C)
+    g2, b2, m2, v2 = bn_params(rng, Cout)
+    bn1, bn2 = (m1, oracle_ops.bn_scale(g1, v1), b1), (m2, oracle_ops.bn_scale(g2, v2), b2)
+    first = ssd.ssd.dw_pw(x, wd, stride, bn1, "relu6", wp, bn2, "relu6")
+    sep = ssd.ssd.conv2d(ssd.ssd.depthwise3x3(x, wd, stride, bn=bn1, act="relu6"), wp, 1, "SAME", bn=bn2, act="relu6")
+    assert cuda.equal(first, sep)
+    side = cuda.cuda.Stream()
+    junk = cuda.empty((64 << 20,), dtype=cuda.float32, device="cuda")
+    for rep in range(20):
+        if rep % 2:
+            with cuda.cuda.stream(side):
+                junk.add_(1.0)                      # 512 MB of traffic beside the kernel
+        again = ssd.ssd.dw_pw(x, wd, stride, bn1, "relu6", wp, bn2, "relu6")
+        assert cuda.equal(first, again), rep
+    cuda.cuda.synchronize()
+
+
 def test_dw_pw_unsupported_shapes_fail_loudly(cuda, ssd):
     x = cuda.zeros((1, 7, 6, 32), dtype=cuda.float32, device="cuda")       # stride 2 on an odd height
     bn32 = (np.zeros(32, np.float32), np.ones(32, np.float32), np.zeros(32, np.float32))
