@@ -1,0 +1,64 @@
+"""-m gpu: INTEGRATION.md section 2 executed as written -- the reference-side binding a maintainer would add in place of
+tf.Session (inference/detector.py:13-34,51-58), with nothing but ctypes + torch (no helper of the package): create / load /
+finalize / forward / filter.  Must give what the package's Detector gives."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class ssd_config(ctypes.Structure):          # include/ssd_hip.h: struct ssd_config
+    _fields_ = [("backbone", ctypes.c_int32), ("depth_multiplier", ctypes.c_float),
+                ("num_classes", ctypes.c_int32), ("score_threshold", ctypes.c_float),
+                ("iou_threshold", ctypes.c_float), ("max_boxes_per_class", ctypes.c_int32),
+                ("min_dimension", ctypes.c_int32), ("device", ctypes.c_int32)]
+
+
+def test_documented_ctypes_binding(cuda, ssd):
+    torch = cuda
+    params = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
+              "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
+    weights = ssd.synthetic_weights(params, seed=4, logits_bias=-4.0)
+    image = np.random.default_rng(4).integers(0, 256, (100, 151, 3), dtype=np.uint8)
+    score_threshold = 0.2
+
+    lib = ctypes.CDLL(os.path.join(ROOT, "single-shot-detector_amd", "csrc", "libssd_hip.so"))
+    lib.ssd_last_error.restype = ctypes.c_char_p
+
+    def check(rc):
+        if rc:
+            raise RuntimeError(ctypes.c_char_p(lib.ssd_last_error()).value.decode())
+
+    h = ctypes.c_void_p()
+    cfg = ssd_config(0, 1.0, 80, 0.15, 0.6, 25, 128, 0)
+    check(lib.ssd_create(ctypes.byref(cfg), ctypes.byref(h)))
+    for name, arr in weights.items():
+        a = np.ascontiguousarray(arr, np.float32)
+        shape = (ctypes.c_int64 * a.ndim)(*a.shape)
+        check(lib.ssd_load_weight(h, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), shape, ctypes.c_int32(a.ndim)))
+    check(lib.ssd_finalize(h))
+    img = torch.from_numpy(image[None]).cuda()
+    T = 80 * 25
+    boxes = torch.empty((1, T, 4), dtype=torch.float32, device="cuda")
+    labels = torch.empty((1, T), dtype=torch.int32, device="cuda")
+    scores = torch.empty((1, T), dtype=torch.float32, device="cuda")
+    num = torch.empty((1,), dtype=torch.int32, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    check(lib.ssd_forward(h, p(img), ctypes.c_int32(1), ctypes.c_int32(img.shape[1]), ctypes.c_int32(img.shape[2]), p(boxes), p(labels),
+                          p(scores), p(num), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    n = int(num.cpu()[0])
+    keep = scores[0, :n].cpu().numpy() > score_threshold                      # inference/detector.py:54-58
+    got = boxes[0, :n].cpu().numpy()[keep], labels[0, :n].cpu().numpy()[keep], scores[0, :n].cpu().numpy()[keep]
+    # errors come back as codes + text, nothing throws across the ABI
+    assert lib.ssd_forward(h, None, 1, 1, 1, None, None, None, None, None) != 0 and b"null" in lib.ssd_last_error()
+    lib.ssd_destroy.argtypes = [ctypes.c_void_p]
+    lib.ssd_destroy(h)
+
+    want = ssd.Detector(weights, config=params)(image, score_threshold=score_threshold)
+    assert len(want[0]) > 0
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
