@@ -81,13 +81,19 @@ class Detector:
     def __call__(self, image, score_threshold=0.1):
         """
         Arguments:
-            image: a numpy uint8 array with shape [height, width, 3] (RGB).
+            image: a numpy uint8 array with shape [height, width, 3] (RGB), or the path of an image file.
             score_threshold: a float number.
         Returns:
             boxes: a float numpy array of shape [N, 4] (ymin, xmin, ymax, xmax!).
             labels: an int numpy array of shape [N].
             scores: a float numpy array of shape [N].
         """
+        if isinstance(image, (str, os.PathLike)):
+            # BASELINE.json's north star words the API as Detector(image_path): a path is read the way the reference's
+            # notebooks read it (inference/just_try_detector.ipynb: PIL, RGB) and then takes the ndarray route
+            from PIL import Image
+            with Image.open(image) as im:
+                image = np.asarray(im.convert("RGB"), dtype=np.uint8)
         image = np.asarray(image)
         if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
             raise ValueError("image must be a uint8 array of shape [height, width, 3]")

@@ -182,6 +182,11 @@ def test_detector_drop_in(cuda, ssd, oracle_graph, tmp_path):
         assert np.array_equal(l2, r2[1]) and len(l2) > 0, shape
         assert np.abs(s2 - r2[2]).max() <= TOL and np.abs(b2 - r2[0]).max() <= TOL, shape
         assert np.array_equal(b2, r2[0]) and np.array_equal(s2, r2[2]), shape
+    # an image path instead of an array (north star: Detector(image_path)): read with PIL as the reference's notebooks do
+    from PIL import Image
+    Image.fromarray(img).save(str(tmp_path / "frame.png"))
+    bp, lp, sp = det(str(tmp_path / "frame.png"), score_threshold=0.2)
+    assert np.array_equal(bp, boxes) and np.array_equal(lp, labels) and np.array_equal(sp, scores)
     with pytest.raises(FileNotFoundError):
         ssd.Detector(str(tmp_path / "nope.npz"))
     # the reference's own container: a frozen GraphDef (.pb), read without TensorFlow
