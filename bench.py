@@ -316,7 +316,16 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
     dt, out, prof = timed.run(engine, step, args.steps, args.warmup)
     assert out[0].shape[0] == total, (out[0].shape, total)
     det_per_image = float(out[3].float().mean().item())
-    status_value = engine.status()            # bit 0: an f16x3 activation left the fp16 range (0 in mode f32)
+    def status_all_ranks():
+        """bit 0: an f16x3 activation left the fp16 range on SOME rank since the last call (0 in mode f32)."""
+        v = engine.status()
+        if world > 1:
+            t = torch.tensor([v], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            v = int(t.item())
+        return v
+
+    status_value = status_all_ranks()
 
     # the same workload in the other precision mode, same process, same frames (shorter run)
     other = "f32" if args.precision == "f16x3" else "f16x3"
@@ -325,7 +334,7 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
         engine.set_precision(other)
         n_other = max(3, args.steps // 2)
         dt_o, out_o, prof_o = timed.run(engine, step, n_other, 2)
-        status_other = engine.status()
+        status_other = status_all_ranks()
         # agreement of the two modes on this run's frames (mode f32 is bit-identical to the CPU oracle, tests/)
         agree = {"num_boxes_identical": bool((out_o[3] == out[3]).all().item()),
                  "labels_identical": bool((out_o[1] == out[1]).all().item()),
