@@ -987,7 +987,8 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         // The backbone is a chain of ~30 short, latency-bound kernels (two blocks per CU each waiting for one
         // round of loads).  From 4 images on it runs as two half-batch chains on the plan's two streams, so that
         // one chain's memory phases sit under the other's compute; FPN and heads stay full-batch launches.
-        // Measured (f16x3, same box): +2.1 % at 32 images, +3.8 % at 16, +3.2 % at 8, +4.5 % at 4; mode f32 +0.3 %.
+        // Measured (f16x3, same box): +2.1 % at 32 images, +3.8 % at 16, +3.2 % at 8, +4.5 % at 4; mode f32 (round 2):
+        // +1.3 % at 4, +1.5 % at 8, +0.8 % at 16, none at 32.
         // SSD_BACKBONE_SPLIT=1 keeps one chain.
         int nhalf = B >= 4 ? 2 : 1;
         if (const char *e = getenv("SSD_BACKBONE_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4 && v <= B) nhalf = v; }
