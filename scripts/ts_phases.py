@@ -38,6 +38,7 @@ xcc = t[:, 8] >> 32
 cu = ((hw >> 8) & 0xF) | (((hw >> 13) & 0x7) << 4) | ((xcc & 0xF) << 8)    # CU_ID, SE_ID(+SH), XCC
 ids, cnt = np.unique(cu, return_counts=True)
 print("   %d distinct (xcc, se, cu) ids; blocks per id min %d max %d" % (len(ids), cnt.min(), cnt.max()))
+print("   dispatch order: blocks 0..255 sit on %d distinct CUs, blocks 256..511 on %d" % (len(np.unique(cu[:256])), len(np.unique(cu[256:512]))))
 # gaps between consecutive blocks on the same slot are invisible here; idle estimate per CU:
 busy = []
 for i in ids[:: max(1, len(ids) // 32)]:
@@ -52,3 +53,29 @@ for i in ids[:: max(1, len(ids) // 32)]:
     busy.append([acc[j] / tot for j in range(4)])
 b = np.array(busy).mean(0)
 print("   sampled CUs: time with 0 / 1 / 2 / 3+ resident blocks = %.2f / %.2f / %.2f / %.2f" % tuple(b))
+# is the MFMA pipe of a CU fed?  Fraction of the launch span during which 0 / 1 / 2+ of the CU's resident blocks are inside
+# their K loop (co-resident blocks that start together stay in phase: their prologues and epilogues then coincide)
+t0, t1 = st[:, 0].min(), st[:, 4].max()
+inloop = []
+for i in ids:
+    s = st[cu == i]
+    ev = sorted([(a, 1) for a in s[:, 1]] + [(b_, -1) for b_ in s[:, 2]])
+    depth, last, acc = 0, t0, [0.0, 0.0, 0.0]
+    for tt, dd in ev:
+        acc[min(depth, 2)] += tt - last
+        last = tt
+        depth += dd
+    acc[0] += t1 - last
+    inloop.append([a / (t1 - t0) for a in acc])
+il = np.array(inloop).mean(0)
+print("   all CUs: share of the launch span with 0 / 1 / 2+ resident blocks in their K loop = %.3f / %.3f / %.3f" % tuple(il))
+# phase offset of co-resident blocks: for every block, distance of its start to the nearest start of ANOTHER block on the same CU
+offs = []
+for i in ids:
+    s = np.sort(st[cu == i][:, 0])
+    if len(s) > 1:
+        dn = np.diff(s)
+        offs.extend(np.minimum(np.r_[dn, np.inf], np.r_[np.inf, dn]))
+offs = np.array(offs)
+print("   start-to-nearest-start on the same CU: p10 %.2f  p50 %.2f  p90 %.2f us (mean lifetime %.2f)" %
+      (*np.percentile(offs, [10, 50, 90]), life.mean()))
