@@ -111,6 +111,32 @@ int main(int argc, char **argv)
                             {"Conv2d_7  s1 40x56x512", 40, 56, 512, 1},   {"Conv2d_12 s2 40x56x512", 40, 56, 512, 2},
                             {"Conv2d_13 s1 20x28x1024", 20, 28, 1024, 1}, {"Conv2d_1  s1 320x448x32", 320, 448, 32, 1}};
     const int NBUF = 4, reps = 20;
+    {   // first convolution (uint8 frames 640x896x3 -> 320x448x32, stride 2) of the MobileNet backbone, alone
+        const int H = 640, W = 896, Cout = 32;
+        const long long nimg = (long long)B * H * W * 3, nout = (long long)B * (H / 2) * (W / 2) * Cout;
+        uint8_t *img; float *out[2], *w, *mean, *sf, *beta;
+        hipMalloc(&img, nimg); hipMalloc(&out[0], nout * 4); hipMalloc(&out[1], nout * 4);
+        hipMalloc(&w, 27 * Cout * 4); hipMalloc(&mean, Cout * 4); hipMalloc(&sf, Cout * 4); hipMalloc(&beta, Cout * 4);
+        hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, (float *)img, nimg / 4, 3u);
+        hipLaunchKernelGGL(fill, dim3(16), dim3(256), 0, 0, w, 27LL * Cout, 5u);
+        hipLaunchKernelGGL(fill, dim3(16), dim3(256), 0, 0, mean, (long long)Cout, 6u);
+        hipLaunchKernelGGL(fill, dim3(16), dim3(256), 0, 0, sf, (long long)Cout, 7u);
+        hipLaunchKernelGGL(fill, dim3(16), dim3(256), 0, 0, beta, (long long)Cout, 8u);
+        hipDeviceSynchronize();
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int i = 0; i < 3; ++i) launch_first_conv(img, B, H, W, H, W, H, W, w, Cout, mean, sf, beta, 2, out[i & 1], 0);
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < reps; ++i) launch_first_conv(img, B, H, W, H, W, H, W, w, Cout, mean, sf, beta, 2, out[i & 1], 0);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        ms /= reps;
+        printf("first conv 640x896x3 u8 -> 320x448x32, %d images: %.1f MB in + %.1f MB out: %.1f us, %.2f TB/s\n", B, nimg / 1e6, nout * 4 / 1e6,
+               ms * 1e3, (nimg + nout * 4.0) / (ms * 1e-3) / 1e12);
+        hipFree(img); hipFree(out[0]); hipFree(out[1]); hipFree(w); hipFree(mean); hipFree(sf); hipFree(beta);
+    }
     for (const Shape &s : shapes) {
         const int OH = s.H / s.stride, OW = s.W / s.stride;
         const long long nin = (long long)B * s.H * s.W * s.C, nout = (long long)B * OH * OW * s.C;
@@ -158,7 +184,7 @@ int main(int argc, char **argv)
         hipDeviceSynchronize();
         timeit("copy of the same bytes", [&](const float *i, float *o) {
             hipLaunchKernelGGL(copy_like, dim3(256 * 16), dim3(256), 0, 0, (const v4f *)i, nin / 4, (v4f *)o, nout / 4); }, false);
-        timeit("shipped (1 row x 4 px)", shipped, true);
+        timeit("shipped kernel", shipped, true);
 #define VAR(ST, R, PX, CAP)                                                                                                        \
     if (s.stride == ST)                                                                                                            \
         timeit("R=" #R " PX=" #PX " cap " #CAP, [&](const float *i, float *o) {                                                     \

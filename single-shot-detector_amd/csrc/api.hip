@@ -293,18 +293,6 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
             else if (atoi(e) == 64) tile = IGEMM_64x64;
         }
     }
-    if (const char *e = getenv("SSD_IGEMM_TR")) {        // experiment: transposed accumulators where the epilogue form allows
-        bool ok = atoi(e) != 0 && cw.mean && !out2 && !out_fmt && !in_fmt && !res && !cw.bias && (cw.CoutP & 3) == 0;
-        for (size_t i = 0; i < lv.size() && ok; ++i) ok = ((lv[i].out_rstride | lv[i].out_bstride | lv[i].out_off) & 3) == 0;
-        a.tr = ok ? 1 : 0;
-    }
-    if (const char *e = getenv("SSD_PW_STAGGER")) {      // experiment: 10-ns ticks per slot step, 1x1 launches in mode f32
-        if (cw.taps == 1 && !in_fmt && atoi(e) > 0) {
-            a.stagger_step = atoi(e);
-            a.stagger_slots = tile == IGEMM_128x128 ? 2 : (tile == IGEMM_128x64 ? 3 : (tile == IGEMM_64x64 ? 5 : 0));
-            if (const char *n = getenv("SSD_PW_STAGGER_SLOTS")) a.stagger_slots = atoi(n);
-        }
-    }
     // Large S16 -> S16 batch-norm launches (head towers, FPN outputs at serving batch sizes) take the
     // 256 x 256-tile kernel of igemm16.hip once there are at least two full rounds of tiles for the 256 CUs;
     // SSD_IGEMM16=0 / 1 pins the choice (tests, A/B runs).

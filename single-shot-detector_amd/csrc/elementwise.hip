@@ -63,16 +63,16 @@ __global__ __launch_bounds__(256, IDENT ? 4 : 2) void first_conv_kernel(const ui
         v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
         if constexpr (IDENT) {
             // The 3 pixels x 3 channels under one filter row are 9 contiguous bytes at byte (..*W + 2*ox)*3, i.e.
-            // 0 or 2 bytes past a dword boundary (W is even): three aligned dword loads through a range-checked
+            // 0 or 2 bytes past a dword boundary (W is even; which of the two depends on the row when W % 4 == 2): three aligned dword loads through a range-checked
             // buffer resource and a byte alignment replace nine byte loads (the kernel was bound by the rate of
             // its 27 byte-load instructions per thread, not by HBM).  Bytes past the image edge are masked below.
             const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, (int)((long long)B * H * W * 3), 0x00020000);
-            const int sh = (ox & 1) * 2;                       // byte offset of the row's first pixel inside its dword
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = 2 * oy + ky;
                 const bool yok = iy < H;
-                const int a0 = (((b * H + (yok ? iy : 0)) * W + 2 * ox) * 3) & ~3;
+                const int ad = ((b * H + (yok ? iy : 0)) * W + 2 * ox) * 3;
+                const int a0 = ad & ~3, sh = ad & 3;           // sh: byte offset of the row's first pixel inside its dword (0 or 2)
                 const unsigned w0 = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 0, 0);
                 const unsigned w1 = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0 + 4, 0, 0);
                 const unsigned w2 = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0 + 8, 0, 0);
@@ -145,6 +145,104 @@ __global__ __launch_bounds__(256, IDENT ? 4 : 2) void first_conv_kernel(const ui
     }
 }
 
+// K1b: the identity-resize case (the image is already H x W: every frame of the benchmark workload) with Cout % 8 == 0.
+// K1 is bound by LDS reads -- 27 x 16 B of weights per 16 B of output, 1.5 TB/s alone -- and by its ~500 instructions
+// per 16 B.  Here one LANE = one output pixel, all channels: the 27 input values are unpacked and normalised once per
+// pixel, the weights are wave-uniform (scalar loads, an SGPR operand of the packed fmaf), channels go in chunks of 8
+// accumulators, and the finished rows leave through a per-wave LDS transpose so that a store instruction writes 1 KB of
+// consecutive bytes (the wave's 64 pixels are 64 * Cout * 4 consecutive bytes of the output).  Same (ky,kx,ci)-ordered
+// fmaf chain per output.
+#define FC_ROWPAD 4     // floats of padding per LDS row: 16-B aligned rows whose 16-B writes of 16 consecutive lanes miss each other's banks
+// COUT: the width as a compile-time constant (scalar-load offsets become immediates), 0 = read the argument.
+template <int COUT>
+__global__ __launch_bounds__(256) void first_conv_px_kernel(const uint8_t *__restrict__ img, int B, int H, int W,
+                                                             const float *__restrict__ w, int Cout_arg,
+                                                             const float *__restrict__ mean, const float *__restrict__ sf,
+                                                             const float *__restrict__ beta, int act, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float fc_tr[];     // [4 waves][64 pixels][Cout + FC_ROWPAD]
+    const int Cout = COUT ? COUT : Cout_arg;
+    const int OH = H >> 1, OW = W >> 1;
+    const long long total = (long long)B * OH * OW;
+    const float inv255 = (float)(1.0 / 255.0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rowf = Cout + FC_ROWPAD;
+    float *reg = fc_tr + (size_t)wave * 64 * rowf;
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, (int)((long long)B * H * W * 3), 0x00020000);
+    const long long nwave = (long long)gridDim.x * 4;
+    for (long long wbase = ((long long)blockIdx.x * 4 + wave) * 64; wbase < total; wbase += nwave * 64) {
+        const long long pix = wbase + lane;
+        const bool live = pix < total;
+        const long long pp = live ? pix : total - 1;
+        const int ox = (int)(pp % OW);
+        const long long rowi = pp / OW;
+        const int oy = (int)(rowi % OH);
+        const int b = (int)(rowi / OH);
+        // 3 pixels x 3 channels under one filter row = 9 contiguous bytes at byte (..*W + 2*ox)*3, 0 or 2 bytes past a dword
+        // boundary (W even): three aligned dword loads and a byte alignment.  Only the taps of column 2ox+2 and of row
+        // 2oy+2 can fall outside the image (even H, W): they are masked, the others never are.
+        float x[27];
+        const bool xok = 2 * ox + 2 < W;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy + ky;
+            const bool yok = ky < 2 || iy < H;
+            const int ad = ((b * H + (yok ? iy : 0)) * W + 2 * ox) * 3;
+            const int a0 = ad & ~3, sh = ad & 3;
+            const unsigned w0 = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 0, 0);
+            const unsigned w1 = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0 + 4, 0, 0);
+            const unsigned w2 = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0 + 8, 0, 0);
+            const unsigned d0 = __builtin_amdgcn_alignbyte(w1, w0, sh);
+            const unsigned d1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            const unsigned d2 = w2 >> (8 * sh);
+            const unsigned char px[9] = {(unsigned char)d0, (unsigned char)(d0 >> 8), (unsigned char)(d0 >> 16), (unsigned char)(d0 >> 24),
+                                         (unsigned char)d1, (unsigned char)(d1 >> 8), (unsigned char)(d1 >> 16), (unsigned char)(d1 >> 24),
+                                         (unsigned char)d2};
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                float v = (float)px[k] * inv255;
+                v = 2.0f * v - 1.0f;
+                if (ky == 2 && !yok) v = 0.0f;
+                if (k >= 6 && !xok) v = 0.0f;
+                x[ky * 9 + k] = v;
+            }
+        }
+        constexpr int CH = (COUT && COUT % 16 == 0) ? 16 : 8;       // accumulators per pass over the 27 taps
+#pragma unroll 1
+        for (int ch = 0; ch < Cout; ch += CH) {         // wave-uniform (not unrolled: 864 weights do not fit the SGPRs)
+            float acc[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                const float *wr = w + t * Cout + ch;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) acc[i] = fmaf(x[t], wr[i], acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (mean) {
+                    const float tq = (acc[i] - mean[ch + i]) * sf[ch + i];
+                    acc[i] = tq + beta[ch + i];
+                }
+                acc[i] = act_apply(acc[i], act);
+            }
+#pragma unroll
+            for (int i = 0; i < CH; i += 4) *(v4f *)(reg + lane * rowf + ch + i) = (v4f){acc[i], acc[i + 1], acc[i + 2], acc[i + 3]};
+        }
+        // the wave's rows -> 64 * Cout * 4 consecutive bytes of the output, 16 B per lane and instruction (wave-private LDS
+        // region: the wave's own ds_writes are ordered before its ds_reads by the counter wait the compiler places)
+        const int LP = Cout >> 2;                        // 16-B pieces per pixel
+        const long long nlive = (total - wbase < 64 ? total - wbase : 64) * LP;
+        float *obase = out + wbase * Cout;
+        for (int q = lane; q < 64 * LP; q += 64) {
+            const int p = q / LP, c4 = q - p * LP;
+            const v4f v = *(const v4f *)(reg + p * rowf + c4 * 4);
+            if (q < nlive) *(v4f *)(obase + (long long)q * 4) = v;
+        }
+    }
+}
+
 hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int nh, int nw, int H, int W,
                              const float *w, int Cout, const float *mean, const float *sf, const float *beta, int act,
                              float *out, hipStream_t s)
@@ -156,7 +254,18 @@ hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int 
     const long long total = (long long)B * (H / 2) * (W / 2) * (Cout / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    if (srcH == nh && nh == H && srcW == nw && nw == W)
+    if (srcH == nh && nh == H && srcW == nw && nw == W && Cout % 8 == 0 && Cout <= 128) {
+        const long long px = (long long)B * (H / 2) * (W / 2);
+        blocks = (px + 255) / 256;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        const size_t lds = (size_t)256 * (Cout + FC_ROWPAD) * sizeof(float);
+        if (Cout == 32)        // MobileNet-v1 at depth multiplier 1
+            hipLaunchKernelGGL(first_conv_px_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, s, img, B, H, W, w, Cout, mean, sf, beta, act, out);
+        else if (Cout == 24)   // ShuffleNet-v2
+            hipLaunchKernelGGL(first_conv_px_kernel<24>, dim3((unsigned)blocks), dim3(256), lds, s, img, B, H, W, w, Cout, mean, sf, beta, act, out);
+        else
+            hipLaunchKernelGGL(first_conv_px_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, s, img, B, H, W, w, Cout, mean, sf, beta, act, out);
+    } else if (srcH == nh && nh == H && srcW == nw && nw == W)
         hipLaunchKernelGGL(first_conv_kernel<true>, dim3((unsigned)blocks), dim3(256), 27 * Cout * sizeof(float), s, img, B,
                            srcH, srcW, nh, nw, H, W, hs, ws, w, Cout, mean, sf, beta, act, out);
     else
@@ -167,83 +276,98 @@ hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int 
 
 // ---------------------------------------------------------------------------------------
 // K2: depthwise 3x3, stride 1/2, zero padding `pad` on top/left (TF 'SAME': 1 for stride 1,
-// 0 for stride 2 on even sizes), + BN + act.  One thread = DW_PX consecutive output pixels of
-// one row x 4 channels: the three input rows it needs are loaded once (6 resp. 9 float4 per
-// row instead of 12) and every output keeps its own (ky,kx)-ordered fmaf chain.  An
-// out-of-image tap contributes fmaf(0, w, acc) == acc, so zero filling is exact.
-#define DW_PX 4
+// 0 for stride 2 on even sizes), + BN + act.  One thread = R output rows x PX consecutive output
+// pixels x 4 channels.  The input rows it needs are streamed top to bottom, each loaded once
+// ((PX-1)*STRIDE+3 float4) and applied to every output row it belongs to, so every output keeps
+// its own (ky,kx)-ordered fmaf chain.  An out-of-image tap contributes fmaf(0, w, acc) == acc, so
+// zero filling is exact.  Stride 1 runs 2 rows x 4 pixels (24 loads for 8 outputs instead of 36:
+// the layer is bound by L1/L2 reads, 3.2 -> 3.7 TB/s alone), stride 2 1 row x 2 pixels (4.3 -> 4.7 TB/s):
+// profiles/r02_depthwise_probe.log, scripts/experiments/dw_probe.hip.
 // OUT16: the result rows are written in split-fp16 form (h | l per octet, igemm.hip) for a pointwise
 // convolution that runs in precision mode f16x3; the values are exact fp32 results, rounded to h + l.
-template <int STRIDE, int OUT16 = 0>
+template <int STRIDE, int OUT16 = 0, int R = (STRIDE == 1 ? 2 : 1), int PX = (STRIDE == 1 ? 4 : 2)>
 __global__ __launch_bounds__(256) void depthwise_kernel(const float *__restrict__ in, int B, int H, int W, int C,
                                                          const float *__restrict__ w, int pad, int OH, int OW,
                                                          const float *mean, const float *sf, const float *beta,
                                                          int act, float *__restrict__ out, int *flags)
 {
-    constexpr int NCOL = (DW_PX - 1) * STRIDE + 3;
+    constexpr int NCOL = (PX - 1) * STRIDE + 3, NROW = (R - 1) * STRIDE + 3;
     bool ovf = false;
-    const int C4 = C >> 2, XG = (OW + DW_PX - 1) / DW_PX;
-    const long long total = (long long)B * OH * XG * C4;
+    const int C4 = C >> 2, XG = (OW + PX - 1) / PX, YG = (OH + R - 1) / R;
+    const long long total = (long long)B * YG * XG * C4;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(idx % C4) * 4;
         long long q = idx / C4;
-        const int ox0 = (int)(q % XG) * DW_PX;
+        const int ox0 = (int)(q % XG) * PX;
         q /= XG;
-        const int oy = (int)(q % OH);
-        const int b = (int)(q / OH);
+        const int oy0 = (int)(q % YG) * R;
+        const int b = (int)(q / YG);
         v4f wv[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) wv[t] = *(const v4f *)(w + t * C + c);
-        v4f acc[DW_PX];
+        v4f acc[R][PX];
 #pragma unroll
-        for (int p = 0; p < DW_PX; ++p) acc[p] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-        const int ix0 = ox0 * STRIDE - pad;
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * STRIDE + ky - pad;
+            for (int p = 0; p < PX; ++p) acc[r][p] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+        const int ix0 = ox0 * STRIDE - pad, iy0 = oy0 * STRIDE - pad;
+#pragma unroll
+        for (int j = 0; j < NROW; ++j) {
+            const int iy = iy0 + j;
             const bool rowok = (unsigned)iy < (unsigned)H;
             const float *rowp = in + (((long long)b * H + (rowok ? iy : 0)) * W) * C + c;
             v4f x[NCOL];
 #pragma unroll
-            for (int j = 0; j < NCOL; ++j) {
-                const int ix = ix0 + j;
+            for (int k = 0; k < NCOL; ++k) {
+                const int ix = ix0 + k;
                 const bool ok = rowok && (unsigned)ix < (unsigned)W;
-                x[j] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-                if (ok) x[j] = *(const v4f *)(rowp + (long long)ix * C);
+                x[k] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                if (ok) x[k] = *(const v4f *)(rowp + (long long)ix * C);
             }
 #pragma unroll
-            for (int p = 0; p < DW_PX; ++p)
+            for (int r = 0; r < R; ++r) {
+                const int ky = j - r * STRIDE;            // this input row is tap row ky of output row r
+                if (ky >= 0 && ky < 3) {
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+                    for (int p = 0; p < PX; ++p)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[p][i] = fmaf(x[p * STRIDE + kx][i], wv[ky * 3 + kx][i], acc[p][i]);
-        }
-        if constexpr (OUT16) {
-            typedef _Float16 v4h __attribute__((ext_vector_type(4)));
-            typedef unsigned v2u __attribute__((ext_vector_type(2)));
-            // 4 channels = half an octet: h at (octet * 8 + half * 2) floats, l 4 floats further
-            float *o = out + (((long long)b * OH + oy) * OW + ox0) * C + (c >> 3) * 8 + ((c >> 2) & 1) * 2;
+                        for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int p = 0; p < DW_PX; ++p)
-                if (ox0 + p < OW) {
-                    const v4f v = bn_act4(acc[p], mean, sf, beta, c, act);
-                    v4h h, l;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ovf |= !(fabsf(v[e]) <= 65504.0f);       // also true for NaN
-                        const float x = fminf(fmaxf(v[e], -65504.0f), 65504.0f);
-                        h[e] = (_Float16)x;
-                        l[e] = (_Float16)(x - (float)h[e]);
-                    }
-                    *(v2u *)(o + (long long)p * C) = __builtin_bit_cast(v2u, h);
-                    *(v2u *)(o + (long long)p * C + 4) = __builtin_bit_cast(v2u, l);
+                            for (int i = 0; i < 4; ++i)
+                                acc[r][p][i] = fmaf(x[p * STRIDE + kx][i], wv[ky * 3 + kx][i], acc[r][p][i]);
                 }
-        } else {
-        float *o = out + (((long long)b * OH + oy) * OW + ox0) * C + c;
+            }
+        }
 #pragma unroll
-        for (int p = 0; p < DW_PX; ++p)
-            if (ox0 + p < OW) *(v4f *)(o + (long long)p * C) = bn_act4(acc[p], mean, sf, beta, c, act);
+        for (int r = 0; r < R; ++r) {
+            if (oy0 + r >= OH) continue;
+            if constexpr (OUT16) {
+                typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                // 4 channels = half an octet: h at (octet * 8 + half * 2) floats, l 4 floats further
+                float *o = out + (((long long)b * OH + oy0 + r) * OW + ox0) * C + (c >> 3) * 8 + ((c >> 2) & 1) * 2;
+#pragma unroll
+                for (int p = 0; p < PX; ++p)
+                    if (ox0 + p < OW) {
+                        const v4f v = bn_act4(acc[r][p], mean, sf, beta, c, act);
+                        v4h h, l;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ovf |= !(fabsf(v[e]) <= 65504.0f);       // also true for NaN
+                            const float x = fminf(fmaxf(v[e], -65504.0f), 65504.0f);
+                            h[e] = (_Float16)x;
+                            l[e] = (_Float16)(x - (float)h[e]);
+                        }
+                        *(v2u *)(o + (long long)p * C) = __builtin_bit_cast(v2u, h);
+                        *(v2u *)(o + (long long)p * C + 4) = __builtin_bit_cast(v2u, l);
+                    }
+            } else {
+                float *o = out + (((long long)b * OH + oy0 + r) * OW + ox0) * C + c;
+#pragma unroll
+                for (int p = 0; p < PX; ++p)
+                    if (ox0 + p < OW) *(v4f *)(o + (long long)p * C) = bn_act4(acc[r][p], mean, sf, beta, c, act);
+            }
         }
     }
     if constexpr (OUT16) { if (ovf && flags) atomicOr(flags, 1); }
@@ -254,7 +378,8 @@ hipError_t launch_depthwise(const float *in, int B, int H, int W, int C, const f
                             hipStream_t s, int out16, int *flags)
 {
     if (C % 4 || (stride != 1 && stride != 2) || (out16 && C % 8)) return hipErrorInvalidValue;
-    const long long total = (long long)B * OH * ((OW + DW_PX - 1) / DW_PX) * (C / 4);
+    const int R = stride == 1 ? 2 : 1, PX = stride == 1 ? 4 : 2;      // as in the kernel
+    const long long total = (long long)B * ((OH + R - 1) / R) * ((OW + PX - 1) / PX) * (C / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (blocks < 1) blocks = 1;

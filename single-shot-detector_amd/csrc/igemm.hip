@@ -67,31 +67,15 @@ static __device__ __forceinline__ v4f join_f16(const v2u hi, const v2u lo)
 // DBG (timing experiments only, results are wrong): 1 = no global loads / LDS writes in the
 // K loop, 2 = additionally no LDS fragment reads, 3 = additionally no barrier.
 // DBG 7 (results are right): thread 0 of every block records 100 MHz timestamps of its phases.
-// TR (fp32 rows, batch-norm form): the MFMA operands swapped -- weights as the A operand, activations as B -- so that the
-// accumulators come out transposed: a lane holds 4 consecutive channels of one position and stores them as they are
-// (no LDS transpose, no barrier in the epilogue).  fma(a, b, c) == fma(b, a, c): the same k-ordered chain per output.
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int DBGT = 0, int S16 = 0, int TR = 0>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WM * WAVES_N * WN == 4 && !S16) ? 4 : 2) void igemm_kernel(const IgemmArgs a)
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int DBGT = 0, int S16 = 0>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const IgemmArgs a)
 {
-    static_assert(!TR || !S16, "transposed accumulators: fp32 operands only");
     constexpr int DBG = DBGT == 7 ? 0 : DBGT;
     long long stamp[8];
     auto mark = [&](int i) {
         if constexpr (DBGT == 7) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[i] = wall_clock64(); }
     };
     if constexpr (DBGT == 7) stamp[0] = wall_clock64();
-    // Blocks that start together on one CU run the same program on equal tiles and stay in phase for the whole launch:
-    // their prologues and epilogues coincide and the matrix pipe idles meanwhile (a 1x1 launch with 16 K-steps per tile:
-    // no block of the CU in its K loop for 13-24 % of the launch, profiles/r02_pointwise_phases.log).  The dispatcher hands
-    // the first 256 blocks one to each CU, the next 256 their second slot, ...: slot s of the first round starts s steps late,
-    // every later block inherits the phase of the block whose slot it takes.
-    if (a.stagger_step > 0) {
-        const int slot = blockIdx.x >> 8;
-        if (slot > 0 && slot < a.stagger_slots) {
-            const long long t_end = (long long)wall_clock64() + (long long)slot * a.stagger_step;
-            while ((long long)wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16);
-        }
-    }
     constexpr int NT = 64 * WAVES_M * WAVES_N;   // threads per block (256 or 512)
     constexpr int RPP = NT / 8;                  // tile rows covered by one pass of the block
     constexpr int BM = WAVES_M * WM * 32;
@@ -261,10 +245,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WM * WAVES_N * W
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    if constexpr (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][t], af[i][t], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
     };
     constexpr int PM = 4 * WM * WN;          // MFMAs per phase
     constexpr int NFR = WM + WN;             // LDS reads per fragment set
@@ -429,63 +411,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WM * WAVES_N * W
     // image is plain row-major: a 32-lane ds_write_b32 covers 32 consecutive dwords of one row
     // and a 16-lane ds_read_b128 group covers 16 distinct 16-B chunks -- conflict-free as is.
     mark(2);
-    if constexpr (TR) {
-        // acc[i][j][4g + r] = output (position i*32 + (lane & 31), channel j*32 + 8g + 4*(lane >> 5) + r) of the wave's
-        // sub-tile: per (j, g) one 16-B parameter triple and, per i, one 16-B store; the four g of a (i, j) fill the 128-B
-        // line of a position between them (the L2 merges them).  Host: batch-norm form, fp32 rows, 16-B aligned rows.
-        mark(3);
-        const int n = lane & 31, hh = lane >> 5;
-        constexpr unsigned OOBS = 0x80000000u;
-        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + L.out_off), 0, (int)OOBS, 0x00020000);
-        const int bstride = (int)L.out_bstride, rstride = L.out_rstride;
-        unsigned rowoff[WM];
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            const int m = m0 + (wave_m * WM + i) * 32 + n;
-            const int b = m / P, p = m - b * P;
-            rowoff[i] = m < M ? (unsigned)(b * bstride + p * rstride) * 4u : OOBS;
-        }
-        const int colw = tile_n * BN + wave_n * WN * 32 + 4 * hh;
-        v4f pm[WN][4], ps[WN][4], pb[WN][4];
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = colw + j * 32 + 8 * g;              // parameter vectors are padded to CoutPad
-                pm[j][g] = *(const v4f *)(a.mean + L.param_off + col);
-                ps[j][g] = *(const v4f *)(a.sf + L.param_off + col);
-                pb[j][g] = *(const v4f *)(a.beta + L.param_off + col);
-            }
-        if constexpr (DBGT == 7) { stamp[5] = wall_clock64(); stamp[6] = stamp[5]; stamp[7] = stamp[5]; }
-        const float act_hi = a.act == 2 ? 6.0f : __builtin_inff();
-        auto store_tr = [&](auto act_tag) __attribute__((always_inline)) {
-            constexpr int ACT = decltype(act_tag)::value;
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int col = colw + j * 32 + 8 * g;
-                    const bool colok = col < a.Cout;
-#pragma unroll
-                    for (int i = 0; i < WM; ++i) {
-                        v4f v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float t = (acc[i][j][4 * g + e] - pm[j][g][e]) * ps[j][g][e];
-                            v[e] = t + pb[j][g][e];
-                            if constexpr (ACT == 1) {
-                                v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-                                v[e] = v[e] < act_hi ? v[e] : act_hi;
-                            }
-                        }
-                        const unsigned o = (rowoff[i] != OOBS && colok) ? rowoff[i] + (unsigned)col * 4u : OOBS;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), orsrc, (int)o, 0, 0);
-                    }
-                }
-        };
-        if (a.act >= 1) store_tr(std::integral_constant<int, 1>{});
-        else store_tr(std::integral_constant<int, 0>{});
-    } else {
     if constexpr (S16 == 2) { if (in_ovf && a.flags) atomicOr(a.flags, 1); }
     const bool has_bn = a.mean != nullptr;
     constexpr int RW = WN * 32;                  // floats per row of the wave's sub-tile
@@ -566,11 +491,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WM * WAVES_N * W
         bool ovf = false;
         // One straight-line loop per epilogue form (uniform switch below): all LDS reads first,
         // then arithmetic and stores of independent rows for the scheduler to interleave.
-        const float act_hi = a.act == 2 ? 6.0f : __builtin_inff();
-        auto store_rows_act = [&](auto mode_tag, auto o16_tag, auto act_tag) __attribute__((always_inline)) {
+        auto store_rows = [&](auto mode_tag, auto o16_tag) {
             constexpr int MODE = decltype(mode_tag)::value;   // 0 plain, 1 +upsampled, 2 BN, 3 BN + relu(raw) copy, 4 bias
             constexpr bool O16 = decltype(o16_tag)::value;    // output rows in S16 form
-            constexpr int ACT = decltype(act_tag)::value;     // 1: ReLU, then min with act_hi (6 or +inf); -1: a.act read per value
             v4f raw[ITS];
 #pragma unroll
             for (int it = 0; it < ITS; ++it) raw[it] = *(const v4f *)(reg + (it * ROWS_PER_IT + row0) * RW + (c4 << 2));
@@ -604,14 +527,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WM * WAVES_N * W
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if constexpr (ACT < 0) {
-                        if (a.act >= 1) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-                        if (a.act == 2) v[e] = v[e] < 6.0f ? v[e] : 6.0f;
-                    }
-                    if constexpr (ACT == 1) {
-                        v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-                        v[e] = v[e] < act_hi ? v[e] : act_hi;
-                    }
+                    if (a.act >= 1) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                    if (a.act == 2) v[e] = v[e] < 6.0f ? v[e] : 6.0f;
                 }
                 const unsigned o = (m < M && colok) ? off : OOBS;
                 if constexpr (MODE == 4 && !O16) {
@@ -660,18 +577,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WM * WAVES_N * W
                 off += (unsigned)(step + (wrap ? wrapstep : 0));
             }
         };
-        // a.act is uniform.  Batch-norm forms with an activation (every layer of the network but the heads' last and the
-        // laterals): ReLU, then min with 6 or +inf -- two vector instructions per value; reading a.act per value costs two
-        // selects on top of each (5 of the 8 vector instructions per value), kept for the other forms.
-        auto store_rows = [&](auto mode_tag, auto o16_tag) __attribute__((always_inline)) {
-            constexpr int MODE = decltype(mode_tag)::value;
-            if constexpr (!S16 && (MODE == 2 || MODE == 3)) {     // (the S16 instances are at their register limit as they are)
-                if (a.act >= 1) store_rows_act(mode_tag, o16_tag, std::integral_constant<int, 1>{});
-                else store_rows_act(mode_tag, o16_tag, std::integral_constant<int, -1>{});
-            } else {
-                store_rows_act(mode_tag, o16_tag, std::integral_constant<int, -1>{});
-            }
-        };
         // (host checks: bias and batch norm are exclusive, the upsampled operand comes without
         // either, the second output only with batch norm)
         using F = std::false_type;
@@ -697,7 +602,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WM * WAVES_N * W
         } else {
             store_rows(std::integral_constant<int, 0>{}, F{});
         }
-    }
     }
     if constexpr (DBGT == 7) {
         // stamp 4 is taken with the stores still in flight (a wave does not wait for them to retire)
@@ -727,13 +631,13 @@ int igemm_tile_bn(int tile)
     }
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int DBG = 0, int S16 = 0, int TR = 0>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int DBG = 0, int S16 = 0>
 static hipError_t launch_tt(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
     constexpr int lds_bytes = 2 * (BM + BN) * 128;
     static bool attr_set = false;
-    auto k = igemm_kernel<WAVES_M, WAVES_N, WM, WN, TAPS, DBG, S16, TR>;
+    auto k = igemm_kernel<WAVES_M, WAVES_N, WM, WN, TAPS, DBG, S16>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -758,11 +662,6 @@ static hipError_t launch_t(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
             return a.taps == 9 ? launch_tt<WAVES_M, WAVES_N, WM, WN, 9, 0, 1>(a, total_tiles_m, s)
                                : launch_tt<WAVES_M, WAVES_N, WM, WN, 1, 0, 1>(a, total_tiles_m, s);
     }
-    if constexpr (DBG == 0 || DBG == 7) {
-        if (a.tr)
-            return a.taps == 9 ? launch_tt<WAVES_M, WAVES_N, WM, WN, 9, DBG, 0, 1>(a, total_tiles_m, s)
-                               : launch_tt<WAVES_M, WAVES_N, WM, WN, 1, DBG, 0, 1>(a, total_tiles_m, s);
-    }
     return a.taps == 9 ? launch_tt<WAVES_M, WAVES_N, WM, WN, 9, DBG>(a, total_tiles_m, s)
                        : launch_tt<WAVES_M, WAVES_N, WM, WN, 1, DBG>(a, total_tiles_m, s);
 }
@@ -786,11 +685,6 @@ hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStre
     if (a.out_fmt && (a.bias || (a.Cout & 7) || !a.dense_out)) return hipErrorInvalidValue;
     if (a.res_fmt && !a.res) return hipErrorInvalidValue;
     if (a.in_fmt && tile >= 10) return hipErrorInvalidValue;
-    if (a.tr) {     // transposed accumulators: batch-norm form on fp32 rows whose 4-channel groups are 16-B aligned
-        if (!a.mean || a.out2 || a.out_fmt || a.in_fmt || a.res || a.bias || (a.Cout & 3)) return hipErrorInvalidValue;
-        for (int i = 0; i < a.nlevels; ++i)
-            if ((a.lv[i].out_rstride | a.lv[i].out_bstride | a.lv[i].out_off) & 3) return hipErrorInvalidValue;
-    }
     for (int i = 0; i < a.nlevels; ++i)     // 32-bit byte offsets in the epilogue's buffer stores, relative to the level's base
         if ((long long)a.B * a.lv[i].out_bstride * 4 >= (1LL << 31) || a.lv[i].out_bstride < 0) return hipErrorInvalidValue;
     if (a.n_tiles_n * igemm_tile_bn(tile >= 10 ? 0 : tile) != a.CoutPad || a.nlevels < 1 || a.nlevels > SSD_MAX_LEVELS) return hipErrorInvalidValue;

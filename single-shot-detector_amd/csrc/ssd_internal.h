@@ -58,10 +58,6 @@ struct IgemmArgs {
     float scan_lo;
     unsigned *scan_bits;
     long long *ts;         // diagnostics (ssd_bench_conv tile 17): per-block phase timestamps, else null
-    // De-phasing of the blocks that share a CU (igemm.hip, top of the kernel): the first-round block of slot s
-    // (blockIdx / 256, s < stagger_slots) starts stagger_step * s ticks of the 100 MHz clock late; 0 = off
-    int stagger_slots, stagger_step;
-    int tr;                // 1: transposed accumulators (igemm.hip "TR"): batch-norm form, fp32 rows, no LDS transpose in the epilogue
     IgemmLevel lv[SSD_MAX_LEVELS];
 };
 

@@ -204,7 +204,11 @@ def test_depthwise(cuda, ssd, oracle_ops, B, H, W, C, stride, act):
     assert close(got, ref, "depthwise C=%d s=%d" % (C, stride)) == 1.0
 
 
-@pytest.mark.parametrize("B,H,W,Cout,act", [(2, 128, 128, 32, "relu6"), (1, 64, 96, 24, "relu")])
+# widths 32 / 24: the pixel-per-lane kernel's compile-time instances; 8 / 16 / 64: its run-time width; 12: the 4-channel-per-thread
+# kernel (Cout % 8 != 0); 10x14 and 18x22: pixel counts that leave the last wave partly filled (35 and 297 pixels)
+@pytest.mark.parametrize("B,H,W,Cout,act", [(2, 128, 128, 32, "relu6"), (1, 64, 96, 24, "relu"), (1, 10, 14, 32, "relu6"),
+                                            (3, 18, 22, 24, "relu"), (2, 32, 32, 8, "relu6"), (1, 32, 64, 16, None),
+                                            (1, 16, 16, 64, "relu6"), (2, 32, 32, 12, "relu")])
 def test_first_conv(cuda, ssd, oracle_ops, B, H, W, Cout, act):
     rng = np.random.default_rng(Cout)
     img = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
