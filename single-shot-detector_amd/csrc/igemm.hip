@@ -119,27 +119,42 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)a.wt, 0, (int)((long long)TAPS * a.CoutPad * Cin * 4), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    int abase[NA], aiy0[NA], aix0[NA];      // byte offset of the row's image, top-left tap coordinate
+    // Per row: byte offset of its tap (0,0) (used only where that tap exists) and 9 bits "tap t reads inside the image"; the
+    // offset of tap t is then one wave-uniform displacement away.  (A tap change used to redo the coordinate arithmetic
+    // per row: ~100 vector instructions every KC K-steps, 0.2 per MFMA in the 3x3 launches -- every one of them takes an
+    // issue slot from the matrix pipe, profiles/r02_pointwise_phases.log.)
+    int abase0[NA];
+    unsigned amask[NA];
+    const bool dense1x1 = TAPS == 1 && a.stride == 1 && a.pad == 0 && L.OH == H && OW == W;   // rows of A = rows of the input
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
         const int m = m0 + (tid >> 3) + RPP * u;
         const bool rowok = m < M;
         const int mm = rowok ? m : 0;
-        const int b = mm / P, p = mm - b * P;
-        const int oy = p / OW, ox = p - oy * OW;
-        abase[u] = (b * H * W * Cin + (tid & 7) * 4) * 4;
-        aiy0[u] = rowok ? oy * a.stride - a.pad : -(1 << 20);
-        aix0[u] = ox * a.stride - a.pad;
+        if (dense1x1) {
+            abase0[u] = (mm * Cin + (tid & 7) * 4) * 4;
+            amask[u] = rowok ? 1u : 0u;
+        } else {
+            const int b = mm / P, p = mm - b * P;
+            const int oy = p / OW, ox = p - oy * OW;
+            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            abase0[u] = (b * H * W * Cin + (tid & 7) * 4) * 4 + (iy0 * W + ix0) * Cin * 4;
+            unsigned vx = 0, mk = 0;                              // bit 3*ky + kx
+#pragma unroll
+            for (int k = 0; k < (TAPS == 9 ? 3 : 1); ++k)
+                if ((unsigned)(ix0 + k) < (unsigned)W) vx |= 1u << k;
+#pragma unroll
+            for (int k = 0; k < (TAPS == 9 ? 3 : 1); ++k)
+                if ((unsigned)(iy0 + k) < (unsigned)H) mk |= vx << (3 * k);
+            amask[u] = rowok ? mk : 0u;
+        }
     }
-    // byte offsets of this thread's A chunks for filter tap `t` (OOB when the tap is padding)
+    // byte offsets of this thread's A chunks for filter tap `t` (OOB when the tap is padding, or t == TAPS)
     auto tap_offsets = [&](int t, unsigned (&off)[NA]) {
         const int tky = TAPS == 9 ? t / 3 : 0, tkx = TAPS == 9 ? t - 3 * tky : 0;
+        const int d = (tky * W + tkx) * Cin * 4;                  // wave-uniform
 #pragma unroll
-        for (int u = 0; u < NA; ++u) {
-            const int iy = aiy0[u] + tky, ix = aix0[u] + tkx;
-            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && t < TAPS;
-            off[u] = ok ? (unsigned)(abase[u] + (iy * W + ix) * Cin * 4) : OOB;
-        }
+        for (int u = 0; u < NA; ++u) off[u] = ((amask[u] >> t) & 1u) ? (unsigned)(abase0[u] + d) : OOB;
     };
     const int bvoff = ((tile_n * BN + (tid >> 3)) * Cin + (tid & 7) * 4) * 4;
     const int b_ustride = RPP * Cin * 4;
@@ -274,10 +289,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     __syncthreads();
     mark(1);
     rdfrag(0, 0, fa0, fb0);
-    if (KS > 1) {
-      int ks = 0;
-      do {
-        const int cur = ks & 1, nxt = cur ^ 1;
+    // One K-step with the LDS stage as a compile-time constant: every LDS address of the loop is then a loop-invariant
+    // register plus an immediate (with `ks & 1` as the stage the loop spent 8 vector adds per K-step on them -- 0.125 per
+    // MFMA, each taking an issue slot from the matrix pipe).  The loop runs the steps in pairs, stage 0 then stage 1.
+    auto kstep = [&](auto cur_tag) __attribute__((always_inline)) {
+        constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
         // phase 0: registers (step ks+1) -> LDS stage nxt
         if (DBG < 2) rdfrag(cur, 1, fa1, fb1);
         if (DBG < 1) lstore(nxt);
@@ -299,7 +315,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         mfma16(fa1, fb1);
         phase_sched(1, 0, 0);
         gadvance();
-      } while (++ks < KS - 1);
+    };
+    {
+        int ks = 0;                                   // K-steps 0 .. KS-2 stage their successor; step ks reads stage ks & 1
+        for (; ks + 2 <= KS - 1; ks += 2) {
+            kstep(std::integral_constant<int, 0>{});
+            kstep(std::integral_constant<int, 1>{});
+        }
+        if (ks < KS - 1) kstep(std::integral_constant<int, 0>{});
     }
     {   // last K-step: nothing left to stage
         const int cur = (KS - 1) & 1;
@@ -491,9 +514,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         bool ovf = false;
         // One straight-line loop per epilogue form (uniform switch below): all LDS reads first,
         // then arithmetic and stores of independent rows for the scheduler to interleave.
-        auto store_rows = [&](auto mode_tag, auto o16_tag) {
+        const float act_hi = a.act == 2 ? 6.0f : __builtin_inff();
+        auto store_rows_act = [&](auto mode_tag, auto o16_tag, auto act_tag) __attribute__((always_inline)) {
             constexpr int MODE = decltype(mode_tag)::value;   // 0 plain, 1 +upsampled, 2 BN, 3 BN + relu(raw) copy, 4 bias
             constexpr bool O16 = decltype(o16_tag)::value;    // output rows in S16 form
+            constexpr int ACT = decltype(act_tag)::value;     // 1: ReLU, then min with act_hi (6 or +inf); -1: a.act read per value
             v4f raw[ITS];
 #pragma unroll
             for (int it = 0; it < ITS; ++it) raw[it] = *(const v4f *)(reg + (it * ROWS_PER_IT + row0) * RW + (c4 << 2));
@@ -527,8 +552,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (a.act >= 1) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-                    if (a.act == 2) v[e] = v[e] < 6.0f ? v[e] : 6.0f;
+                    if constexpr (ACT < 0) {
+                        if (a.act >= 1) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                        if (a.act == 2) v[e] = v[e] < 6.0f ? v[e] : 6.0f;
+                    } else {
+                        v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                        v[e] = v[e] < act_hi ? v[e] : act_hi;
+                    }
                 }
                 const unsigned o = (m < M && colok) ? off : OOBS;
                 if constexpr (MODE == 4 && !O16) {
@@ -575,6 +605,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
                 const bool wrap = p >= P;
                 p -= wrap ? P : 0;
                 off += (unsigned)(step + (wrap ? wrapstep : 0));
+            }
+        };
+        // a.act is uniform.  Batch-norm forms with an activation on the wide fp32 tiles (backbone, FPN outputs and towers at
+        // serving batch sizes): ReLU, then min with 6 or +inf -- two vector instructions per value; reading a.act per value
+        // costs two selects on top of each (5 of the 8 vector instructions per value).  The other forms, the S16 instances
+        // (at their register limit) and the 64-wide tiles (five blocks per CU need <= 96 VGPRs) keep reading it.
+        auto store_rows = [&](auto mode_tag, auto o16_tag) __attribute__((always_inline)) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            if constexpr (!S16 && BM * BN >= 128 * 64 && (MODE == 2 || MODE == 3)) {
+                if (a.act >= 1) store_rows_act(mode_tag, o16_tag, std::integral_constant<int, 1>{});
+                else store_rows_act(mode_tag, o16_tag, std::integral_constant<int, -1>{});
+            } else {
+                store_rows_act(mode_tag, o16_tag, std::integral_constant<int, -1>{});
             }
         };
         // (host checks: bias and batch norm are exclusive, the upsampled operand comes without
