@@ -49,6 +49,12 @@ CONV_CASES = [
     (1, 16, 16, 24, 58, 1, 1, "SAME", True, False, "relu", False),       # shufflenet odd channels
     (1, 16, 16, 116, 116, 1, 1, "SAME", True, False, "relu", False),
     (3, 33, 17, 40, 72, 3, 1, "SAME", False, False, None, False),        # ragged everything
+    # odd numbers of K-steps (the K loop runs its steps in stage pairs plus one): 3, 9, 27
+    (1, 12, 12, 96, 64, 1, 1, "SAME", True, False, "relu6", False),
+    (1, 9, 11, 32, 64, 3, 1, "SAME", True, False, "relu", False),
+    (2, 8, 8, 96, 128, 3, 2, "EXPLICIT", True, False, "relu", False),
+    (1, 16, 16, 64, 64, 1, 2, "SAME", False, False, None, False),        # 1x1 with a stride: rows of A are not the rows of the input
+    (1, 8, 8, 64, 64, 3, 1, "SAME", True, False, None, False),           # batch norm without an activation
 ]
 
 
@@ -193,7 +199,9 @@ def test_dw_pw_unsupported_shapes_fail_loudly(cuda, ssd):
 
 @pytest.mark.parametrize("B,H,W,C,stride,act", [(2, 20, 28, 32, 1, "relu6"), (1, 40, 56, 64, 2, "relu6"),
                                                 (2, 16, 16, 24, 2, None), (1, 10, 10, 58, 1, None),
-                                                (1, 6, 8, 1024, 1, "relu6")])
+                                                (1, 6, 8, 1024, 1, "relu6"),
+                                                # odd output sizes: the last row pair / pixel pair of a thread is partly outside
+                                                (1, 7, 9, 32, 1, "relu6"), (2, 14, 10, 16, 2, None), (1, 5, 3, 64, 1, "relu")])
 def test_depthwise(cuda, ssd, oracle_ops, B, H, W, C, stride, act):
     rng = np.random.default_rng(C * 7 + stride)
     x = rng.standard_normal((B, H, W, C)).astype(np.float32)
