@@ -636,7 +636,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
             // a value outside the fp16 range was clamped: tell the host (ssd_status)
             if (ovf && a.flags) atomicOr(a.flags, 1);
         } else if (has_bn) {
-            if (a.out2) store_rows(std::integral_constant<int, 3>{}, F{});
+            bool fast = false;
+            if constexpr (!S16 && BM * BN >= 128 * 64) fast = !a.out2 && a.act >= 1 && a.dense_out && vec_rows;
+            if (fast) {
+                if constexpr (!S16 && BM * BN >= 128 * 64) {
+                    // The form every backbone / FPN-output / tower launch takes: batch norm + ReLU|ReLU6, fp32 rows, dense
+                    // output ((image, position) -> row m of the level: no wrap arithmetic), 16-B aligned: 14 instructions per
+                    // row group instead of ~30.  v_med3_f32(x, 0, hi) is the clamp in one instruction; a NaN comes out as 0,
+                    // as it does from `x > 0 ? x : 0` (oracle act_apply; tests/test_gpu_stages.py::test_conv2d_nan_inf).
+                    v4f raw[ITS];
+#pragma unroll
+                    for (int it = 0; it < ITS; ++it) raw[it] = *(const v4f *)(reg + (it * ROWS_PER_IT + row0) * RW + (c4 << 2));
+                    const int mrem = colok ? M - mfirst : 0;                 // rows of this lane's column group that exist
+                    unsigned off = (unsigned)(mfirst * rstride + col) * 4u;
+                    const unsigned rstep = (unsigned)(ROWS_PER_IT * rstride) * 4u;
+#pragma unroll
+                    for (int it = 0; it < ITS; ++it) {
+                        v4f v = raw[it];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = (v[e] - mean[e]) * sf[e];
+                            v[e] = __builtin_amdgcn_fmed3f(t + beta[e], 0.0f, act_hi);
+                        }
+                        const unsigned o = it * ROWS_PER_IT < mrem ? off : OOBS;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), orsrc, (int)o, 0, 0);
+                        off += rstep;
+                    }
+                }
+            } else if (a.out2) store_rows(std::integral_constant<int, 3>{}, F{});
             else store_rows(std::integral_constant<int, 2>{}, F{});
         } else if (a.bias) {
             store_rows(std::integral_constant<int, 4>{}, F{});

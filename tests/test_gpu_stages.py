@@ -3,6 +3,7 @@ inputs.  Integer / index results must be identical; fp32 values are compared wit
 tolerance BASELINE.json's north_star states (1e-4), and -- because the kernels accumulate
 in the oracle's k-order on the exact-fp32 matrix cores -- additionally reported / asserted
 bit-for-bit where noted."""
+import os
 import numpy as np
 import pytest
 
@@ -91,6 +92,32 @@ def test_conv2d(cuda, ssd, oracle_ops, case, tile, monkeypatch):
     exact = close(got, ref, "conv2d %s" % (case,))
     # same accumulation order on the exact-fp32 MFMA as the oracle's fmaf chain
     assert exact == 1.0, "conv2d result is within tolerance but not bit-identical to the oracle"
+
+
+@pytest.mark.parametrize("act", ["relu", "relu6"])
+@pytest.mark.parametrize("shape", [(2, 20, 28, 64, 128, 3), (1, 12, 12, 64, 64, 1)])
+def test_conv2d_nan_inf(cuda, ssd, oracle_ops, shape, act):
+    """Non-finite inputs through the batch-norm + activation epilogues (the wide-tile form clamps with v_med3_f32, the
+    others with two selects): a NaN must come out as 0, +inf as the upper bound, exactly as the oracle's act_apply
+    (`v > 0 ? v : 0`, then `v < 6 ? v : 6`) produces them."""
+    B, H, W, Cin, Cout, k = shape
+    rng = np.random.default_rng(Cin + Cout + k)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    x[0, 3, 4, 5] = np.nan
+    x[0, 7, 7, 9] = np.inf
+    x[B - 1, 9, 2, 1] = -np.inf
+    w = (rng.standard_normal((k, k, Cin, Cout)) * np.sqrt(2.0 / (k * k * Cin))).astype(np.float32)
+    g, b, m, v = bn_params(rng, Cout)
+    with np.errstate(all="ignore"):
+        ref = oracle_ops.bn_act(oracle_ops.conv2d(x, w, 1, "SAME"), g, b, m, v, act)
+    assert not np.isnan(ref).any() and (ref == 0).any()      # (ReLU keeps +inf; ReLU6 turns it into 6)
+    for tile in ("128", "64"):
+        os.environ["SSD_IGEMM_TILE"] = tile
+        try:
+            got = ssd.ssd.conv2d(dev(cuda, x), w, 1, "SAME", bn=(m, oracle_ops.bn_scale(g, v), b), act=act).cpu().numpy()
+        finally:
+            del os.environ["SSD_IGEMM_TILE"]
+        assert np.array_equal(got, ref), "tile %s: %d of %d values differ" % (tile, int((got != ref).sum()), ref.size)
 
 
 @pytest.mark.parametrize("cout", [96, 192, 480])
