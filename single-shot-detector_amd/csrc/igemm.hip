@@ -183,19 +183,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     const int KC = Cin >> 5;
     const int KS = TAPS * KC;
     v4f ra[NA], rb[NB];
+    typedef v4f (&RegA)[NA];
+    typedef v4f (&RegB)[NB];
     unsigned offc[NA], offn[NA];       // A offsets of the load stream's tap and of the next tap
     int ltap = 0, lkc = 0, kload = 0;  // coordinates of the NEXT K-step to load
     tap_offsets(0, offc);
     tap_offsets(1, offn);
-    auto gload = [&]() {
+    auto gload_into = [&](RegA qa, RegB qb) __attribute__((always_inline)) {
         const int so = lkc * 128;      // scalar offset: 32 channels per K-step
 #pragma unroll
         for (int u = 0; u < NA; ++u)
-            ra[u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)offc[u], so, 0));
+            qa[u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)offc[u], so, 0));
 #pragma unroll
         for (int u = 0; u < NB; ++u)
-            rb[u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(brsrc, bvoff + u * b_ustride, ltap * b_tapstride + so, 0));
+            qb[u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(brsrc, bvoff + u * b_ustride, ltap * b_tapstride + so, 0));
     };
+    auto gload = [&]() __attribute__((always_inline)) { gload_into(ra, rb); };
     // advance the load stream by one K-step (uniform branch once per tap; kept out of the
     // MFMA phases).  Past the last step the counters stay put: the software pipeline's
     // surplus prefetch re-reads valid memory.
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     const int woff_h = (tid >> 3) * 128 + ((((tid & 6)) ^ ((tid >> 4) & 7)) << 4) + (tid & 1) * 8;
     const int woff_l = (tid >> 3) * 128 + ((((tid & 6) + 1) ^ ((tid >> 4) & 7)) << 4) + (tid & 1) * 8;
     bool in_ovf = false;               // S16 == 2: a staged fp32 value was outside the fp16 range (or NaN) -> status word
-    auto lstore = [&](int stage) {
+    auto lstore_from = [&](int stage, RegA ra, RegB rb) __attribute__((always_inline)) {
         unsigned char *base = lds + stage * STAGE;
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
@@ -238,6 +241,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 #pragma unroll
         for (int u = 0; u < NB; ++u) *(v4f *)(base + A_BYTES + woff + u * (RPP * 128)) = rb[u];
     };
+    auto lstore = [&](int stage) __attribute__((always_inline)) { lstore_from(stage, ra, rb); };
     // ---- fragment reads / MFMA phases -------------------------------------------------
     // A K-step is four phases (one 8-channel octet each, 4*WM*WN MFMAs = 4*WM*WN*64 pipe
     // cycles).  Phase g issues the LDS reads of octet g+1 FIRST and then its MFMAs, so a
@@ -281,11 +285,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 
     if constexpr (!S16) {
     v4f fa0[WM], fb0[WN], fa1[WM], fb1[WN];
-    gload();
-    gadvance();
-    lstore(0);
-    gload();
-    gadvance();
+    // Two register sets: the loads of K-step j are issued during step j-3 and written to LDS during step j-1 (set j & 1
+    // is written in phase 0 of a step and reloaded in its phase 1), so a load has two K-steps to arrive instead of
+    // three quarters of one -- the 16-step 1x1 launches, whose blocks all fetch at once, were waiting for them.
+    // (The 64-wide tiles keep one set: five blocks per CU need <= 96 VGPRs.)
+    constexpr bool DEEP = BM * BN >= 128 * 64;
+    v4f ra1[DEEP ? NA : 1], rb1[DEEP ? NB : 1];
+    if constexpr (DEEP) {
+        gload_into(ra, rb);        // step 0
+        gadvance();
+        gload_into((RegA)ra1, (RegB)rb1);      // step 1
+        gadvance();
+        lstore_from(0, ra, rb);
+        gload_into(ra, rb);        // step 2
+        gadvance();
+    } else {
+        gload();
+        gadvance();
+        lstore(0);
+        gload();
+        gadvance();
+    }
     __syncthreads();
     mark(1);
     rdfrag(0, 0, fa0, fb0);
@@ -294,14 +314,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     // MFMA, each taking an issue slot from the matrix pipe).  The loop runs the steps in pairs, stage 0 then stage 1.
     auto kstep = [&](auto cur_tag) __attribute__((always_inline)) {
         constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
-        // phase 0: registers (step ks+1) -> LDS stage nxt
+        // phase 0: registers (step ks+1, set nxt) -> LDS stage nxt
         if (DBG < 2) rdfrag(cur, 1, fa1, fb1);
-        if (DBG < 1) lstore(nxt);
+        if (DBG < 1) { if constexpr (DEEP && nxt) lstore_from(nxt, (RegA)ra1, (RegB)rb1); else lstore_from(nxt, ra, rb); }
         mfma16(fa0, fb0);
         phase_sched(1, NA + NB, 0);
-        // phase 1: global loads of step ks+2 -> registers
+        // phase 1: global loads of step ks+3 (one set: ks+2) -> the set just written
         if (DBG < 2) rdfrag(cur, 2, fa0, fb0);
-        if (DBG < 1) gload();
+        if (DBG < 1) { if constexpr (DEEP && nxt) gload_into((RegA)ra1, (RegB)rb1); else gload_into(ra, rb); }
         mfma16(fa1, fb1);
         phase_sched(1, 0, NA + NB);
         // phase 2
