@@ -325,6 +325,7 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
     }
     if (scan_marked) *scan_marked = a.scan_bits != nullptr;
     a.n_tiles_n = a.CoutPad / (tile == IGEMM16_TILE ? 256 : igemm_tile_bn(tile));
+    a.dN = ssd_udiv_make((unsigned)a.n_tiles_n);
     a.dense_out = dense ? 1 : 0;
     int tiles = 0;
     double rows = 0, inb = 0;
@@ -333,6 +334,8 @@ static Op make_conv_op(const ConvW &cw, const float *in, float *out, float *out2
         IgemmLevel &L = a.lv[i];
         L.H = lv[i].H; L.W = lv[i].W; L.OH = lv[i].OH; L.OW = lv[i].OW;
         L.M = B * L.OH * L.OW;
+        L.dP = ssd_udiv_make((unsigned)(L.OH * L.OW));
+        L.dOW = ssd_udiv_make((unsigned)L.OW);
         L.tile_begin = tiles;
         tiles += (L.M + BM - 1) / BM;
         L.param_off = lv[i].param_off;

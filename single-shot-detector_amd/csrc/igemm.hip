@@ -64,6 +64,11 @@ static __device__ __forceinline__ v4f join_f16(const v2u hi, const v2u lo)
     return v;
 }
 
+__device__ __forceinline__ unsigned udiv(unsigned n, UDiv u)      // ssd_internal.h: n < 2^31
+{
+    return u.sh < 0 ? n : __umulhi(n, u.mag) >> u.sh;
+}
+
 // DBG (timing experiments only, results are wrong): 1 = no global loads / LDS writes in the
 // K loop, 2 = additionally no LDS fragment reads, 3 = additionally no barrier.
 // DBG 7 (results are right): thread 0 of every block records 100 MHz timestamps of its phases.
@@ -98,8 +103,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
         swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tile_n = swz % a.n_tiles_n;
-    const int tile_m = swz / a.n_tiles_n;
+    const int tile_m = (int)udiv((unsigned)swz, a.dN);
+    const int tile_n = swz - tile_m * a.n_tiles_n;
     int lvl = 0;
 #pragma unroll
     for (int i = 1; i < SSD_MAX_LEVELS; ++i)
@@ -135,8 +140,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
             abase0[u] = (mm * Cin + (tid & 7) * 4) * 4;
             amask[u] = rowok ? 1u : 0u;
         } else {
-            const int b = mm / P, p = mm - b * P;
-            const int oy = p / OW, ox = p - oy * OW;
+            const int b = (int)udiv((unsigned)mm, L.dP), p = mm - b * P;
+            const int oy = (int)udiv((unsigned)p, L.dOW), ox = p - oy * OW;
             const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
             abase0[u] = (b * H * W * Cin + (tid & 7) * 4) * 4 + (iy0 * W + ix0) * Cin * 4;
             unsigned vx = 0, mk = 0;                              // bit 3*ky + kx
@@ -493,8 +498,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         // lane advance by ROWS_PER_IT, i.e. by (qR images, rR positions) with one possible wrap.
         const int row0 = (lane / C4N) % ROWS_PER_IT;
         const int mfirst = m0 + wave_m * WM * 32 + row0;
-        const int b0 = mfirst / P, p0 = mfirst - b0 * P;
-        const int qR = ROWS_PER_IT / P, rR = ROWS_PER_IT - qR * P;
+        const int b0 = (int)udiv((unsigned)mfirst, L.dP), p0 = mfirst - b0 * P;
+        const int qR = (int)udiv((unsigned)ROWS_PER_IT, L.dP), rR = ROWS_PER_IT - qR * P;
         const int bstride = (int)L.out_bstride, rstride = L.out_rstride;
         const int step = (qR * bstride + rR * rstride) * 4, wrapstep = (bstride - P * rstride) * 4;   // bytes
         // upsample-add operand (FPN laterals): all rows' loads first, then ONE wait (see below)
@@ -505,8 +510,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
                 const int m = mfirst + it * ROWS_PER_IT;
                 rv[it] = v4f{0.f, 0.f, 0.f, 0.f};
                 if (m < M && colok) {
-                    const int b = m / P, p = m - b * P;
-                    const int oy = p / OW, ox = p - oy * OW;
+                    const int b = (int)udiv((unsigned)m, L.dP), p = m - b * P;
+                    const int oy = (int)udiv((unsigned)p, L.dOW), ox = p - oy * OW;
                     const int ch = L.OH >> 1, cw = OW >> 1;
                     const float *rrow = a.res + L.res_off + (((long long)b * ch + (oy >> 1)) * cw + (ox >> 1)) * a.Cout;
                     if (a.res_fmt) rv[it] = join_f16(*(const v2u *)(rrow + col16), *(const v2u *)(rrow + col16 + 4));

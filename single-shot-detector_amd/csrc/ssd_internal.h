@@ -18,6 +18,21 @@ static inline int ssd_logical_of_phys(int p) { int o = p & ~7, r = p & 7; return
 
 #define SSD_MAX_LEVELS 5
 
+// floor(n / d) for 0 <= n < 2^31 without a division (Granlund-Montgomery: l = ceil(log2 d), mag = ceil(2^(31+l) / d) < 2^32,
+// q = mulhi(n, mag) >> (l - 1); d == 1: sh < 0, q = n).  The compiler's run-time division is ~22 vector instructions, this
+// is 2-3; the kernels' prologues and epilogues are paid in issue slots.  Host side fills, device side divides.
+struct UDiv { unsigned mag; int sh; };
+static inline UDiv ssd_udiv_make(unsigned d)
+{
+    UDiv u;
+    if (d <= 1) { u.mag = 0; u.sh = -1; return u; }
+    int l = 0;
+    while ((1u << l) < d) ++l;
+    u.mag = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+    u.sh = l - 1;
+    return u;
+}
+
 struct IgemmLevel {
     int H, W;              // input spatial size
     int OH, OW;            // output spatial size
@@ -29,6 +44,7 @@ struct IgemmLevel {
     long long out_off;     // float offset of output (image 0, position 0)
     long long out_bstride; // floats between images in the output
     long long res_off;     // float offset of the coarse tensor [B,OH/2,OW/2,Cout] (upsample-add)
+    UDiv dP, dOW;          // division by OH*OW and by OW
 };
 
 struct IgemmArgs {
@@ -45,6 +61,7 @@ struct IgemmArgs {
     int act;
     int nlevels;
     int n_tiles_n;
+    UDiv dN;               // division by n_tiles_n
     int dense_out;         // 1: out_bstride == OH*OW*out_rstride for every level
     // precision mode f16x3 (igemm.hip, "S16"): formats of the activations this launch touches
     int in_fmt;            // 1: `in` rows and `wt` rows are split-fp16 (h|l per octet), MFMA f16 x3;
