@@ -12,8 +12,14 @@
 //   LDS         2 stages x (BM + BN) rows x 128 B; row r keeps its eight 16-B chunks
 //               at chunk ^ ((r >> 1) & 7): ds_read_b128 of 16 rows x 1 chunk and
 //               ds_write_b128 of 1 row x 8 chunks are both bank-conflict free.
-//   pipeline    global_load_dwordx4 of K-step s+1 -> registers while the MFMAs of
+//   pipeline    global_load_dwordx4 of a later K-step -> registers while the MFMAs of
 //               K-step s run from LDS; registers -> LDS (other stage); one barrier.
+//               fp32 operands: the loop runs its K-steps in pairs (LDS stage = compile-time
+//               constant: no vector address arithmetic per step), the wide tiles keep two
+//               register sets (loads three steps ahead); tap changes and row decompositions
+//               use per-row masks and host-made multiply-shift divisors -- the exact-fp32
+//               MFMA shares the SIMD's issue with every other vector instruction, so the
+//               kernel is tuned by instruction count.
 //   numerics    each output element is ONE accumulator that receives its k terms in
 //               increasing logical (ky,kx,ci) order: bit-identical to the fmaf chain
 //               of the oracle.  Epilogue ops are separately rounded (-ffp-contract=off).
