@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 #pragma unroll
     for (int i = 1; i < SSD_MAX_LEVELS; ++i)
         if (i < a.nlevels && tile_m >= a.lv[i].tile_begin) lvl = i;
-    const IgemmLevel &L = a.lv[lvl];
+    const IgemmLevel L = a.lv[lvl];       // by value: one wide scalar load up front (a reference re-reads its fields, each behind its own wait)
     const int H = L.H, W = L.W, OW = L.OW, M = L.M;
     const int P = L.OH * L.OW;
     const int Cin = a.Cin;
@@ -172,24 +172,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     const int b_tapstride = a.CoutPad * Cin * 4;
     const int woff = (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
 
-    // ---- per-lane fragment read offsets (4 octets of the 32-channel K-step)
+    // ---- per-lane fragment read offsets (4 octets of the 32-channel K-step) and the accumulators: filled by late_init(),
+    // which the pipelines call right BEHIND their first global loads -- nothing here is needed to issue those, and every
+    // instruction in front of them is latency the block's first MFMA waits for (the blocks of a 1x1 launch sit in their
+    // prologues together).
     int roff[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        // fp32: octet g, lanes 0-31 physical channels 0-3, lanes 32-63 physical 4-7.
-        // S16: g = 2*s + hl: 16-channel step s, lane group (lane >> 5) takes octet 2s + group,
-        //      hl = 0 the h chunk, 1 the l chunk of that octet.
-        const int chunk = S16 ? ((g >> 1) * 4 + 2 * (lane >> 5) + (g & 1)) : (2 * g + (lane >> 5));
-        roff[g] = (lane & 31) * 128 + ((chunk ^ (((lane & 31) >> 1) & 7)) << 4);
-    }
-
     v16f acc[WM][WN];
+    auto late_init = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+        for (int g = 0; g < 4; ++g) {
+            // fp32: octet g, lanes 0-31 physical channels 0-3, lanes 32-63 physical 4-7.
+            // S16: g = 2*s + hl: 16-channel step s, lane group (lane >> 5) takes octet 2s + group,
+            //      hl = 0 the h chunk, 1 the l chunk of that octet.
+            const int chunk = S16 ? ((g >> 1) * 4 + 2 * (lane >> 5) + (g & 1)) : (2 * g + (lane >> 5));
+            roff[g] = (lane & 31) * 128 + ((chunk ^ (((lane & 31) >> 1) & 7)) << 4);
+        }
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    };
 
     const int KC = Cin >> 5;
     const int KS = TAPS * KC;
@@ -307,12 +312,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         gadvance();
         gload_into((RegA)ra1, (RegB)rb1);      // step 1
         gadvance();
+        late_init();
         lstore_from(0, ra, rb);
         gload_into(ra, rb);        // step 2
         gadvance();
     } else {
         gload();
         gadvance();
+        late_init();
         lstore(0);
         gload();
         gadvance();
@@ -427,6 +434,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     v4f ah0[WM], al0[WM], bh0[WN], bl0[WN], ah1[WM], al1[WM], bh1[WN], bl1[WN];
     gload();
     gadvance();
+    late_init();
     lstore(0);
     gload();
     gadvance();
