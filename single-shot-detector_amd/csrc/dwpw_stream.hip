@@ -233,6 +233,10 @@ __global__ __launch_bounds__(256, (STRIDE == 1 && WN == 1) ? 3 : 2) void dwpw_st
     if ((abl & 32) && (blockIdx.x >= gridDim.x / 2)) { for (int z = 0; z < ((abl >> 8) & 255); ++z) __builtin_amdgcn_s_sleep(127); }   // experiment: start stagger
     if (abl & 64) { const int ph8 = (blockIdx.x >> 3) & 7; for (int z = 0; z < ph8 * ((abl >> 8) & 255); ++z) __builtin_amdgcn_s_sleep(2); }   // 8 start phases, 128-cycle units
 #endif
+    // a.dact / a.act are uniform: "ReLU, then min with 6 or +inf" when an activation follows, nothing otherwise -- as plain
+    // selects on precomputed uniform bounds (lo = 0 or -inf, hi = 6 or +inf) instead of reading the codes per value
+    const bool dact_on = a.dact >= 1, pact_on = a.act >= 1;
+    const float dact_hi = a.dact == 2 ? 6.0f : __builtin_inff(), pact_hi = a.act == 2 ? 6.0f : __builtin_inff();
     for (int it = 0; it < T; ++it) {
         // landed after this wait: patch(it), B(it), weights(it) -- everything older than patch(it+1) and the stores of
         // the previous iteration's epilogue
@@ -272,8 +276,7 @@ __global__ __launch_bounds__(256, (STRIDE == 1 && WN == 1) ? 3 : 2) void dwpw_st
                 for (int e = 0; e < 4; ++e) {
                     const float t = (v[e] - dm[e]) * ds[e];
                     v[e] = t + db[e];
-                    if (a.dact >= 1) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-                    if (a.dact == 2) v[e] = v[e] < 6.0f ? v[e] : 6.0f;
+                    if (dact_on) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.0f, dact_hi);
                 }
                 const int r = (ty0 + o) * TX + tx;
                 *(v4f *)(lds + OFF_A + r * 128 + ((c4 ^ ((r >> 1) & 7)) << 4)) = v;
@@ -326,8 +329,7 @@ __global__ __launch_bounds__(256, (STRIDE == 1 && WN == 1) ? 3 : 2) void dwpw_st
                         float x = acc[j][4 * m + e];
                         const float t = (x - mean[e]) * sf[e];
                         x = t + beta[e];
-                        if (a.act >= 1) x = x > 0.0f ? x : 0.0f;
-                        if (a.act == 2) x = x < 6.0f ? x : 6.0f;
+                        if (pact_on) x = __builtin_amdgcn_fmed3f(x, 0.0f, pact_hi);
                         v[e] = x;
                         acc[j][4 * m + e] = 0.0f;
                     }
