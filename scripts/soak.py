@@ -1,6 +1,6 @@
 """Race screen at full size: N forwards of the bench workload (32 frames of 640x896, precision f16x3, two
 streams, 256x256-tile kernel with LDS-DMA staging and the fused candidate bitmap) on the same input must all
-give the same bits as the first.  usage: python scripts/soak_f16x3.py [N]"""
+give the same bits as the first.  usage: python scripts/soak.py [N] [f16x3|f32] [mobilenet|shufflenet]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,10 +8,14 @@ import torch
 import ssd_amd
 import bench
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-Wt = ssd_amd.synthetic_weights(bench.PARAMS, seed=0, logits_bias=bench.LOGITS_BIAS)
-eng = ssd_amd.Engine(bench.PARAMS, Wt, precision="f16x3")
+MODE = sys.argv[2] if len(sys.argv) > 2 else "f16x3"
+NET = sys.argv[3] if len(sys.argv) > 3 else "mobilenet"
+PARAMS = bench.PARAMS if NET == "mobilenet" else bench.PARAMS_SHUFFLE
+Wt = ssd_amd.synthetic_weights(PARAMS, seed=0, logits_bias=bench.LOGITS_BIAS[NET])
+eng = ssd_amd.Engine(PARAMS, Wt, precision=MODE)
 g = torch.Generator().manual_seed(1234)
-frames = torch.randint(0, 256, (32, bench.H, bench.W, 3), dtype=torch.uint8, generator=g).cuda()
+shape = (32, bench.H, bench.W, 3) if NET == "mobilenet" else (64, 640, 640, 3)
+frames = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g).cuda()
 first = [t.clone() for t in eng.forward(frames)]
 bad = 0
 for i in range(N):
