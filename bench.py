@@ -96,21 +96,20 @@ def cpu_baseline(budget_s=12.0):
                       % (len(times), best_t, ncpu, med)}
 
 
-def latency_batch1(engine):
-    """inference/just_try_detector.ipynb:149-155: 110 calls of the batch-1 detector on one
-    host uint8 image (H2D + graph + D2H + score filter), first 10 dropped."""
+def latency_batch1(detector):
+    """inference/just_try_detector.ipynb:149-155, through the boundary class itself: 110 calls of
+    `Detector.__call__(image, score_threshold=0.5)` on one host uint8 image (pinned staging + H2D, graph, ONE packed
+    D2H, score filter; numpy in -> numpy out), first 10 dropped."""
     img = np.random.default_rng(0).integers(0, 256, (H, W, 3), dtype=np.uint8)
     times = []
     for _ in range(110):
         t0 = time.perf_counter()
-        boxes, labels, scores, num = engine.forward_cached(img[None])     # what Detector.__call__ does
-        n = int(num.cpu()[0])
-        s = scores[0, :n].cpu().numpy()
-        keep = s > 0.5
-        _ = boxes[0, :n].cpu().numpy()[keep], labels[0, :n].cpu().numpy()[keep], s[keep]
+        boxes, labels, scores = detector(img, score_threshold=0.5)
         times.append(time.perf_counter() - t0)
     t = np.array(times[10:]) * 1e3
-    return {"p50_ms": float(np.percentile(t, 50)), "mean_ms": float(t.mean()), "std_ms": float(t.std())}
+    return {"p50_ms": float(np.percentile(t, 50)), "mean_ms": float(t.mean()), "std_ms": float(t.std()),
+            "protocol": "Detector.__call__, host ndarray in -> filtered numpy out, 110 calls, first 10 dropped",
+            "detections_over_0.5": int(len(scores))}
 
 
 def free_port():
@@ -175,12 +174,13 @@ def kernel_tables(prof, steps):
 class Timed:
     """W warm-up steps, then exactly K steps between two fences (device sync + barrier)."""
 
-    def __init__(self, world, dist, sync, dev):
+    def __init__(self, world, dist, sync, dev, use_dist=None):
         self.world, self.dist, self.sync, self.dev = world, dist, sync, dev
+        self.use_dist = world > 1 if use_dist is None else use_dist
 
     def fence(self):
         self.sync()
-        if self.world > 1:
+        if self.use_dist:
             self.dist.barrier()
             self.sync()
 
@@ -198,7 +198,7 @@ class Timed:
         dt = time.perf_counter() - t0
         engine.profile_enable(False)
         prof = engine.profile_read()
-        if self.world > 1:      # MAX over ranks
+        if self.use_dist:       # MAX over ranks
             t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -244,7 +244,7 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step (BASELINE config 5: 256/8)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 = BASELINE config 5: 256/8; 64 with --config shufflenet)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="total images per step over all GPUs (default --batch x --gpus); a count the GPUs do not divide "
                          "gives uneven contiguous shards")
@@ -262,14 +262,25 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-shufflenet", action="store_true", help="skip the config-4 object (N = 1 only anyway)")
     ap.add_argument("--no-other-precision", action="store_true")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="a kernel / schedule selector of the library for this run (ssd_set_option, include/ssd_hip.h; A/B runs: "
+                         "scripts/ab_opt.sh); none changes a result bit in mode f32")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the collective path (init_process_group on RCCL, the ranks_seen gather, the all-gather of the detection "
+                         "records, the all-reduces and the final barrier) even at world size 1 -- what a launch under "
+                         "`torch.distributed.run --nproc-per-node 1` does too (WORLD_SIZE=1 in the environment)")
     args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.global_batch and args.global_batch < args.gpus:
+        ap.error("--global-batch (%d) is smaller than --gpus (%d): some rank would get an empty shard" % (args.global_batch, args.gpus))
     argv = list(sys.argv[1:] if argv is None else argv)
     net = args.config
     params = PARAMS if net == "mobilenet" else PARAMS_SHUFFLE
     Hh, Ww = (H, W) if net == "mobilenet" else (640, 640)
+    if args.batch is None:
+        args.batch = 64 if net == "shufflenet" else 32
     if net == "shufflenet":
-        if "--batch" not in " ".join(argv):
-            args.batch = 64
         args.no_latency = args.no_shufflenet = args.no_cpu_baseline = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -290,8 +301,12 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
         torch.cuda.set_device(local)
         dev, sync = torch.device("cuda", local), torch.cuda.synchronize
     ranks_seen = [0]
-    if world > 1:
+    # inside a torch.distributed.run launch (WORLD_SIZE set, also = 1) or with --force-dist the collective path runs
+    use_dist = world > 1 or args.force_dist or "WORLD_SIZE" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(free_port())
         if stub:
             dist.init_process_group(backend, rank=rank, world_size=world)
         else:
@@ -300,18 +315,26 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
         dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int32, device=dev))
         ranks_seen = [int(v) for v in ids.cpu()]
 
+    for kv in args.option:
+        k, v = kv.split("=", 1)
+        ssd_amd.set_option(k, int(v, 0))
     B = args.batch
     total = args.global_batch or B * world
     Wt = ssd_amd.synthetic_weights(params, seed=0, logits_bias=LOGITS_BIAS[net])
-    engine = engine_factory(params, Wt, local) if stub else ssd_amd.Engine(params, Wt, device=local, precision=args.precision)
+    detector = None
+    if stub:
+        engine = engine_factory(params, Wt, local)
+    else:       # the boundary class (inference/detector.py:5-60) owns the engine; the throughput legs drive its engine directly
+        detector = ssd_amd.Detector(Wt, visible_device_list=str(local), config=params, precision=args.precision)
+        engine = detector.engine
     # this rank's shard of the global batch, resident in HBM before the timed region
     lo, hi = ssd_amd.shard_range(total, rank, world)
     g = torch.Generator().manual_seed(1234 + rank)
     frames = torch.randint(0, 256, (hi - lo, Hh, Ww, 3), dtype=torch.uint8, generator=g).to(dev)
-    timed = Timed(world, dist, sync, dev)
+    timed = Timed(world, dist, sync, dev, use_dist)
 
     def step():
-        return ssd_amd.detect_sharded(engine, frames, total=total)
+        return ssd_amd.detect_sharded(engine, frames, total=total, force=use_dist)
 
     dt, out, prof = timed.run(engine, step, args.steps, args.warmup)
     assert out[0].shape[0] == total, (out[0].shape, total)
@@ -319,7 +342,7 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
     def status_all_ranks():
         """bit 0: an f16x3 activation left the fp16 range on SOME rank since the last call (0 in mode f32)."""
         v = engine.status()
-        if world > 1:
+        if use_dist:
             t = torch.tensor([v], dtype=torch.int32, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             v = int(t.item())
@@ -356,16 +379,16 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
     if not stub:
         # the same step with the boundary's host buffers in the loop (pinned host frames -> HBM,
         # detections -> host); reported beside `value`, never as `value`
-        host_frames = frames.cpu().pin_memory()
+        host_frames = frames.cpu().numpy()
         sync()
-        n_p = max(2, args.steps // 2)
+        n_p = max(4, args.steps)
+        it = detector.detect_stream(host_frames for _ in range(n_p + 1))
+        next(it)                               # the first batch fills the pipeline (and builds nothing new: same shape)
         t1 = time.perf_counter()
-        for _ in range(n_p):
-            d = host_frames.to(dev, non_blocking=True)
-            o = engine.forward(d)
-            _ = [t.cpu() for t in o]
-        sync()
+        for o in it:
+            pass
         pcie_img_s = (hi - lo) * n_p / (time.perf_counter() - t1)
+        pcie_ok = all(np.array_equal(a, b.cpu().numpy()) for a, b in zip(o, [t[lo:hi] for t in out])) if args.precision == "f32" else None
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -378,7 +401,7 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
             "dtype": "f32" if args.precision == "f32" else "f32 carried as split f16 pairs (3 x f16 MFMA, f32 accumulate)",
             "precision": args.precision, "status_word": status_value,
             "data": "synthetic" if not stub else "STAND-IN ENGINE (launcher test, no GPU work)",
-            "ranks_seen": ranks_seen,
+            "ranks_seen": ranks_seen, "collective_path": bool(use_dist),
             "config": {"workload": ("MobileNet-v1 + FPN + RetinaNet heads + decode + per-class NMS, 640x896 (HxW) "
                                     "uint8 frames, %d per GPU (BASELINE config 5 shard; config 2 = same graph at batch 1, "
                                     "see latency_batch1; config 4 = the shufflenet_config4 object)" % B) if net == "mobilenet" else
@@ -388,6 +411,7 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
                        "shards": [list(ssd_amd.shard_range(total, r, world)) for r in range(world)],
                        "parallelism": "dp%d" % world,
                        "weights": "random-init (seed 0), logits bias %.1f" % LOGITS_BIAS[net],
+                       "library_options": args.option,
                        "detections_per_image": det_per_image},
         }
         if not stub:
@@ -395,6 +419,11 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
             res["roofline"] = roofline_block(prof, args.precision, args.steps, None if net == "mobilenet" else "shufflenet_" + args.precision)
             res["kernel_ms_per_step"], res["kernel_rates"] = ms, rates
             res["pcie_inclusive_img_s_per_gpu"] = pcie_img_s
+            res["pcie_inclusive"] = {"img_s_per_gpu": pcie_img_s, "ratio_to_resident": pcie_img_s * world / (total * args.steps / dt),
+                                     "outputs_equal_resident_run": pcie_ok,
+                                     "path": "Detector.detect_stream: host uint8 batches -> pinned staging -> H2D on a copy stream, "
+                                             "forward, packed D2H on a second copy stream, numpy out; copies of batches k+1 / k-1 under "
+                                             "the compute of batch k"}
             # 1.113 ms/img at the per-layer roofline of the exact-fp32 arithmetic
             res["whole_net_roofline_frac"] = ROOFLINE_MS[net] * (hi - lo) / ms_step if args.precision == "f32" else None
             if other_res:
@@ -403,7 +432,7 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
                 lat = {}
                 for mode in ("f32", "f16x3"):
                     engine.set_precision(mode)
-                    lat[mode] = latency_batch1(engine)
+                    lat[mode] = latency_batch1(detector)
                 engine.set_precision(args.precision)
                 res["latency_batch1"] = dict(lat[args.precision], precision=args.precision,
                                              roofline_ms=ROOFLINE_MS["mobilenet"], by_precision=lat)
@@ -414,7 +443,7 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
                 res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
         sys.stdout.flush()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

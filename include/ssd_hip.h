@@ -28,7 +28,11 @@
  *     stage entry points that take host weights (ssd_conv2d, ssd_depthwise3x3, ssd_dw_pw,
  *     ssd_first_conv, ssd_concat_shuffle_split) are test conveniences and synchronise before
  *     returning.
- *   - one handle per device; calls on one handle must be serialised by the caller.
+ *   - one handle per device.  Every entry point that takes a handle holds the handle's mutex, so concurrent calls on
+ *     one handle are serialised by the library, and a forward enqueued on another stream than the previous one first
+ *     waits for that one's last kernel (the arena is one per handle): two host threads may share a handle the way they
+ *     may share a tf.Session (inference/detector.py:34,52).  The OUTPUT buffers belong to the caller, who must not let
+ *     two in-flight forwards write the same ones.
  */
 #ifndef SSD_HIP_H
 #define SSD_HIP_H
@@ -94,6 +98,29 @@ const char *ssd_last_error(void);
  * takes its mode from the environment variable SSD_PRECISION ("f32" | "f16x3"), default f32. */
 int ssd_set_precision(ssd_handle *h, int32_t mode /* SSD_PRECISION_* */);
 int ssd_get_precision(ssd_handle *h);
+/* Tuning / test switches.  None changes a result bit in mode F32 (each selects among kernels or schedules that are
+ * bit-identical by construction and by test); the library reads NO environment variable for them (SSD_PRECISION above is
+ * the only one it reads).  `h` == NULL sets the process-wide value, which the handle-less stage entry points below use and
+ * which a handle falls back to for an option it has not been given itself; with a handle the call synchronises and drops
+ * the cached layer plan.  Keys (value; default):
+ *   "igemm_tile"      0 auto | 128 | 64 pin the tile of the 128x128-class launches | 20..23 pin a wave tile of the latency
+ *                     form (1x1, 1x2, 2x1, 2x2 sixteen-wide units) wherever that form applies           (0)
+ *   "igemm_lat"       1 | 0: tiny exact-fp32 launches on the latency form (v_mfma_f32_16x16x4_f32)      (1)
+ *   "igemm_deep64"    -1 auto | 0 | 1: 64x64 tiles with operand loads three K-steps ahead                (-1)
+ *   "streams"         0 auto | 1: every kernel of a forward on one stream, in plan order                 (0)
+ *   "igemm16"         -1 auto | 0 | 1: F16X3 launches on the 256x256-tile kernel                         (-1)
+ *   "igemm_96"        1 | 0: 128x96 tiles for widths 96 divides and 128 does not (read by ssd_finalize)  (1)
+ *   "lateral_split"   1 | 0: F16X3 laterals split fp32 rows while staging them                           (1)
+ *   "backbone_split"  0 auto | 1..4: MobileNet backbone chains                                           (0)
+ *   "nsub"            0 auto | 1..8: staggered sub-batch plans                                            (0)
+ *   "level_split"     0 | 1: head towers of levels 6-7 as launches of their own (batch <= 2)             (0)
+ *   "nms_fast_max"    -1 default | n >= 0: candidate lists up to n stay in one wave's registers          (-1)
+ *   "fuse_dw"         -1 default | bit mask of depthwise+pointwise pairs that run as one launch          (-1)
+ *   "graph"           0 | 1: hipGraph replay of a repeating forward                                      (0)
+ *   "debug_sync"      0 | 1: announce every op on stderr, run it alone and wait for it                   (0)
+ * ssd_get_option returns the value in effect (handle, else process), INT32_MIN when neither was set. */
+int ssd_set_option(ssd_handle *h, const char *key, int32_t value);
+int ssd_get_option(ssd_handle *h, const char *key, int32_t *value);
 /* Synchronises the device and returns (and clears) the handle's status word.  Bit 0: in
  * F16X3 mode an activation left the fp16 range (|x| > 65504) and was clamped -- the results
  * of the forwards since the last call are not trustworthy; re-run them in F32 mode. */

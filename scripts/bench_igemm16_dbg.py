@@ -21,7 +21,7 @@ for rnd in range(2):
               % (B, dbg, ms.value, gf.value / ms.value, gf.value / ms.value / 838.9), flush=True)
 os.environ["SSD_IGEMM16_DBG"] = "0"
 for igemm16 in ("0", "1"):
-    os.environ["SSD_IGEMM16"] = igemm16
+    ssd_amd.set_option("igemm16", int(igemm16))
     ms, gf = ctypes.c_double(), ctypes.c_double()
     check(L.ssd_bench_conv(B, 80, 112, 256, 256, 3, 1, 0, 10, 1, ctypes.byref(ms), ctypes.byref(gf)))
-    print("SSD_IGEMM16=%s: %7.3f ms %6.1f TFLOP/s" % (igemm16, ms.value, gf.value / ms.value), flush=True)
+    print("option igemm16=%s: %7.3f ms %6.1f TFLOP/s" % (igemm16, ms.value, gf.value / ms.value), flush=True)

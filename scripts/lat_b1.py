@@ -6,6 +6,9 @@ import numpy as np, torch, ssd_amd
 P = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
      "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 640}
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+for kv in sys.argv[2:]:          # library options, key=value
+    k, v = kv.split("=")
+    ssd_amd.set_option(k, int(v, 0))
 W = ssd_amd.synthetic_weights(P, seed=0, logits_bias=-7.5)
 e = ssd_amd.Engine(P, W)
 img = torch.randint(0, 256, (B, 640, 896, 3), dtype=torch.uint8).cuda()

@@ -12,9 +12,9 @@ Cin = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 path = "/tmp/ts16.bin"
 os.environ["SSD_TS_DUMP"] = path
 os.environ["SSD_BENCH_PRECISION"] = "f16x3"
-os.environ["SSD_IGEMM16"] = "1"
 ssd_amd._lib.use_diag()        # libssd_hip_diag.so: the -DSSD_DIAG build (include/ssd_hip_diag.h)
 L = ssd_amd.lib()
+ssd_amd.set_option("igemm16", 1)
 ms, gf = ctypes.c_double(), ctypes.c_double()
 check(L.ssd_bench_conv(B, 80, 112, Cin, 256, 3, 1, 17, 3, 1, ctypes.byref(ms), ctypes.byref(gf)))
 t = np.fromfile(path, dtype=np.int64).reshape(-1, 9)

@@ -11,7 +11,7 @@ from .config import load_config, INFERENCE_KEYS                       # noqa: F4
 from .variables import (variable_shapes, synthetic_weights, save_weights,   # noqa: F401
                         load_weights)
 from .pb_import import read_frozen_graph, load_pb_weights             # noqa: F401
-from ._lib import build, lib, lib_path, SsdError                       # noqa: F401
+from ._lib import build, lib, lib_path, SsdError, set_option, get_option                       # noqa: F401
 from .ssd import (SSD, AnchorGenerator, RetinaNetFeatureExtractor, RetinaNetBoxPredictor,     # noqa: F401
                   batch_multiclass_non_max_suppression, network_input_size, Engine)
 from .detector import Detector                                         # noqa: F401

@@ -9,7 +9,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SOURCES = ["api.hip", "igemm.hip", "igemm16.hip", "dwpw_stream.hip", "elementwise.hip", "postprocess.hip"]
+_SOURCES = ["abi.hip", "weights.hip", "plan.hip", "stages.hip", "igemm.hip", "igemm_lat.hip", "igemm16.hip", "dwpw_stream.hip",
+            "elementwise.hip", "postprocess.hip"]
 _LIB_PATH = os.path.join(_CSRC, "libssd_hip.so")
 _DIAG_PATH = os.path.join(_CSRC, "libssd_hip_diag.so")       # -DSSD_DIAG build, scripts/ only
 _lib = None
@@ -32,7 +33,7 @@ def build(force=False, verbose=False, diag=False):
     the same sources with -DSSD_DIAG (ablation kernels, tile overrides, phase stamps, ssd_bench_*;
     include/ssd_hip_diag.h) for scripts/ -- never loaded by the product."""
     srcs = [os.path.join(_CSRC, s) for s in _SOURCES]
-    deps = srcs + [os.path.join(_CSRC, "ssd_internal.h"),
+    deps = srcs + [os.path.join(_CSRC, "ssd_internal.h"), os.path.join(_CSRC, "host.h"),
                    os.path.join(_HERE, "..", "include", "ssd_hip.h"),
                    os.path.join(_HERE, "..", "include", "ssd_hip_diag.h")]
     target = _DIAG_PATH if diag else _LIB_PATH
@@ -139,6 +140,8 @@ SIGNATURES = {
                                   _vp, _i, _vp, _vp]),
     "ssd_conv2d_f16x3": (ctypes.c_int, [_vp, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f,
                                         _vp, _i, _vp, _vp]),
+    "ssd_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _i]),
+    "ssd_get_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _i32p]),
     "ssd_set_precision": (ctypes.c_int, [_vp, _i]),
     "ssd_get_precision": (ctypes.c_int, [_vp]),
     "ssd_status": (ctypes.c_int, [_vp, _i32p]),
@@ -184,6 +187,18 @@ def lib():
             fn.restype = res
             fn.argtypes = args
     return _lib
+
+
+def set_option(key, value, handle=None):
+    """ssd_set_option: a kernel / schedule selector of the library (include/ssd_hip.h lists the keys), process-wide when
+    `handle` is None.  None of them changes a result bit in mode f32."""
+    check(lib().ssd_set_option(handle, key.encode(), int(value)))
+
+
+def get_option(key, handle=None):
+    v = ctypes.c_int32()
+    check(lib().ssd_get_option(handle, key.encode(), ctypes.byref(v)))
+    return v.value
 
 
 def check(rc):

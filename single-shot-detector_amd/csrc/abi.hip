@@ -1,0 +1,393 @@
+// The C ABI of include/ssd_hip.h, handle side: lifetime, options, ssd_forward (= the frozen graph's sess.run),
+// retained tensors, per-class profiling.  Every entry point that takes a handle holds the handle's mutex.
+// No CPU fallback exists: every entry point either launches HIP kernels or fails.
+#include "host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+// ----------------------------------------------------------------------------- errors
+static thread_local std::string g_err;
+int ssd_fail(int code, const std::string &msg) { g_err = msg; return code; }
+extern "C" const char *ssd_last_error(void) { return g_err.c_str(); }
+
+// ----------------------------------------------------------------------------- options
+static Options g_opts;                 // process-wide values (ssd_set_option with a NULL handle)
+static std::mutex g_opts_mu;
+static const char *const OPT_NAMES[OPT_COUNT] = {"igemm_tile", "igemm16", "igemm_96", "lateral_split", "backbone_split", "nsub",
+                                                 "level_split", "nms_fast_max", "debug_sync", "fuse_dw", "graph", "igemm_lat", "igemm_deep64", "streams"};
+int ssd_opt_index(const char *key)
+{
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (key && !strcmp(key, OPT_NAMES[i])) return i;
+    return -1;
+}
+int ssd_opt(const ssd_handle *h, int key, int dflt)
+{
+    if (h && h->opts.v[key] != SSD_OPT_UNSET) return h->opts.v[key];
+    const int g = g_opts.v[key];
+    return g != SSD_OPT_UNSET ? g : dflt;
+}
+int nms_fast_max(const ssd_handle *h)
+{
+    const int v = ssd_opt(h, OPT_NMS_FAST_MAX, -1);
+    return v < 0 ? 0 : (v == 0 ? -1 : v);
+}
+
+extern "C" int ssd_set_option(ssd_handle *h, const char *key, int32_t value)
+{
+    const int k = ssd_opt_index(key);
+    if (k < 0) return ssd_fail(SSD_ERR_INVALID, std::string("ssd_set_option: unknown option ") + (key ? key : "(null)"));
+    if (!h) {
+        std::lock_guard<std::mutex> g(g_opts_mu);
+        g_opts.v[k] = value;
+        return SSD_OK;
+    }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->opts.v[k] == value) return SSD_OK;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    free_plans(h);                  // the layer plan depends on the options
+    h->opts.v[k] = value;
+    return SSD_OK;
+}
+
+extern "C" int ssd_get_option(ssd_handle *h, const char *key, int32_t *value)
+{
+    const int k = ssd_opt_index(key);
+    if (k < 0 || !value) return ssd_fail(SSD_ERR_INVALID, "ssd_get_option: unknown option or null argument");
+    *value = ssd_opt(h, k, SSD_OPT_UNSET);
+    return SSD_OK;
+}
+
+// ----------------------------------------------------------------------------- lifetime
+extern "C" int ssd_create(const ssd_config *cfg, ssd_handle **out)
+{
+    if (!cfg || !out) return ssd_fail(SSD_ERR_INVALID, "ssd_create: null argument");
+    if (cfg->backbone != SSD_BACKBONE_MOBILENET && cfg->backbone != SSD_BACKBONE_SHUFFLENET)
+        return ssd_fail(SSD_ERR_INVALID, "ssd_create: unknown backbone");
+    if (cfg->num_classes < 1 || cfg->max_boxes_per_class < 1)
+        return ssd_fail(SSD_ERR_INVALID, "ssd_create: num_classes and max_boxes_per_class must be >= 1");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return ssd_fail(SSD_ERR_INVALID, "ssd_create: no such HIP device");
+    HIPCHK(hipSetDevice(cfg->device));
+    ssd_handle *h = new ssd_handle();
+    h->cfg = *cfg;
+    if (hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_gin, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_gout, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming) != hipSuccess) {
+        delete h;
+        return ssd_fail(SSD_ERR_HIP, "ssd_create: cannot create events");
+    }
+    if (hipMalloc((void **)&h->flags_dev, sizeof(int)) != hipSuccess || hipMemset(h->flags_dev, 0, sizeof(int)) != hipSuccess) {
+        delete h;
+        return ssd_fail(SSD_ERR_HIP, "ssd_create: cannot allocate the status word");
+    }
+    if (const char *e = getenv("SSD_PRECISION")) {     // default for handles that never call ssd_set_precision
+        if (!strcmp(e, "f16x3")) h->precision = SSD_PRECISION_F16X3;
+        else if (!strcmp(e, "f32")) h->precision = SSD_PRECISION_F32;
+        else { (void)hipFree(h->flags_dev); delete h; return ssd_fail(SSD_ERR_INVALID, "SSD_PRECISION must be f32 or f16x3"); }
+    }
+    *out = h;
+    return SSD_OK;
+}
+
+extern "C" int ssd_set_precision(ssd_handle *h, int32_t mode)
+{
+    if (!h || (mode != SSD_PRECISION_F32 && mode != SSD_PRECISION_F16X3)) return ssd_fail(SSD_ERR_INVALID, "ssd_set_precision: bad arguments");
+    std::lock_guard<std::mutex> g(h->mu);
+    if (mode == h->precision) return SSD_OK;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    free_plans(h);                  // the layer plan (tensor formats, kernels) depends on the mode
+    h->precision = mode;
+    return SSD_OK;
+}
+
+extern "C" int ssd_get_precision(ssd_handle *h)
+{
+    if (!h) return SSD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    return h->precision;
+}
+
+extern "C" int ssd_status(ssd_handle *h, int32_t *flags_out)
+{
+    if (!h || !flags_out) return ssd_fail(SSD_ERR_INVALID, "ssd_status: null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    int v = 0;
+    HIPCHK(hipMemcpy(&v, h->flags_dev, sizeof(int), hipMemcpyDeviceToHost));
+    if (v) HIPCHK(hipMemset(h->flags_dev, 0, sizeof(int)));
+    *flags_out = v;
+    return SSD_OK;
+}
+
+extern "C" void ssd_destroy(ssd_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (auto &e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto r : h->ref_evs) (void)hipEventDestroy(r);
+    for (auto r : h->ev_pool) (void)hipEventDestroy(r);
+    free_plans(h);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->ev_gin) (void)hipEventDestroy(h->ev_gin);
+    if (h->ev_gout) (void)hipEventDestroy(h->ev_gout);
+    if (h->ev_last) (void)hipEventDestroy(h->ev_last);
+    if (h->gstream) (void)hipStreamDestroy(h->gstream);
+    if (h->flags_dev) (void)hipFree(h->flags_dev);
+    h->wpool.free_all();
+    delete h;
+}
+
+extern "C" int ssd_load_weight(ssd_handle *h, const char *name, const float *host, const int64_t *shape, int32_t ndim)
+{
+    if (!h || !name || !host || !shape || ndim < 1 || ndim > 4) return ssd_fail(SSD_ERR_INVALID, "ssd_load_weight: bad arguments");
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->finalized) return ssd_fail(SSD_ERR_STATE, "ssd_load_weight after ssd_finalize");
+    Tensor t;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 1) return ssd_fail(SSD_ERR_INVALID, "ssd_load_weight: non-positive dimension");
+        t.shape.push_back(shape[i]);
+        n *= shape[i];
+    }
+    t.data.assign(host, host + n);
+    h->vars[name] = std::move(t);
+    return SSD_OK;
+}
+
+extern "C" int ssd_finalize(ssd_handle *h)
+{
+    if (!h) return ssd_fail(SSD_ERR_INVALID, "ssd_finalize: null handle");
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->finalized) return ssd_fail(SSD_ERR_STATE, "ssd_finalize called twice");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    SSDCHK(finalize_weights(h));
+    h->vars.clear();   // host copies no longer needed
+    h->finalized = true;
+    return SSD_OK;
+}
+
+// One forward on stream `s` with the handle's mutex held.  The arena is one per handle: when this forward is enqueued on
+// another stream than the previous one it first waits for that one's last kernel (two host threads sharing a Detector on
+// their own streams, as tf.Session.run allows, inference/detector.py:34,52).
+static int forward_locked(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
+                          int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, hipStream_t s)
+{
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (B != h->pB || H != h->pH || W != h->pW) {
+        HIPCHK(hipDeviceSynchronize());
+        int rc = make_plans(h, B, H, W);
+        if (rc != SSD_OK) { free_plans(h); return rc; }
+    }
+    if (h->have_last && h->last_stream != s) HIPCHK(hipStreamWaitEvent(s, h->ev_last, 0));
+    // hipGraph replay (launch-bound regime: batch 1 is ~35 short kernels on a few streams).  A
+    // forward whose pointers, shape and stream repeat is captured on the handle's own stream at
+    // its second occurrence and replayed from then on; profiling or option graph = 0 keep it eager.
+    // Measured (batch 1, 640x896): replay 2.49 ms vs eager 2.33 ms p50 -- the forward is GPU-bound
+    // (host enqueue 0.9 ms < 2.3 ms of kernels), so replay is OFF unless option graph = 1.
+    const bool use_graph = ssd_opt(h, OPT_GRAPH, 0) != 0 && !h->capture_broken;
+    if (!use_graph || h->profiling || h->plans.size() != 1)
+        return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, s);
+    GraphKey key{images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, B, H, W};
+    hipGraphExec_t exec = nullptr;
+    for (auto &g : h->graphs)
+        if (g.first == key) exec = g.second;
+    if (!exec) {
+        if (!(h->last_key == key)) {             // first sighting: run eagerly (lazy one-time inits happen here)
+            h->last_key = key;
+            return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, s);
+        }
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(h->gstream, hipStreamCaptureModeRelaxed));
+        int rc = enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, h->gstream);
+        hipError_t ce = hipStreamEndCapture(h->gstream, &graph);
+        if (rc != SSD_OK || ce != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            h->capture_broken = true;            // capture unsupported here: stay eager from now on
+            return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, s);
+        }
+        HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        if (h->graphs.size() >= 4) { (void)hipGraphExecDestroy(h->graphs.front().second); h->graphs.erase(h->graphs.begin()); }
+        h->graphs.push_back({key, exec});
+    }
+    HIPCHK(hipEventRecord(h->ev_gin, s));
+    HIPCHK(hipStreamWaitEvent(h->gstream, h->ev_gin, 0));
+    HIPCHK(hipGraphLaunch(exec, h->gstream));
+    HIPCHK(hipEventRecord(h->ev_gout, h->gstream));
+    HIPCHK(hipStreamWaitEvent(s, h->ev_gout, 0));
+    return SSD_OK;
+}
+
+extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
+                           int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, void *stream)
+{
+    if (!h || !images_dev || !boxes_dev || !labels_dev || !scores_dev || !num_boxes_dev)
+        return ssd_fail(SSD_ERR_INVALID, "ssd_forward: null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->finalized) return ssd_fail(SSD_ERR_STATE, "ssd_forward before ssd_finalize");
+    if (B < 1 || H < 1 || W < 1 || h->cfg.min_dimension < 128 || h->cfg.min_dimension % 128)
+        return ssd_fail(SSD_ERR_INVALID, "ssd_forward: B, H, W must be positive and min_dimension a multiple of 128 (pipeline.py:152)");
+    {
+        const ResizeDims rd = resize_dims(H, W, h->cfg.min_dimension, 128);
+        if ((long long)(rd.nh + rd.ph) * (rd.nw + rd.pw) > (1LL << 26))
+            return ssd_fail(SSD_ERR_INVALID, "ssd_forward: aspect ratio too extreme (resized image exceeds 64 Mpixel)");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = forward_locked(h, images_dev, B, H, W, boxes_dev, labels_dev, scores_dev, num_boxes_dev, s);
+    if (rc == SSD_OK) {
+        // (not while a caller captures `s` into a graph of its own: an event recorded there belongs to that capture)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs == hipStreamCaptureStatusNone) {
+            HIPCHK(hipEventRecord(h->ev_last, s));
+            h->last_stream = s;
+            h->have_last = true;
+        }
+    }
+    return rc;
+}
+
+extern "C" int ssd_get_tensor(ssd_handle *h, const char *name, float *dst, int64_t cap, int32_t *dims)
+{
+    if (!h || !name || !dst || !dims) return ssd_fail(SSD_ERR_INVALID, "ssd_get_tensor: null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->plans.empty()) return ssd_fail(SSD_ERR_STATE, "ssd_get_tensor before ssd_forward");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    long long done = 0;
+    int Btot = 0;
+    for (Plan *pl : h->plans) {                  // sub-batches are consecutive images
+        auto it = pl->retained.find(name);
+        if (it == pl->retained.end()) return ssd_fail(SSD_ERR_INVALID, std::string("ssd_get_tensor: unknown tensor ") + name);
+        const Retained &r = it->second;
+        const long long rows = (long long)r.B * r.H * r.W;
+        if (cap < done + rows * r.C) return ssd_fail(SSD_ERR_INVALID, "ssd_get_tensor: destination too small");
+        std::vector<float> tmp((size_t)rows * r.Cp);
+        HIPCHK(hipMemcpy(tmp.data(), r.dev, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (long long q = 0; q < rows; ++q)
+            for (int c = 0; c < r.C; ++c) {
+                const int pc = r.permuted ? ssd_phys_of_logical(c) : c;
+                if (r.fmt) {          // split-fp16 row: per octet 8 halves h, 8 halves l
+                    const _Float16 *row = (const _Float16 *)&tmp[q * r.Cp];
+                    dst[done + q * r.C + c] = (float)row[(pc >> 3) * 16 + (pc & 7)] + (float)row[(pc >> 3) * 16 + 8 + (pc & 7)];
+                } else {
+                    dst[done + q * r.C + c] = tmp[q * r.Cp + pc];
+                }
+            }
+        done += rows * r.C;
+        Btot += r.B;
+        dims[1] = r.H; dims[2] = r.W; dims[3] = r.C;
+    }
+    dims[0] = Btot;
+    return SSD_OK;
+}
+
+// Device-to-device variant of ssd_get_tensor: dst_dev receives the tensor in logical
+// channel order; enqueued on `stream`, no synchronisation.
+extern "C" int ssd_get_tensor_dev(ssd_handle *h, const char *name, float *dst_dev, int64_t cap, int32_t *dims, void *stream)
+{
+    if (!h || !name || !dst_dev || !dims) return ssd_fail(SSD_ERR_INVALID, "ssd_get_tensor_dev: null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->plans.empty()) return ssd_fail(SSD_ERR_STATE, "ssd_get_tensor_dev before ssd_forward");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    long long done = 0;
+    int Btot = 0;
+    for (Plan *pl : h->plans) {
+        auto it = pl->retained.find(name);
+        if (it == pl->retained.end()) return ssd_fail(SSD_ERR_INVALID, std::string("ssd_get_tensor_dev: unknown tensor ") + name);
+        const Retained &r = it->second;
+        const long long rows = (long long)r.B * r.H * r.W;
+        if (cap < done + rows * r.C) return ssd_fail(SSD_ERR_INVALID, "ssd_get_tensor_dev: destination too small");
+        if (r.permuted) HIPCHK(launch_permute_channels(r.dev, rows, r.C, r.Cp, r.fmt ? 2 : 0, dst_dev + done, (hipStream_t)stream));
+        else HIPCHK(hipMemcpyAsync(dst_dev + done, r.dev, (size_t)rows * r.C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        done += rows * r.C;
+        Btot += r.B;
+        dims[1] = r.H; dims[2] = r.W; dims[3] = r.C;
+    }
+    dims[0] = Btot;
+    return SSD_OK;
+}
+
+// ----------------------------------------------------------------------------- profiling
+extern "C" int ssd_profile_enable(ssd_handle *h, int32_t on)
+{
+    if (!h) return ssd_fail(SSD_ERR_INVALID, "null handle");
+    std::lock_guard<std::mutex> g(h->mu);
+    h->profiling = on != 0;
+    return SSD_OK;
+}
+
+// Per class, the time is the UNION of its kernels' [start, end] intervals inside each forward
+// (the two head towers run concurrently on two streams: their kernels overlap, and a sum of
+// durations would count the shared GPU twice).
+static int drain_events(ssd_handle *h)
+{
+    std::vector<std::vector<std::pair<float, float>>> iv(SSD_NCLS);
+    int cur_fwd = -1;
+    auto flush = [&]() {
+        for (int c = 0; c < SSD_NCLS; ++c) {
+            auto &v = iv[c];
+            std::sort(v.begin(), v.end());
+            float lo = 0, hi = -1;
+            for (auto &p : v) {
+                if (hi < 0) { lo = p.first; hi = p.second; }
+                else if (p.first <= hi) { if (p.second > hi) hi = p.second; }
+                else { h->acc_ms[c] += hi - lo; lo = p.first; hi = p.second; }
+            }
+            if (hi >= 0) h->acc_ms[c] += hi - lo;
+            v.clear();
+        }
+    };
+    for (auto &e : h->evs) {
+        HIPCHK(hipEventSynchronize(e.b));
+        if (e.fwd != cur_fwd) { flush(); cur_fwd = e.fwd; }
+        float t0 = 0, t1 = 0;
+        if (e.fwd >= 0 && e.fwd < (int)h->ref_evs.size()) {
+            HIPCHK(hipEventElapsedTime(&t0, h->ref_evs[e.fwd], e.a));
+            HIPCHK(hipEventElapsedTime(&t1, h->ref_evs[e.fwd], e.b));
+        } else {
+            HIPCHK(hipEventElapsedTime(&t1, e.a, e.b));
+        }
+        iv[e.cls].push_back({t0, t1});
+        h->ev_pool.push_back(e.a);
+        h->ev_pool.push_back(e.b);
+    }
+    flush();
+    h->evs.clear();
+    for (auto r : h->ref_evs) h->ev_pool.push_back(r);
+    h->ref_evs.clear();
+    return SSD_OK;
+}
+
+extern "C" int ssd_profile_read(ssd_handle *h, int32_t cls, double *total_ms, int64_t *launches, double *flops, double *bytes)
+{
+    if (!h || cls < 0 || cls >= SSD_NCLS) return ssd_fail(SSD_ERR_INVALID, "ssd_profile_read: bad arguments");
+    std::lock_guard<std::mutex> g(h->mu);
+    SSDCHK(drain_events(h));
+    if (total_ms) *total_ms = h->acc_ms[cls];
+    if (launches) *launches = h->acc_n[cls];
+    if (flops) *flops = h->acc_flops[cls];
+    if (bytes) *bytes = h->acc_bytes[cls];
+    return SSD_OK;
+}
+
+extern "C" int ssd_profile_reset(ssd_handle *h)
+{
+    if (!h) return ssd_fail(SSD_ERR_INVALID, "null handle");
+    std::lock_guard<std::mutex> g(h->mu);
+    SSDCHK(drain_events(h));
+    for (int i = 0; i < SSD_NCLS; ++i) { h->acc_ms[i] = h->acc_flops[i] = h->acc_bytes[i] = 0; h->acc_n[i] = 0; }
+    return SSD_OK;
+}

@@ -1,0 +1,250 @@
+// Host-side declarations shared by the translation units behind the C ABI (include/ssd_hip.h):
+//   abi.hip      lifetime, options, ssd_forward, retained tensors, profiling
+//   weights.hip  ssd_finalize: TF variables -> packed device weights (channel order, batch-norm scale factors)
+//   plan.hip     the layer plan of one (B,H,W): ops, streams, dependencies; enqueue
+//   stages.hip   the stage entry points the parity tests call, anchors, resize arithmetic, diagnostics (-DSSD_DIAG)
+// Kernels and their launch wrappers: ssd_internal.h.
+#pragma once
+#include "../../include/ssd_hip.h"
+#include "ssd_internal.h"
+
+#include <climits>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// ----------------------------------------------------------------------------- errors
+int ssd_fail(int code, const std::string &msg);        // records the text for ssd_last_error() of this thread, returns code
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return ssd_fail(SSD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define SSDCHK(expr)                                                                         \
+    do {                                                                                     \
+        int r_ = (expr);                                                                     \
+        if (r_ != SSD_OK) return r_;                                                         \
+    } while (0)
+
+// ----------------------------------------------------------------------------- options
+// Tuning / test switches behind ssd_set_option (include/ssd_hip.h lists them).  None is read from the
+// environment; a handle's own value wins over the process-wide one (handle == NULL), which wins over the default.
+enum SsdOpt {
+    OPT_IGEMM_TILE = 0,     // 0 auto | 128 | 64: pins the 128x128-vs-64x64 choice of the implicit-GEMM kernel | 20 .. 23: a wave tile of igemm_lat.hip
+    OPT_IGEMM16,            // -1 auto | 0 | 1: f16x3 launches on the 256x256-tile kernel
+    OPT_IGEMM_96,           // 1 (default) | 0: 128x96 tiles for widths 96 divides and 128 does not
+    OPT_LATERAL_SPLIT,      // 1 (default) | 0: f16x3 laterals split fp32 rows while staging them
+    OPT_BACKBONE_SPLIT,     // 0 auto | 1..4: MobileNet backbone chains
+    OPT_NSUB,               // 0 auto | 1..8: staggered sub-batch plans
+    OPT_LEVEL_SPLIT,        // 0 (default) | 1: head towers of levels 6-7 as launches of their own (batch <= 2)
+    OPT_NMS_FAST_MAX,       // -1 default | n >= 0: candidate lists up to n run in one wave's registers
+    OPT_DEBUG_SYNC,         // 0 | 1: announce every op, run it alone, wait for it (fault localisation)
+    OPT_FUSE_DW,            // -1 default | mask: depthwise+pointwise pairs that run as one launch
+    OPT_GRAPH,              // 0 (default) | 1: hipGraph replay of a repeating forward
+    OPT_IGEMM_LAT,          // 1 (default) | 0: tiny exact-fp32 launches on the latency form (igemm_lat.hip)
+    OPT_IGEMM_DEEP64,       // -1 auto | 0 | 1: 64x64 tiles with loads three K-steps ahead
+    OPT_STREAMS,            // 0 auto | 1: every op of a plan on one stream (measurement aid)
+    OPT_COUNT
+};
+#define SSD_OPT_UNSET INT_MIN
+struct Options { int v[OPT_COUNT]; Options() { for (int &x : v) x = SSD_OPT_UNSET; } };
+int ssd_opt(const struct ssd_handle *h, int key, int dflt);      // handle value, else process value, else dflt
+int ssd_opt_index(const char *key);                              // -1: unknown key
+
+// ----------------------------------------------------------------------------- helpers
+struct Tensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct DevPool {
+    std::vector<void *> ptrs;
+    int alloc(void **out, size_t bytes)
+    {
+        // 256 bytes of slack behind every tensor: igemm_lat.hip's 4-byte-shifted 16-byte loads touch (and never use)
+        // the dword behind a tensor's last chunk
+        HIPCHK(hipMalloc(out, bytes + 256));
+        ptrs.push_back(*out);
+        return SSD_OK;
+    }
+    template <class T> int upload(T **out, const std::vector<T> &v)
+    {
+        void *p = nullptr;
+        SSDCHK(alloc(&p, v.size() * sizeof(T)));
+        if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        *out = (T *)p;
+        return SSD_OK;
+    }
+    void free_all()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+    }
+};
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// physical position p -> logical channel (or -1 for a pad channel)
+std::vector<int> phys_map(int C, int Cp);
+std::vector<int> ident_map(int C, int Cp);
+
+struct BnHost { std::vector<float> mean, sf, beta; };
+
+struct ConvW {
+    float *wt = nullptr, *mean = nullptr, *sf = nullptr, *beta = nullptr, *bias = nullptr;
+    float *wt16 = nullptr;     // the same rows in split-fp16 form, scaled by 2^s (precision mode f16x3)
+    float *wt16w = nullptr;    // wide outputs whose width 256 does not divide (480 class logits): the S16 rows again,
+    int CoutPad16 = 0;         //   padded to CoutPad16 = a multiple of 256 rows per tap for the 256x256-tile kernel
+    float scale16 = 1.0f;      // 2^-s
+    int CinP = 0, CoutP = 0, CoutPad = 0, taps = 1, tile = IGEMM_128x128;
+    int Cin_l = 0, Cout_l = 0;
+};
+
+struct DwW {
+    float *w = nullptr, *mean = nullptr, *sf = nullptr, *beta = nullptr;
+    float *pack = nullptr;      // [Cp/32][12][32]: per 32-channel slice 9 taps, mean, sf, beta (dwpw_stream.hip); Cp % 32 == 0 only
+    int Cp = 0;
+};
+
+#define SSD_NCLS 8                   // profile classes (include/ssd_hip.h)
+// Conv2d_1..4 as one depthwise+pointwise launch: 751.9 -> 760.6 img/s at B=32 (masks 0x3 / 0x5 / 0x7 / 0xf:
+// 754.6 / 757.2 / 760.2 / 760.6); from Conv2d_5 on (K >= 256) the two-kernel pair is faster.
+#define SSD_FUSE_DW_DEFAULT 0xfu
+#define SSD_FUSE_SHUFFLE_DEFAULT true    // ShuffleNet B=64 640x640: depthwise + pointwise 4.19 -> 3.76 ms per step
+#ifdef SSD_DIAG                      // libssd_hip_diag.so (scripts/): tile override and phase-stamp buffer of ssd_bench_conv
+extern int g_force_tile;
+extern long long *g_dbg_ts;
+#else                                // the shipped library: compile-time constants, no override exists
+static constexpr int g_force_tile = -1;
+static constexpr long long *g_dbg_ts = nullptr;
+#endif
+
+// weights.hip: w HWIO [k,k,Cin_l,Cout_l] -> wt [taps][CoutPad][CinP]
+int pack_conv(const struct ssd_handle *h, DevPool &pool, const float *w, int k, int Cin_l, int Cout_l, const std::vector<int> &inmap,
+              const std::vector<int> &outmap, ConvW &cw);
+int upload_bn(DevPool &pool, const BnHost &b, ConvW &cw);
+int pack_dw(DevPool &pool, const std::vector<float> &w9, const std::vector<float> &mean, const std::vector<float> &sf,
+            const std::vector<float> &beta, DwW &d);
+int finalize_weights(struct ssd_handle *h);
+
+// ----------------------------------------------------------------------------- ops
+struct Op {
+    int cls;            // profile class
+    int stream = 0;     // 0: the plan's main stream, 1: its second stream, 2 / 3: further chains
+    std::vector<int> deps;          // indices of ops (on the other stream) that must have finished
+    hipEvent_t done = nullptr;      // recorded after the op when another op depends on it
+    bool fpn_end = false;           // last op of backbone + FPN (sub-batch stagger point)
+    double flops, bytes;
+    std::function<hipError_t(hipStream_t)> run;
+};
+
+struct LevelDesc {
+    int H, W, OH, OW;
+    long long in_off, out_off, out_bstride;
+    int out_rstride, param_off;
+    long long res_off;
+};
+
+// in_fmt / out_fmt / res_fmt: 0 fp32 rows, 1 split-fp16 rows (ssd_internal.h); flags: the handle's status word
+Op make_conv_op(const struct ssd_handle *h, const ConvW &cw, const float *in, float *out, float *out2, const float *res, int B,
+                int stride, int pad, int act, const std::vector<LevelDesc> &lv, bool dense, int in_fmt = 0, int out_fmt = 0,
+                int res_fmt = 0, int *flags = nullptr, unsigned *scan_bits = nullptr, float scan_lo = 0.0f,
+                bool *scan_marked = nullptr);
+Op make_dw_op(const DwW &d, const float *in, int B, int H, int W, int stride, int act, float *out, int Cl, int out16 = 0,
+              int *flags = nullptr);
+bool dwpws_eligible(const DwW &d, const ConvW &cw, int B, int H, int W, int stride);
+Op make_dwpws_op(const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact, int act,
+                 float *out, const int *omap = nullptr, long long out_bytes = 0, int rs0 = 0, int rs1 = 0);
+LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long in_off = 0, long long out_off = 0,
+                      int param_off = 0, long long res_off = 0);
+float conservative_logit_bound(float thr);
+int nms_fast_max(const struct ssd_handle *h);        // PostArgs encoding: 0 = default, -1 = "0"
+
+// resize_keeping_aspect_ratio (pipeline.py:138-194), the size arithmetic of the TF graph
+struct ResizeDims { int nh, nw, ph, pw; float box_scaler[4]; };
+ResizeDims resize_dims(int height, int width, int min_dimension, int divisor);
+extern const int A_STRIDES[5];
+extern const int MB_STRIDE[13];          // mobilenet_v1.py:52-58 (weights.hip)
+
+// ----------------------------------------------------------------------------- handle
+struct Retained { const float *dev; int B, H, W, C, Cp; bool permuted; int fmt = 0; /* 1: split-fp16 rows */ };
+
+struct EvPair { hipEvent_t a, b; int cls; int fwd; };
+
+// The layer plan of one SUB-BATCH: ssd_forward splits a large batch into a few sub-batches and
+// staggers them over streams, so the HBM-bound backbone of sub-batch k+1 runs underneath the
+// MFMA-bound heads of sub-batch k (images are independent end to end).
+struct Plan {
+    int B = 0, img0 = 0, N = 0;
+    DevPool pool;                       // activations / workspace
+    std::vector<Op> ops;
+    PostArgs post;
+    std::map<std::string, Retained> retained;
+    hipStream_t s_main = nullptr;       // null: the caller's stream (sub-batch 0)
+    hipStream_t s_aux = nullptr;        // class tower beside the box tower (box_predictor.py:47-59)
+    hipStream_t s_bb[2] = {nullptr, nullptr};   // further chains (Op::stream 2, 3)
+    hipEvent_t ev_fpn = nullptr, ev_join = nullptr, ev_done = nullptr, ev_begin = nullptr;
+    hipEvent_t ev_join_bb[2] = {nullptr, nullptr};
+    bool tail_on[2] = {false, false};   // the plan's last ops on stream 2 / 3 are not awaited by any later op: join them before the post-processing
+    int last_aux = -1;                  // index of the last op on the second stream
+};
+
+struct GraphKey {
+    const void *img; void *boxes, *labels, *scores, *num; int B, H, W;
+    bool operator==(const GraphKey &o) const
+    {
+        return img == o.img && boxes == o.boxes && labels == o.labels && scores == o.scores && num == o.num && B == o.B && H == o.H && W == o.W;
+    }
+};
+
+struct ssd_handle {
+    ssd_config cfg;
+    std::mutex mu;                      // every entry point that takes the handle holds it: calls on one handle are serialised
+    Options opts;
+    std::map<std::string, Tensor> vars;
+    bool finalized = false;
+    DevPool wpool;      // weights
+    // packed weights
+    DwW first;                          // first conv (w = [27][CoutP])
+    int firstCp = 0, firstAct = SSD_ACT_RELU6;
+    std::vector<DwW> dw;                // depthwise layers in execution order
+    std::vector<ConvW> pw;              // backbone pointwise layers in execution order
+    ConvW lat[3], pconv[5];             // fpn lateral3..5, p3..p7
+    ConvW tower[2][4], final_[2];       // [box, class]
+    std::vector<int *> tabs;            // shufflenet gather tables (device)
+    int c_ch[3] = {0, 0, 0};            // logical channels of c3, c4, c5
+    int precision = SSD_PRECISION_F32;  // ssd_set_precision
+    int *flags_dev = nullptr;           // status word (bit 0: an S16 tensor was clamped to the fp16 range)
+    // plans
+    int pB = 0, pH = 0, pW = 0;
+    std::vector<Plan *> plans;
+    hipEvent_t ev_start = nullptr;
+    const uint8_t *cur_images = nullptr;
+    // the arena is one per handle: a forward enqueued on another stream than the previous one waits for it
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+    hipEvent_t ev_last = nullptr;
+    // hipGraph replay
+    hipStream_t gstream = nullptr;
+    hipEvent_t ev_gin = nullptr, ev_gout = nullptr;
+    std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
+    GraphKey last_key{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    bool capture_broken = false;        // a failed capture is not retried
+    // profiling
+    bool profiling = false;
+    std::vector<EvPair> evs;
+    std::vector<hipEvent_t> ref_evs;     // one reference event per profiled forward
+    std::vector<hipEvent_t> ev_pool;     // timing events, created once and reused (none is created inside a timed region
+                                         // after the first profiled forward)
+    double acc_ms[SSD_NCLS] = {0}, acc_flops[SSD_NCLS] = {0}, acc_bytes[SSD_NCLS] = {0};
+    long long acc_n[SSD_NCLS] = {0};
+};
+
+// plan.hip
+void free_plans(ssd_handle *h);
+int make_plans(ssd_handle *h, int B, int H, int W);
+int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, int32_t *labels_dev, float *scores_dev,
+                    int32_t *num_boxes_dev, hipStream_t s);

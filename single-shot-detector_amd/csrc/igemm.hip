@@ -81,7 +81,7 @@ __device__ __forceinline__ unsigned udiv(unsigned n, UDiv u)      // ssd_interna
 template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int DBGT = 0, int S16 = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const IgemmArgs a)
 {
-    constexpr int DBG = DBGT == 7 ? 0 : DBGT;
+    constexpr int DBG = (DBGT == 7 || DBGT == 8) ? 0 : DBGT;     // 8: no diagnostic, the deep-prefetch form of a 64-wide tile
     long long stamp[8];
     auto mark = [&](int i) {
         if constexpr (DBGT == 7) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[i] = wall_clock64(); }
@@ -304,8 +304,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     // Two register sets: the loads of K-step j are issued during step j-3 and written to LDS during step j-1 (set j & 1
     // is written in phase 0 of a step and reloaded in its phase 1), so a load has two K-steps to arrive instead of
     // three quarters of one -- the 16-step 1x1 launches, whose blocks all fetch at once, were waiting for them.
-    // (The 64-wide tiles keep one set: five blocks per CU need <= 96 VGPRs.)
-    constexpr bool DEEP = BM * BN >= 128 * 64;
+    // (The 64-wide tiles keep one set: five blocks per CU need <= 96 VGPRs -- except in the instance for launches that do not
+    //  fill the chip anyway (DBGT 8, tile IGEMM_64x64D: batch-1 FPN / pointwise launches, one or two blocks per CU, whose
+    //  K-steps wait for operands that come from HBM or the Infinity Cache, not from a warm L2).)
+    constexpr bool DEEP = BM * BN >= 128 * 64 || DBGT == 8;
     v4f ra1[DEEP ? NA : 1], rb1[DEEP ? NB : 1];
     if constexpr (DEEP) {
         gload_into(ra, rb);        // step 0
@@ -727,13 +729,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     }
 }
 
-int igemm_tile_bm(int tile) { return tile == IGEMM_256x128 ? 256 : (tile == IGEMM_64x64 ? 64 : 128); }
+int igemm_tile_bm(int tile) { return tile == IGEMM_256x128 ? 256 : ((tile == IGEMM_64x64 || tile == IGEMM_64x64D) ? 64 : 128); }
 int igemm_tile_bn(int tile)
 {
     switch (tile) {
     case IGEMM_128x256: return 256;
     case IGEMM_128x128: case IGEMM_256x128: return 128;
-    case IGEMM_128x64: case IGEMM_64x64: return 64;
+    case IGEMM_128x64: case IGEMM_64x64: case IGEMM_64x64D: return 64;
     case IGEMM_128x96: return 96;
     case IGEMM_128x32: return 32;
     default: return 128;   // diagnostic variants of 128x128
@@ -802,6 +804,7 @@ hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStre
     case IGEMM_128x64: return launch_t<4, 1, 1, 2>(a, total_tiles_m, s);
     case IGEMM_128x32: return launch_t<4, 1, 1, 1>(a, total_tiles_m, s);
     case IGEMM_64x64: return launch_t<2, 2, 1, 1>(a, total_tiles_m, s);
+    case IGEMM_64x64D: return a.in_fmt ? launch_t<2, 2, 1, 1>(a, total_tiles_m, s) : launch_t<2, 2, 1, 1, 8>(a, total_tiles_m, s);
     case IGEMM_128x96: return launch_t<4, 1, 1, 3>(a, total_tiles_m, s);
 #ifdef SSD_DIAG   // ablation / phase-stamp instances exist only in libssd_hip_diag.so
     case 10: return launch_t<2, 2, 2, 2, 1>(a, total_tiles_m, s);

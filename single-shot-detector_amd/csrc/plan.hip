@@ -1,0 +1,881 @@
+// The layer plan of one (B,H,W): the reference graph (create_pb.py + model.py PREDICT) as a flat list of kernel
+// launches on a few streams with explicit dependencies, no host synchronisation.  Built once per shape by
+// ssd_forward (abi.hip), enqueued per call.
+#include "host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *out, float *out2, const float *res, int B, int stride,
+                int pad, int act, const std::vector<LevelDesc> &lv, bool dense, int in_fmt, int out_fmt,
+                int res_fmt, int *flags, unsigned *scan_bits, float scan_lo, bool *scan_marked)
+{
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.wt = in_fmt ? cw.wt16 : cw.wt; a.out = out; a.out2 = out2;
+    a.in_fmt = in_fmt; a.out_fmt = out_fmt; a.res_fmt = res ? res_fmt : 0;
+    a.acc_scale = in_fmt ? cw.scale16 : 1.0f;
+    a.flags = flags;
+    a.mean = cw.mean; a.sf = cw.sf; a.beta = cw.beta; a.bias = cw.bias; a.res = res;
+    a.B = B; a.Cin = cw.CinP; a.Cout = cw.CoutP; a.CoutPad = cw.CoutPad; a.taps = cw.taps;
+    a.stride = stride; a.pad = pad; a.act = act;
+    a.nlevels = (int)lv.size();
+    a.ts = g_dbg_ts;
+    // Small problems (batch 1, coarse pyramid levels): 128x128 tiles would leave most of the
+    // 256 CUs with one wave per SIMD or idle; 64x64 tiles give 4x the blocks.
+    int tile = cw.tile;
+    if (tile == IGEMM_128x128 && g_force_tile < 0) {
+        long long t128 = 0;
+        for (size_t i = 0; i < lv.size(); ++i) t128 += ((long long)B * lv[i].OH * lv[i].OW + 127) / 128;
+        if (t128 * (cw.CoutPad / 128) < 2 * 256) tile = IGEMM_64x64;
+        else if (cw.taps == 1 && !in_fmt && cw.CinP >= 256) {    // (K < 256: 2 .. 4 K-steps per tile, epilogue-dominated: left on 128x128)
+            // 1x1 convolutions (8 .. 32 K-steps per tile): a launch is a few rounds of tiles over the 512 block slots and
+            // the last, partly filled round costs a whole tile time.  Estimated time = rounds x tile area / efficiency of the
+            // shape (measured, scripts/bench_conv.py at 16 images: 512->512 at 40x56 128x128 / 128x64 / 64x64 = 0.184 / 0.173 /
+            // 0.180 ms; 1024->1024 at 20x28 0.207 / 0.185 / 0.179 ms).  Inside the network, where two backbone chains run side by
+            // side, the step time does not move (A/B on one box: 41.4 / 41.4 ms, ShuffleNet 55.3 / 55.4 ms).
+            long long t64 = 0;
+            for (size_t i = 0; i < lv.size(); ++i) t64 += ((long long)B * lv[i].OH * lv[i].OW + 63) / 64;
+            const double c128 = ceil((double)t128 * (cw.CoutPad / 128) / 512.0) * 16384.0;
+            const double c12864 = ceil((double)t128 * (cw.CoutPad / 64) / 512.0) * 8192.0 / 0.97;
+            const double c64 = ceil((double)t64 * (cw.CoutPad / 64) / 512.0) * 4096.0 / 0.93;
+            if (c12864 < c128 && c12864 <= c64) tile = IGEMM_128x64;
+            else if (c64 < c128) tile = IGEMM_64x64;
+        }
+        // tests: option igemm_tile = 128 / 64 pins the choice so both variants see every shape
+        const int pin = ssd_opt(h, OPT_IGEMM_TILE, 0);
+        if (pin == 128) tile = IGEMM_128x128;
+        else if (pin == 64) tile = IGEMM_64x64;
+    }
+    // Large S16 -> S16 batch-norm launches (head towers, FPN outputs at serving batch sizes) take the
+    // 256 x 256-tile kernel of igemm16.hip once there are at least two full rounds of tiles for the 256 CUs;
+    // option igemm16 = 0 / 1 pins the choice (tests, A/B runs).
+    // Its second epilogue form (bias, fp32 rows: the class logits, 6 * num_classes wide) pads the width to a multiple of 256.
+    const bool bnform = out_fmt && dense && cw.mean && !cw.bias && cw.CoutPad % 256 == 0 && cw.CoutP == cw.CoutPad;
+    bool biasform = !out_fmt && !out2 && cw.bias && !cw.mean && act == SSD_ACT_NONE && cw.CoutP >= 256 && cw.CoutP % 8 == 0 &&
+                    (cw.wt16w || cw.CoutPad % 256 == 0);
+    for (size_t i = 0; i < lv.size(); ++i)
+        if ((lv[i].out_rstride | lv[i].out_bstride | lv[i].out_off) & 3 || lv[i].OH * lv[i].OW < 4) biasform = false;
+    if (in_fmt && !res && (bnform || biasform) && cw.taps * (cw.CinP / 32) >= 3 && g_force_tile < 0) {
+        long long t256 = 0;
+        for (size_t i = 0; i < lv.size(); ++i) t256 += ((long long)B * lv[i].OH * lv[i].OW + 255) / 256;
+        bool use16 = t256 * (cw.CoutPad16 / 256) >= 2 * 256;
+        const int pin16 = ssd_opt(h, OPT_IGEMM16, -1);
+        if (pin16 >= 0) use16 = pin16 != 0;
+        if (use16) {
+            tile = IGEMM16_TILE;
+            a.CoutPad = cw.CoutPad16;
+            if (cw.wt16w) a.wt = cw.wt16w;
+            if (scan_bits && biasform) { a.scan_lo = scan_lo; a.scan_bits = scan_bits; }
+        }
+    }
+    // Exact-fp32 kernel, bias form with 16-byte stores (the class logits): its epilogue marks the candidate octets too, so
+    // the post-processing's scan reads the bitmap instead of every logit in BOTH precision modes (batch 1: 52 -> ~10 us)
+    if (scan_bits && !a.scan_bits && tile != IGEMM16_TILE && !in_fmt && !out_fmt && !out2 && !res && cw.bias && !cw.mean &&
+        act == SSD_ACT_NONE && cw.CoutP % 4 == 0) {
+        bool aligned = true;
+        for (size_t i = 0; i < lv.size(); ++i)
+            if ((lv[i].out_rstride | lv[i].out_bstride | lv[i].out_off) & 3) aligned = false;
+        if (aligned) { a.scan_lo = scan_lo; a.scan_bits = scan_bits; }
+    }
+    if (scan_marked) *scan_marked = a.scan_bits != nullptr;
+    a.dense_out = dense ? 1 : 0;
+    double rows = 0, inb = 0;
+    for (size_t i = 0; i < lv.size(); ++i) {
+        IgemmLevel &L = a.lv[i];
+        L.H = lv[i].H; L.W = lv[i].W; L.OH = lv[i].OH; L.OW = lv[i].OW;
+        L.M = B * L.OH * L.OW;
+        L.dP = ssd_udiv_make((unsigned)(L.OH * L.OW));
+        L.dOW = ssd_udiv_make((unsigned)L.OW);
+        L.param_off = lv[i].param_off;
+        L.out_rstride = lv[i].out_rstride;
+        L.in_off = lv[i].in_off; L.out_off = lv[i].out_off; L.out_bstride = lv[i].out_bstride;
+        L.res_off = lv[i].res_off;
+        rows += L.M;
+        inb += (double)B * L.H * L.W * cw.Cin_l * 4.0;
+    }
+    // Tiny launches in exact fp32 (batch 1-2: fpn p6 and p7 -- 140 and 35 positions per image): the latency form of
+    // igemm_lat.hip -- v_mfma_f32_16x16x4_f32 (a quarter of the 32x32x2 accumulator's chain latency, 16x16 tiles: sixteen
+    // times the independent chains of a 64x64 tile), one wave per block, no LDS.  Same bits.  Measured at batch 1
+    // (profiles/r03_conv_latency_form.log, alone on the chip): p6 141 -> 66 us, p7 38 -> 19 us; every LARGER launch is
+    // slower on it (p5 39 -> 42 .. 53, p4 42 -> 102, pointwise 512 -> 512 22 -> 46, p3 117 -> 385 us): each wave fetches
+    // its own operands in fragment shape, ~70 cycles per 1-KB load instruction, and only a launch of at most one or two
+    // waves per CU keeps that under its MFMA chain.  Option igemm_lat = 0 switches the form off, igemm_tile = 20 .. 23
+    // pins a wave tile wherever the form applies (tests run every shape on all four).
+    if (igemm_is_lat(tile)) {            // (diagnostics: ssd_bench_conv asked for this wave tile)
+        if (!igemm_lat_supports(a)) tile = IGEMM_128x128;
+    } else if (tile != IGEMM16_TILE && g_force_tile < 0 && igemm_lat_supports(a)) {
+        const int pin = ssd_opt(h, OPT_IGEMM_TILE, 0);
+        if (igemm_is_lat(pin)) tile = pin;
+        else if (pin == 0 && ssd_opt(h, OPT_IGEMM_LAT, 1)) {
+            long long waves = 0;
+            for (size_t i = 0; i < lv.size(); ++i) waves += (((long long)a.lv[i].M + 15) / 16) * (cw.CoutPad / 16);
+            if (waves <= 320) tile = IGEMM_LAT_1x1;
+        }
+    }
+    // 64x64 tiles of a launch that leaves the chip mostly empty (at most ~2.5 blocks per CU: the FPN and pointwise layers of
+    // a batch-1 forward): the instance with two register sets, loads three K-steps ahead.  In the network these launches'
+    // operands come from HBM / the Infinity Cache (57 MB of weights pass between two uses of a layer's), and a K-step of
+    // 0.43 us of MFMA work with loads issued 3/4 of a step ahead waits for them.  Option igemm_deep64 = 0 / 1 pins it.
+    if (tile == IGEMM_64x64 && !in_fmt && g_force_tile < 0) {
+        long long b64 = 0;
+        for (size_t i = 0; i < lv.size(); ++i) b64 += (((long long)a.lv[i].M + 63) / 64) * (cw.CoutPad / 64);
+        bool deep = b64 <= 640;
+        const int pin = ssd_opt(h, OPT_IGEMM_DEEP64, -1);
+        if (pin >= 0) deep = pin != 0;
+        if (deep) tile = IGEMM_64x64D;
+    }
+    const bool lat = igemm_is_lat(tile);
+    a.n_tiles_n = a.CoutPad / (tile == IGEMM16_TILE ? 256 : (lat ? igemm_lat_bn(tile) : igemm_tile_bn(tile)));
+    a.dN = ssd_udiv_make((unsigned)a.n_tiles_n);
+    int tiles = 0;
+    const int BM = tile == IGEMM16_TILE ? 256 : (lat ? igemm_lat_bm(tile) : igemm_tile_bm(tile));
+    for (size_t i = 0; i < lv.size(); ++i) {
+        a.lv[i].tile_begin = tiles;
+        tiles += (a.lv[i].M + BM - 1) / BM;
+    }
+    Op op;
+    op.cls = cw.taps == 9 ? (tile == IGEMM16_TILE ? 7 : 0) : 1;
+    op.flops = 2.0 * rows * cw.taps * cw.Cin_l * cw.Cout_l;
+    op.bytes = inb + rows * cw.Cout_l * 4.0 + (double)cw.taps * cw.Cin_l * cw.Cout_l * 4.0;
+    op.run = [a, tile, tiles](hipStream_t s) {
+        if (tile == IGEMM16_TILE) return launch_igemm16(a, tiles, s);
+        return igemm_is_lat(tile) ? launch_igemm_lat(tile, a, tiles, s) : launch_igemm(tile, a, tiles, s);
+    };
+    return op;
+}
+
+void free_plans(ssd_handle *h)
+{
+    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.second);
+    h->graphs.clear();
+    h->last_key = GraphKey{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    for (Plan *pl : h->plans) {
+        for (Op &op : pl->ops)
+            if (op.done) (void)hipEventDestroy(op.done);
+        pl->pool.free_all();
+        if (pl->s_main) (void)hipStreamDestroy(pl->s_main);
+        if (pl->s_aux) (void)hipStreamDestroy(pl->s_aux);
+        for (int i = 0; i < 2; ++i) if (pl->s_bb[i]) (void)hipStreamDestroy(pl->s_bb[i]);
+        if (pl->ev_fpn) (void)hipEventDestroy(pl->ev_fpn);
+        if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
+        if (pl->ev_done) (void)hipEventDestroy(pl->ev_done);
+        if (pl->ev_begin) (void)hipEventDestroy(pl->ev_begin);
+        for (int i = 0; i < 2; ++i) if (pl->ev_join_bb[i]) (void)hipEventDestroy(pl->ev_join_bb[i]);
+        delete pl;
+    }
+    h->plans.clear();
+    h->pB = h->pH = h->pW = 0;
+}
+
+// ----------------------------------------------------------------------------- plan
+struct Pyr { int h[5], w[5]; long long off[5]; long long total; };
+
+static Pyr make_pyr(int B, int H, int W, int C)
+{
+    Pyr p;
+    long long o = 0;
+    for (int l = 0; l < 5; ++l) {
+        p.h[l] = (H + A_STRIDES[l] - 1) / A_STRIDES[l];
+        p.w[l] = (W + A_STRIDES[l] - 1) / A_STRIDES[l];
+        p.off[l] = o;
+        o += (long long)B * p.h[l] * p.w[l] * C;
+    }
+    p.total = o;
+    return p;
+}
+
+Op make_dw_op(const DwW &d, const float *in, int B, int H, int W, int stride, int act, float *out, int Cl, int out16, int *flags)
+{
+    const int OH = H / stride, OW = W / stride, pad = stride == 1 ? 1 : 0;
+    Op op;
+    op.cls = 2;
+    op.flops = 2.0 * 9 * (double)B * OH * OW * Cl;
+    op.bytes = ((double)B * H * W + (double)B * OH * OW) * Cl * 4.0;
+    const DwW dd = d;
+    op.run = [=](hipStream_t s) {
+        return launch_depthwise(in, B, H, W, dd.Cp, dd.w, stride, pad, OH, OW, dd.mean, dd.sf, dd.beta, act, out, s, out16, flags);
+    };
+    return op;
+}
+
+// depthwise + pointwise on the streaming kernel (dwpw_stream.hip): any K % 32 == 0, any image size.  omap / out_bytes:
+// per-channel destination map (ShuffleNet: concat_shuffle_split folded into the stores), else a dense [M][CoutP] output.
+bool dwpws_eligible(const DwW &d, const ConvW &cw, int B, int H, int W, int stride)
+{
+    const int OH = H / stride, OW = W / stride;
+    if (cw.taps != 1 || d.Cp != cw.CinP || d.Cp % 32 != 0 || !d.pack || !cw.mean || cw.bias) return false;
+    if ((stride != 1 && stride != 2) || (stride == 2 && ((H | W) & 1))) return false;
+    if ((long long)B * H * W * d.Cp * 4 >= (1LL << 31) || (long long)B * OH * OW * cw.CoutP * 4 >= (1LL << 31)) return false;
+    return (cw.CoutP + dwpws_tile_n(stride, cw.CoutP) - 1) / dwpws_tile_n(stride, cw.CoutP) <= 64;
+}
+
+Op make_dwpws_op(const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact, int act,
+                 float *out, const int *omap, long long out_bytes, int rs0, int rs1)
+{
+    DwPwSArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.dwpack = d.pack; a.wt = cw.wt; a.mean = cw.mean; a.sf = cw.sf; a.beta = cw.beta; a.out = out; a.omap = omap;
+    a.B = B; a.H = H; a.W = W; a.K = d.Cp; a.OH = H / stride; a.OW = W / stride;
+    a.Cout = cw.CoutP; a.wt_rows = cw.CoutPad;
+    a.pad = stride == 1 ? 1 : 0;
+    a.dact = dact; a.act = act;
+    const int TY = stride == 1 ? 8 : 4, BN = dwpws_tile_n(stride, cw.CoutP);
+    a.tiles_y = (a.OH + TY - 1) / TY; a.tiles_x = (a.OW + 7) / 8;
+    a.m_tiles = B * a.tiles_y * a.tiles_x;
+    a.n_tiles = (cw.CoutP + BN - 1) / BN;
+    const long long dense = (long long)B * a.OH * a.OW * cw.CoutP * 4;
+    a.out_bytes = (int)(omap ? out_bytes : dense);
+    a.rs0 = rs0; a.rs1 = rs1;
+    a.ts = g_dbg_ts;
+#ifdef SSD_DIAG
+    if (const char *e = getenv("SSD_DWPWS_ABL")) a.abl = atoi(e);
+#endif
+    Op op;
+    op.cls = 6;
+    const double M = (double)B * a.OH * a.OW;
+    op.flops = (2.0 * 9 * cw.Cin_l + 2.0 * cw.Cin_l * cw.Cout_l) * M;
+    op.bytes = ((double)B * H * W * cw.Cin_l + M * cw.Cout_l) * 4.0 + (double)cw.Cin_l * cw.Cout_l * 4.0;
+    op.run = [a, stride](hipStream_t s) { return launch_dwpw_stream(stride, a, s); };
+    return op;
+}
+
+LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long in_off, long long out_off, int param_off, long long res_off)
+{
+    LevelDesc d;
+    d.H = H; d.W = W; d.OH = OH; d.OW = OW;
+    d.in_off = in_off; d.out_off = out_off;
+    d.out_bstride = (long long)OH * OW * CoutP;
+    d.out_rstride = CoutP;
+    d.param_off = param_off;
+    d.res_off = res_off;
+    return d;
+}
+
+static void push_dw_pw(const ssd_handle *h, std::vector<Op> &ops, bool fuse, const DwW &d, const ConvW &cw, const float *in, float *mid,
+                       float *out, int B, int H, int W, int stride, int dact, int act, int Cl)
+{
+    const int OH = H / stride, OW = W / stride;
+    if (fuse && in != out && dwpws_eligible(d, cw, B, H, W, stride)) {
+        ops.push_back(make_dwpws_op(d, cw, in, B, H, W, stride, dact, act, out));
+        return;
+    }
+    ops.push_back(make_dw_op(d, in, B, H, W, stride, dact, mid, Cl));
+    ops.push_back(make_conv_op(h, cw, mid, out, nullptr, nullptr, B, 1, 0, act, {dense_level(OH, OW, OH, OW, cw.CoutP)}, true));
+}
+
+static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int img0)
+{
+    pl.B = B;
+    pl.img0 = img0;
+    const size_t img_off = (size_t)img0 * srcH * srcW * 3;
+    const ResizeDims rd = resize_dims(srcH, srcW, h->cfg.min_dimension, 128);
+    const int H = rd.nh + rd.ph, W = rd.nw + rd.pw;     // network input size (multiples of 128)
+    const int rnh = rd.nh, rnw = rd.nw;
+    DevPool &ap = pl.pool;
+    auto falloc = [&](float **p, long long nfloats) { return ap.alloc((void **)p, (size_t)nfloats * sizeof(float)); };
+
+    // precision mode f16x3: FPN + heads run on split-fp16 operands (igemm.hip "S16"); the backbone stays exact
+    // fp32 and hands over c5 in S16 rows, c3 / c4 (which the next depthwise layer also reads) in fp32.
+    const int X16 = h->precision == SSD_PRECISION_F16X3 ? 1 : 0;
+    int *const FL = h->flags_dev;
+    // ---------------- backbone
+    float *C3 = nullptr, *C4 = nullptr, *C5 = nullptr;
+    const int h2 = H / 2, w2 = W / 2;
+    int id_bb_last[4] = {-1, -1, -1, -1};     // last backbone op of each chain (MobileNet split), -1: no such chain
+    if (h->cfg.backbone == SSD_BACKBONE_MOBILENET) {
+        // The backbone is a chain of ~30 short, latency-bound kernels (two blocks per CU each waiting for one
+        // round of loads).  From 4 images on it runs as two half-batch chains on the plan's two streams, so that
+        // one chain's memory phases sit under the other's compute; FPN and heads stay full-batch launches.
+        // Measured (f16x3, same box): +2.1 % at 32 images, +3.8 % at 16, +3.2 % at 8, +4.5 % at 4; mode f32 (round 2):
+        // +1.3 % at 4, +1.5 % at 8, +0.8 % at 16, none at 32.
+        // option backbone_split = 1 keeps one chain.
+        int nhalf = B >= 4 ? 2 : 1;
+        { const int v = ssd_opt(h, OPT_BACKBONE_SPLIT, 0); if (v >= 1 && v <= 4 && v <= B) nhalf = v; }
+        // retained outputs c3 / c4 / c5: full-batch tensors, each half writes its images
+        {
+            int hh = h2, ww = w2;
+            for (int i = 0; i < 13; ++i) {
+                hh /= MB_STRIDE[i]; ww /= MB_STRIDE[i];
+                if (i == 4 || i == 10 || i == 12) {
+                    float *t;
+                    SSDCHK(falloc(&t, (long long)B * hh * ww * h->pw[i].CoutP));
+                    if (i == 4) C3 = t; else if (i == 10) C4 = t; else C5 = t;
+                    const char *nm = i == 4 ? "c3" : (i == 10 ? "c4" : "c5");
+                    pl.retained[nm] = Retained{t, B, hh, ww, h->pw[i].Cout_l, h->pw[i].CoutP, true, (i == 12 && X16) ? 1 : 0};
+                }
+            }
+        }
+        // depthwise -> pointwise pairs that run as one launch (bit i = Conv2d_{i+1}); option fuse_dw overrides
+        // (streaming kernel: every pair in mode f32; in mode f16x3 Conv2d_5..13 keep their f16x3 pointwise products)
+        // Measured with the streaming kernel (B = 32, mode f32, one box): masks 0xf / 0x1f / 0x3f / 0x1fff -> 770.7 / 769.4 /
+        // 765.4 / 758.9 img/s: from Conv2d_6 on the pointwise product is MFMA-bound, the exact-fp32 MFMA and the depthwise
+        // VALU work do not overlap on a SIMD, and the two-kernel pair wins.
+        unsigned fuse_mask = SSD_FUSE_DW_DEFAULT;
+        if (ssd_opt(h, OPT_FUSE_DW, -1) >= 0) fuse_mask = (unsigned)ssd_opt(h, OPT_FUSE_DW, -1);
+        std::vector<Op> half_ops[4];
+        for (int hf = 0; hf < nhalf; ++hf) {
+            const int b0 = (int)((long long)B * hf / nhalf), nb = (int)((long long)B * (hf + 1) / nhalf) - b0;
+            std::vector<Op> &ops = half_ops[hf];
+            long long maxf = (long long)nb * h2 * w2 * h->firstCp;
+            {
+                int hh = h2, ww = w2;
+                for (int i = 0; i < 13; ++i) {
+                    hh /= MB_STRIDE[i]; ww /= MB_STRIDE[i];
+                    long long a = (long long)nb * hh * ww * h->dw[i].Cp, b = (long long)nb * hh * ww * h->pw[i].CoutP;
+                    if (a > maxf) maxf = a;
+                    if (b > maxf) maxf = b;
+                }
+            }
+            float *X, *Y;
+            SSDCHK(falloc(&X, maxf));
+            SSDCHK(falloc(&Y, maxf));
+            {
+                Op op;
+                op.cls = 3;
+                op.flops = 2.0 * 27 * (double)nb * h2 * w2 * h->pw[0].Cin_l;
+                op.bytes = (double)nb * H * W * 3 + (double)nb * h2 * w2 * h->pw[0].Cin_l * 4.0;
+                ssd_handle *hh = h;
+                const DwW f = h->first;
+                const int act = h->firstAct;
+                const size_t off = img_off + (size_t)b0 * srcH * srcW * 3;
+                op.run = [=](hipStream_t s) {
+                    return launch_first_conv(hh->cur_images + off, nb, srcH, srcW, rnh, rnw, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, X, s);
+                };
+                ops.push_back(op);
+            }
+            float *cur = X;
+            int ch = h2, cwid = w2;
+            for (int i = 0; i < 13; ++i) {
+                const int s = MB_STRIDE[i];
+                float *dwo = (cur == X) ? Y : X;
+                const ConvW &cw = h->pw[i];
+                const bool fuse = ((fuse_mask >> i) & 1) && dwpws_eligible(h->dw[i], cw, nb, ch, cwid, s);
+                // f16x3: an unfused pair hands the depthwise result (exact fp32, in [0, 6]) to its pointwise
+                // convolution in split-fp16 rows, and the pointwise product runs as 3 x f16 MFMA
+                const int pw16 = X16 && !fuse && (h->dw[i].Cp % 32 == 0) ? 1 : 0;
+                if (!fuse) ops.push_back(make_dw_op(h->dw[i], cur, nb, ch, cwid, s, SSD_ACT_RELU6, dwo, h->pw[i].Cin_l, pw16, FL));
+                const int dh = ch, dwid = cwid;
+                ch /= s; cwid /= s;
+                float *pwo;
+                if (i == 4 || i == 10 || i == 12) {
+                    float *full = i == 4 ? C3 : (i == 10 ? C4 : C5);
+                    pwo = full + (long long)b0 * ch * cwid * cw.CoutP;
+                } else {
+                    pwo = fuse ? dwo : ((dwo == X) ? Y : X);    // fused: input `cur` is live until the launch ends
+                }
+                if (fuse)
+                    ops.push_back(make_dwpws_op(h->dw[i], cw, cur, nb, dh, dwid, s, SSD_ACT_RELU6, SSD_ACT_RELU6, pwo));
+                else   // c5 feeds only the FPN (lateral5, p6): in f16x3 mode it is written in split-fp16 rows
+                    ops.push_back(make_conv_op(h, cw, dwo, pwo, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU6,
+                                               {dense_level(ch, cwid, ch, cwid, cw.CoutP)}, true, pw16, (i == 12 && X16) ? 1 : 0, 0, h->flags_dev));
+                cur = pwo;
+            }
+        }
+        // enqueue order interleaved so that both queues are fed
+        for (size_t i = 0; i < half_ops[0].size(); ++i)
+            for (int hf = 0; hf < nhalf; ++hf)
+                if (i < half_ops[hf].size()) {
+                    Op op = half_ops[hf][i];
+                    op.stream = hf;
+                    pl.ops.push_back(op);
+                    id_bb_last[hf] = (int)pl.ops.size() - 1;
+                    if (hf == 1) pl.last_aux = id_bb_last[hf];
+                }
+    } else {
+        // ---------------- ShuffleNet v2 (shufflenet_v2.py:50-69,79-137)
+        const int units[3] = {4, 8, 4};
+        const int fc = h->firstCp;
+        // depthwise -> 1x1 pairs of the units as one launch each (option fuse_dw = 0 keeps them apart)
+        bool sn_fuse = SSD_FUSE_SHUFFLE_DEFAULT;
+        if (ssd_opt(h, OPT_FUSE_DW, -1) >= 0) sn_fuse = ssd_opt(h, OPT_FUSE_DW, -1) != 0;
+        float *F, *MP;
+        SSDCHK(falloc(&F, (long long)B * h2 * w2 * fc));
+        const int h4 = h2 / 2, w4 = w2 / 2;
+        SSDCHK(falloc(&MP, (long long)B * h4 * w4 * fc));
+        {
+            Op op;
+            op.cls = 3;
+            op.flops = 2.0 * 27 * (double)B * h2 * w2 * 24;
+            op.bytes = (double)B * H * W * 3 + (double)B * h2 * w2 * 24 * 4.0;
+            ssd_handle *hh = h;
+            const DwW f = h->first;
+            const int act = h->firstAct;
+            op.run = [=](hipStream_t s) {
+                return launch_first_conv(hh->cur_images + img_off, B, srcH, srcW, rnh, rnw, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s);
+            };
+            pl.ops.push_back(op);
+            Op mp;
+            mp.cls = 5; mp.flops = 0;
+            mp.bytes = ((double)B * h2 * w2 + (double)B * h4 * w4) * 24 * 4.0;
+            mp.run = [=](hipStream_t s) { return launch_maxpool(F, B, h2, w2, fc, MP, s); };
+            pl.ops.push_back(mp);
+        }
+        const float *cur = MP;
+        int ch = h4, cwid = w4, ipw = 0, idw = 0;
+        for (int st = 0; st < 3; ++st) {
+            const int oh = ch / 2, ow = cwid / 2;
+            const long long rows = (long long)B * oh * ow;
+            // unit_1
+            const ConvW &before = h->pw[ipw], &after = h->pw[ipw + 1], &after2 = h->pw[ipw + 2];
+            const DwW &d1 = h->dw[idw], &d2 = h->dw[idw + 1];
+            const int Dp = after.CoutP, D = after.Cout_l;
+            // ---- concat_shuffle_split (shufflenet_v2.py:94-115) and the stage concat (:89) FOLDED into the stores of the
+            // convolutions that produce the channels: every 1x1 of the stage runs on the streaming depthwise+pointwise
+            // kernel, whose epilogue stores channel by channel through a destination map.  A channel is traced from its
+            // producer (unit_1's two branches, or unit j's conv1x1_after) through the shuffles to the ONE place that
+            // consumes it -- input channel k of a later unit's conv1x1_before (buffer X'_u, standard physical position
+            // of k, so that convolution's k order is untouched and the result stays bit-identical), or channel c of the
+            // stage output -- and is written there directly.  No shuffle, split or concat kernel runs.
+            {
+                const int n_units = units[st], Cc = round_up(2 * D, 32);
+                const long long xbytes = rows * Dp * 4, sbytes = rows * Cc * 4;
+                const long long total = xbytes * (n_units - 1) + sbytes;
+                bool ok = sn_fuse && total < (1LL << 31) && (D & 1) == 0 &&
+                          dwpws_eligible(d1, after, B, ch, cwid, 2) && dwpws_eligible(d2, after2, B, ch, cwid, 2);
+                for (int j = 2; ok && j <= n_units; ++j)
+                    ok = dwpws_eligible(h->dw[idw + j], h->pw[ipw + 3 + 2 * (j - 2) + 1], B, oh, ow, 1);
+                if (ok) {
+                    float *stage, *t1, *U;
+                    SSDCHK(falloc(&stage, total / 4));
+                    HIPCHK(hipMemset(stage, 0, (size_t)total));       // pad channels are never written: they stay zero
+                    SSDCHK(falloc(&t1, (long long)B * ch * cwid * before.CoutP));
+                    SSDCHK(falloc(&U, rows * Dp));
+                    // buffer u (2..n) at (u - 2) * xbytes, the stage output at (n - 1) * xbytes
+                    struct Src { int prod, col; };
+                    std::vector<Src> x(D), y(D);
+                    for (int d = 0; d < D; ++d) { x[d] = Src{0, d}; y[d] = Src{1, d}; }      // producer 0: second branch (x), 1: main branch (y)
+                    std::vector<std::vector<int>> omap(n_units + 1, std::vector<int>(Dp, -1));
+                    auto place = [&](const Src &v, long long off, int physcol, int sel) {
+                        omap[v.prod][ssd_phys_of_logical(v.col)] = (int)(off + (long long)physcol * 4) | sel;
+                    };
+                    for (int j = 2; j <= n_units; ++j) {
+                        std::vector<Src> z(2 * D);
+                        for (int d = 0; d < D; ++d) { z[2 * d] = x[d]; z[2 * d + 1] = y[d]; }
+                        for (int k = 0; k < D; ++k) place(z[k], (long long)(j - 2) * xbytes, ssd_phys_of_logical(k), 0);
+                        for (int d = 0; d < D; ++d) { x[d] = Src{j, d}; y[d] = z[D + d]; }
+                    }
+                    const long long soff = (long long)(n_units - 1) * xbytes;
+                    for (int c = 0; c < 2 * D; ++c) place(c < D ? x[c] : y[c - D], soff, ssd_phys_of_logical(c), 1);
+                    std::vector<const int *> omap_dev(n_units + 1, nullptr);
+                    for (int p = 0; p <= n_units; ++p) {
+                        int *dv;
+                        SSDCHK(ap.upload(&dv, omap[p]));
+                        omap_dev[p] = dv;
+                    }
+                    const int rs0 = Dp * 4, rs1 = Cc * 4;
+                    pl.ops.push_back(make_conv_op(h, before, cur, t1, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+                                                  {dense_level(ch, cwid, ch, cwid, before.CoutP)}, true));
+                    pl.ops.push_back(make_dwpws_op(d1, after, t1, B, ch, cwid, 2, SSD_ACT_NONE, SSD_ACT_RELU, stage, omap_dev[1], total, rs0, rs1));
+                    pl.ops.push_back(make_dwpws_op(d2, after2, cur, B, ch, cwid, 2, SSD_ACT_NONE, SSD_ACT_RELU, stage, omap_dev[0], total, rs0, rs1));
+                    for (int j = 2; j <= n_units; ++j) {
+                        const ConvW &b2 = h->pw[ipw + 3 + 2 * (j - 2)], &a2 = h->pw[ipw + 3 + 2 * (j - 2) + 1];
+                        const DwW &dd = h->dw[idw + j];
+                        const float *xin = stage + (long long)(j - 2) * (xbytes / 4);
+                        pl.ops.push_back(make_conv_op(h, b2, xin, U, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU, {dense_level(oh, ow, oh, ow, Dp)}, true));
+                        pl.ops.push_back(make_dwpws_op(dd, a2, U, B, oh, ow, 1, SSD_ACT_NONE, SSD_ACT_RELU, stage, omap_dev[j], total, rs0, rs1));
+                    }
+                    float *S = stage + soff / 4;
+                    if (st == 0) { C3 = S; pl.retained["c3"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
+                    if (st == 1) { C4 = S; pl.retained["c4"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
+                    ipw += 3 + 2 * (n_units - 1); idw += 2 + (n_units - 1);
+                    cur = S;
+                    ch = oh; cwid = ow;
+                    continue;
+                }
+            }
+            ipw += 3; idw += 2;
+            float *t1, *t2, *t3, *Xa, *Xb, *Ya, *Yb, *U, *V;
+            SSDCHK(falloc(&t1, (long long)B * ch * cwid * before.CoutP));
+            SSDCHK(falloc(&t2, rows * d1.Cp));
+            SSDCHK(falloc(&t3, rows * d2.Cp));
+            SSDCHK(falloc(&Xa, rows * Dp)); SSDCHK(falloc(&Xb, rows * Dp));
+            SSDCHK(falloc(&Ya, rows * Dp)); SSDCHK(falloc(&Yb, rows * Dp));
+            SSDCHK(falloc(&U, rows * Dp)); SSDCHK(falloc(&V, rows * Dp));
+            pl.ops.push_back(make_conv_op(h, before, cur, t1, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+                                          {dense_level(ch, cwid, ch, cwid, before.CoutP)}, true));
+            push_dw_pw(h, pl.ops, sn_fuse, d1, after, t1, t2, Ya, B, ch, cwid, 2, SSD_ACT_NONE, SSD_ACT_RELU, before.Cout_l);
+            push_dw_pw(h, pl.ops, sn_fuse, d2, after2, cur, t3, Xa, B, ch, cwid, 2, SSD_ACT_NONE, SSD_ACT_RELU, before.Cin_l);
+            float *x = Xa, *y = Ya, *xs = Xb, *ys = Yb;
+            const int *tabx = h->tabs[st * 3], *taby = h->tabs[st * 3 + 1], *tabc = h->tabs[st * 3 + 2];
+            for (int j = 2; j <= units[st]; ++j) {
+                {   // concat_shuffle_split: (x, y) -> (xs, ys)
+                    Op g;
+                    g.cls = 5; g.flops = 0; g.bytes = 4.0 * rows * D * 4.0;
+                    const float *cx = x, *cy = y; float *ox = xs, *oy = ys;
+                    g.run = [=](hipStream_t s) {
+                        hipError_t e = launch_gather_channels(cx, Dp, cy, Dp, rows, tabx, Dp, ox, s);
+                        if (e != hipSuccess) return e;
+                        return launch_gather_channels(cx, Dp, cy, Dp, rows, taby, Dp, oy, s);
+                    };
+                    pl.ops.push_back(g);
+                }
+                const ConvW &b2 = h->pw[ipw], &a2 = h->pw[ipw + 1];
+                const DwW &dd = h->dw[idw];
+                ipw += 2; idw += 1;
+                pl.ops.push_back(make_conv_op(h, b2, xs, U, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+                                              {dense_level(oh, ow, oh, ow, Dp)}, true));
+                // new x overwrites the old x buffer (dead after the shuffle); y' = ys
+                push_dw_pw(h, pl.ops, sn_fuse, dd, a2, U, V, x, B, oh, ow, 1, SSD_ACT_NONE, SSD_ACT_RELU, D);
+                // now (x, ys) is the live pair; old y and xs are free
+                float *oldy = y;
+                y = ys; ys = oldy;
+            }
+            // concat([x, y]) -> stage output
+            const int Cc = round_up(2 * D, 32);
+            float *S;
+            SSDCHK(falloc(&S, rows * Cc));
+            {
+                Op g;
+                g.cls = 5; g.flops = 0; g.bytes = 4.0 * rows * D * 4.0;
+                const float *cx = x, *cy = y;
+                g.run = [=](hipStream_t s) { return launch_gather_channels(cx, Dp, cy, Dp, rows, tabc, Cc, S, s); };
+                pl.ops.push_back(g);
+            }
+            if (st == 0) { C3 = S; pl.retained["c3"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
+            if (st == 1) { C4 = S; pl.retained["c4"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
+            cur = S;
+            ch = oh; cwid = ow;
+        }
+        const ConvW &c5 = h->pw[ipw];
+        SSDCHK(falloc(&C5, (long long)B * ch * cwid * c5.CoutP));
+        pl.ops.push_back(make_conv_op(h, c5, cur, C5, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
+                                      {dense_level(ch, cwid, ch, cwid, c5.CoutP)}, true, 0, X16, 0, FL));
+        pl.retained["c5"] = Retained{C5, B, ch, cwid, c5.Cout_l, c5.CoutP, true, X16};
+    }
+
+    // ---------------- FPN (feature_extractor.py:40-76)
+    const Pyr py = make_pyr(B, H, W, 256);
+    float *P, *X5, *X4, *X3, *T6;
+    SSDCHK(falloc(&P, py.total));
+    SSDCHK(falloc(&X5, (long long)B * py.h[2] * py.w[2] * 256));
+    SSDCHK(falloc(&X4, (long long)B * py.h[1] * py.w[1] * 256));
+    SSDCHK(falloc(&X3, (long long)B * py.h[0] * py.w[0] * 256));
+    SSDCHK(falloc(&T6, (long long)B * py.h[3] * py.w[3] * 256));
+    auto lvl = [&](int l, int CoutP) { return dense_level(py.h[l], py.w[l], py.h[l], py.w[l], CoutP); };
+    // Three streams, explicit dependencies.  Main: lateral5 -> lateral4 (+up) -> lateral3 (+up) -> p3 (the critical
+    // path); second stream: p5 (needs x5) -> p4 (needs x4); third stream: p6 -> p7 (need only c5).  p6 is a chain of
+    // 288 dependent K-steps on a handful of tiles (K = 9 x 1024, M = B x 140): at batch 1 it takes 0.29 ms whatever
+    // the GPU does beside it, so nothing may queue behind it -- with p7, p5, p4 behind it on one stream the head towers
+    // started 0.12 ms later (batch-1 kernel trace, profiles/r02_batch1_timeline.txt).
+    // All of them are the same 3x3 kernel, and two such kernels side by side fill each other's
+    // tails (measured: paired tower layers run at 0.91 of the MFMA peak, a lone one at 0.85).
+    auto push = [&](Op op, int stream, std::vector<int> deps = {}) {
+        op.stream = stream;
+        op.deps = deps;
+        pl.ops.push_back(op);
+        if (stream == 1) pl.last_aux = (int)pl.ops.size() - 1;
+        return (int)pl.ops.size() - 1;
+    };
+    // last backbone op on the main stream (produces c5, or its first half); the second half, if any, ends on the
+    // second stream: the main stream's first FPN op waits for it
+    const int id_c5 = id_bb_last[0] >= 0 ? id_bb_last[0] : (int)pl.ops.size() - 1;
+    std::vector<int> l5_deps;
+    for (int c = 1; c < 4; ++c) if (id_bb_last[c] >= 0) l5_deps.push_back(id_bb_last[c]);
+    const int id_l5 = push(make_conv_op(h, h->lat[2], C5, X5, nullptr, nullptr, B, 1, 0, SSD_ACT_NONE, {lvl(2, 256)}, true, X16, X16, 0, FL), 0, l5_deps);
+    // (hipGraph capture of a forward with this third forked stream crashed inside the ROCm 7.2 runtime, and so did a captured
+    //  wait on an event of the waiting stream itself: with option graph = 1 p6 -> p7 stay on the second stream, in front of p5
+    //  and p4, as in round 1; enqueue_forward skips same-stream waits)
+    const int s6 = ssd_opt(h, OPT_GRAPH, 0) ? 1 : 2;
+    std::vector<int> p6_deps = {id_c5};             // c5 of every backbone chain that is not on p6's own stream
+    for (int c = 1; c < 4; ++c) if (c != s6 && id_bb_last[c] >= 0) p6_deps.push_back(id_bb_last[c]);
+    int id_p7;
+    {   // p6 = conv s2 (c5): BN+ReLU -> P6, ReLU(raw) -> T6 (input of p7, :60)
+        LevelDesc d = dense_level(py.h[2], py.w[2], py.h[3], py.w[3], 256);
+        d.out_off = py.off[3];
+        push(make_conv_op(h, h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), s6, p6_deps);
+        LevelDesc d7 = dense_level(py.h[3], py.w[3], py.h[4], py.w[4], 256);
+        d7.out_off = py.off[4];
+        id_p7 = push(make_conv_op(h, h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true, X16, X16, 0, FL), s6);
+    }
+    {   // p5 = conv(x5)
+        LevelDesc d = lvl(2, 256);
+        d.out_off = py.off[2];
+        push(make_conv_op(h, h->pconv[2], X5, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 1, {id_l5});
+    }
+    // x4 = up(x5) + lateral4(c4); p4;  x3 = up(x4) + lateral3(c3); p3
+    // lateral4 / lateral3 read c4 / c3, which stay fp32 rows for the depthwise layer that also consumes them: in
+    // f16x3 mode the rows are split into halves while they are staged (in_fmt 2); the upsampled operand and the
+    // output follow the mode
+    int LF = X16 && h->lat[1].tile == IGEMM_128x128 && h->lat[0].tile == IGEMM_128x128 ? 2 : 0;
+    if (!ssd_opt(h, OPT_LATERAL_SPLIT, 1)) LF = 0;       // A/B runs: 0 keeps them on the exact MFMA
+    const int id_l4 = push(make_conv_op(h, h->lat[1], C4, X4, nullptr, X5, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true, LF, X16, X16, FL), 0);
+    int id_p4, id_p3;
+    {
+        LevelDesc d = lvl(1, 256);
+        d.out_off = py.off[1];
+        id_p4 = push(make_conv_op(h, h->pconv[1], X4, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 1, {id_l4});
+    }
+    push(make_conv_op(h, h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true, LF, X16, X16, FL), 0);
+    {
+        LevelDesc d = lvl(0, 256);
+        d.out_off = py.off[0];
+        id_p3 = push(make_conv_op(h, h->pconv[0], X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 0);
+        pl.ops[id_p3].fpn_end = true;
+    }
+    for (int l = 0; l < 5; ++l) {
+        char nm[8];
+        snprintf(nm, sizeof nm, "p%d", l + 3);
+        pl.retained[nm] = Retained{P + py.off[l], B, py.h[l], py.w[l], 256, 256, true, X16};
+    }
+
+    // ---------------- heads (box_predictor.py:36-155), all levels per launch; box tower on the
+    // main stream, class tower on the second stream (independent chains)
+    const int C = h->cfg.num_classes, A = 6;
+    long long N = 0, aoff[5];
+    for (int l = 0; l < 5; ++l) { aoff[l] = N; N += (long long)py.h[l] * py.w[l] * A; }
+    pl.N = (int)N;
+    float *logits, *codes;
+    SSDCHK(falloc(&logits, (long long)B * N * C));
+    SSDCHK(falloc(&codes, (long long)B * N * 4));
+    // ---------------- anchors + post-processing
+    std::vector<float> anc((size_t)N * 4);
+    SSDCHK(ssd_anchors(H, W, anc.data()));
+    float *anc_dev;
+    SSDCHK(ap.upload(&anc_dev, anc));
+    void *ws;
+    const size_t wsb = post_workspace_bytes(B, (int)N, C, h->cfg.max_boxes_per_class);
+    SSDCHK(ap.alloc(&ws, wsb));
+    PostArgs &p = pl.post;
+    memset(&p, 0, sizeof(p));
+    p.logits = logits; p.codes = codes; p.anchors = anc_dev;
+    p.B = B; p.N = (int)N; p.C = C;
+    p.score_thr = h->cfg.score_threshold; p.iou_thr = h->cfg.iou_threshold;
+    p.max_per_class = h->cfg.max_boxes_per_class;
+    p.fast_max = nms_fast_max(h);
+    for (int k = 0; k < 4; ++k) p.box_scaler[k] = rd.box_scaler[k];    // model.py:67-68
+    post_carve(p, ws);
+    HIPCHK(hipMemset(p.scan_bits, 0, post_scan_bitmap_bytes(B, (int)N, C)));
+    HIPCHK(hipMemset(p.counts, 0, (size_t)B * C * sizeof(int)));      // the post-processing kernels leave these zeroed again
+    HIPCHK(hipMemset(p.big_n, 0, sizeof(int)));
+    p.self_clean = 1;
+    // (Measured and not adopted, batch 1: the two coarse levels -- 175 of 11 935 positions -- as launches of their own on a
+    //  third / fourth stream behind p7, so that the towers of levels 3..5 start when p3..p5 exist: 2.12 -> 2.29 ms per forward;
+    //  ten more launches of 72-step chains beside the big ones cost more than the 0.07 ms earlier start.  option level_split = 1
+    //  keeps the experiment reachable.)
+    const bool split_levels = B <= 2 && s6 == 2 && ssd_opt(h, OPT_LEVEL_SPLIT, 0) != 0;
+    const int ngrp = split_levels ? 2 : 1;
+    const int g_lo[2] = {0, 3}, g_hi[2] = {split_levels ? 3 : 5, 5};
+    std::vector<Op> tower_ops[2][2];            // [tower][level group]
+    bool all_marked = true;
+    for (int t = 0; t < 2; ++t) {
+        float *TA, *TB;
+        SSDCHK(falloc(&TA, py.total));
+        SSDCHK(falloc(&TB, py.total));
+        const float *in = P;
+        float *out = TA;
+        for (int i = 0; i < 4; ++i) {
+            for (int g = 0; g < ngrp; ++g) {
+                std::vector<LevelDesc> lv;
+                for (int l = g_lo[g]; l < g_hi[g]; ++l) lv.push_back(dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, py.off[l], py.off[l], l * 256));
+                tower_ops[t][g].push_back(make_conv_op(h, h->tower[t][i], in, out, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true, X16, X16, 0, FL));
+            }
+            in = out;
+            out = (out == TA) ? TB : TA;
+        }
+        const int per = t == 0 ? 4 : C;     // values per anchor
+        // class logits: the convolution's epilogue also marks the octets that hold a candidate (p.scan_bits) and
+        // post_scan_kernel reads the bitmap instead of all logits
+        const bool can_mark = t == 1 && ((long long)N * C) % 8 == 0 && (6 * C) % 8 == 0;
+        for (int g = 0; g < ngrp; ++g) {
+            std::vector<LevelDesc> lv;
+            for (int l = g_lo[g]; l < g_hi[g]; ++l) {
+                LevelDesc d = dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 0, py.off[l]);
+                d.out_off = aoff[l] * per;
+                d.out_bstride = N * per;
+                d.out_rstride = A * per;
+                d.param_off = 0;
+                lv.push_back(d);
+            }
+            bool marked = false;
+            Op fop = make_conv_op(h, h->final_[t], in, t == 0 ? codes : logits, nullptr, nullptr, B, 1, 1, SSD_ACT_NONE, lv, false, X16, 0, 0, FL,
+                                  can_mark ? p.scan_bits : nullptr, conservative_logit_bound(h->cfg.score_threshold), &marked);
+            if (t == 1) all_marked = all_marked && marked;
+            tower_ops[t][g].push_back(fop);
+        }
+    }
+    p.scan_fused = all_marked ? 1 : 0;
+    // enqueue order interleaved so the hardware queues stay fed.  The first box-tower layer (main) needs p4, p5 from the
+    // second stream (and, unless the coarse levels run apart, p6, p7 from the third); the first class-tower layer (second
+    // stream) needs p3 from the main stream (and p6, p7).  Coarse-level chains: box on the third stream (behind p7, same
+    // stream), class on the fourth (waits for p7).
+    for (size_t i = 0; i < tower_ops[0][0].size(); ++i)
+        for (int t = 1; t >= 0; --t) {
+            std::vector<int> deps;
+            if (i == 0) { deps.push_back(t == 0 ? id_p4 : id_p3); if (!split_levels) deps.push_back(id_p7); }
+            push(tower_ops[t][0][i], t, deps);
+            if (split_levels) {
+                std::vector<int> d2;
+                if (i == 0) d2.push_back(id_p7);
+                push(tower_ops[t][1][i], t == 0 ? 2 : 3, d2);
+            }
+        }
+    pl.tail_on[0] = pl.tail_on[1] = split_levels;
+    // events for every op another stream waits on
+    for (const Op &op : pl.ops)
+        for (int d : op.deps)
+            if (!pl.ops[d].done) HIPCHK(hipEventCreateWithFlags(&pl.ops[d].done, hipEventDisableTiming));
+    pl.retained["encoded_boxes"] = Retained{codes, B, 1, (int)N, 4, 4, false};
+    pl.retained["class_predictions"] = Retained{logits, B, 1, (int)N, C, C, false};
+
+    return SSD_OK;
+}
+
+float conservative_logit_bound(float thr)
+{
+    if (!(thr > 0.0f)) return -INFINITY;
+    if (!(thr < 1.0f)) return INFINITY;
+    const double l = log((double)thr / (1.0 - (double)thr));
+    return (float)(l - 1e-3 * (1.0 + fabs(l)));
+}
+
+static hipError_t pool_event(ssd_handle *h, hipEvent_t *e)
+{
+    if (!h->ev_pool.empty()) { *e = h->ev_pool.back(); h->ev_pool.pop_back(); return hipSuccess; }
+    return hipEventCreate(e);
+}
+
+static hipError_t run_op(ssd_handle *h, const Op &op, hipStream_t s)
+{
+    if (ssd_opt(h, OPT_DEBUG_SYNC, 0)) {      // fault localisation: announce every op, run it alone, wait for it
+        fprintf(stderr, "[ssd] op class %d stream %d flops %.3g bytes %.3g ...", op.cls, op.stream, op.flops, op.bytes);
+        fflush(stderr);
+        (void)hipDeviceSynchronize();
+        hipError_t r = op.run(s);
+        hipError_t r2 = hipDeviceSynchronize();
+        fprintf(stderr, " %s\n", r == hipSuccess && r2 == hipSuccess ? "ok" : "FAILED");
+        return r != hipSuccess ? r : r2;
+    }
+    if (!h->profiling) return op.run(s);
+    EvPair e;
+    e.cls = op.cls;
+    e.fwd = (int)h->ref_evs.size() - 1;
+    hipError_t r = pool_event(h, &e.a);
+    if (r != hipSuccess) return r;
+    r = pool_event(h, &e.b);
+    if (r != hipSuccess) return r;
+    (void)hipEventRecord(e.a, s);
+    r = op.run(s);
+    (void)hipEventRecord(e.b, s);
+    h->evs.push_back(e);
+    h->acc_flops[op.cls] += op.flops;
+    h->acc_bytes[op.cls] += op.bytes;
+    h->acc_n[op.cls] += 1;
+    return r;
+}
+
+int make_plans(ssd_handle *h, int B, int H, int W)
+{
+    free_plans(h);
+    // Measured on MI355X (B = 32, 640x896): 1 / 2 / 4 / 8 sub-batches -> 730 / 696 / 647 / 587 img/s.
+    // Backbone kernels running beside head kernels take CU slots from them and stretch far more
+    // than the overlap returns, so the default is ONE plan; option nsub keeps the experiment alive.
+    int nsub = 1;
+    { const int v = ssd_opt(h, OPT_NSUB, 0); if (v >= 1 && v <= 8) nsub = v; }
+    {   // every tensor a launch addresses with 32-bit byte offsets must stay < 2 GiB -> split very large batches into
+        // consecutive sub-batch plans.  Per image: the largest backbone tensor (first conv / max-pool output
+        // [H/2, W/2, 32]; MobileNet's Conv2d_1_pointwise doubles the channels at that resolution), the concatenated
+        // pyramid of a head tower (256 channels), the class logits [N, C], the box codes, and the uint8 source image.
+        const ResizeDims rd = resize_dims(H, W, h->cfg.min_dimension, 128);
+        const int nH = rd.nh + rd.ph, nW = rd.nw + rd.pw;
+        const int cmax = h->cfg.backbone == SSD_BACKBONE_MOBILENET && !h->pw.empty() ? std::max(h->firstCp, h->pw[0].CoutP) : h->firstCp;
+        long long per_img = (long long)(nH / 2) * (nW / 2) * cmax * 4;
+        const Pyr py1 = make_pyr(1, nH, nW, 256);
+        per_img = std::max(per_img, py1.total * 4);
+        per_img = std::max(per_img, (long long)ssd_num_anchors(nH, nW) * std::max(h->cfg.num_classes, 4) * 4);
+        per_img = std::max(per_img, (long long)H * W * 3);
+        const long long bmax = ((1LL << 31) - 1) / per_img;
+        if (bmax < 1) return ssd_fail(SSD_ERR_INVALID, "ssd_forward: image too large for one launch");
+        const int need = (int)((B + bmax - 1) / bmax);
+        if (need > nsub) nsub = need;
+    }
+    if (nsub > B) nsub = B;
+    int img0 = 0;
+    for (int k = 0; k < nsub; ++k) {
+        const int bk = B / nsub + (k < B % nsub ? 1 : 0);
+        Plan *pl = new Plan();
+        h->plans.push_back(pl);
+        if (k > 0) HIPCHK(hipStreamCreateWithFlags(&pl->s_main, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&pl->s_aux, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&pl->s_bb[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&pl->ev_fpn, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&pl->ev_done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&pl->ev_begin, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&pl->ev_join_bb[i], hipEventDisableTiming));
+        SSDCHK(build_plan(h, *pl, bk, H, W, img0));
+        img0 += bk;
+    }
+    h->pB = B; h->pH = H; h->pW = W;
+    return SSD_OK;
+}
+
+// Enqueues one forward on stream `s` (plus the plans' internal streams): kernels only, no host
+// synchronisation -- also what a hipGraph capture records.
+int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, int32_t *labels_dev,
+                           float *scores_dev, int32_t *num_boxes_dev, hipStream_t s)
+{
+    h->cur_images = images_dev;
+    if (h->profiling) {
+        hipEvent_t ref;
+        HIPCHK(pool_event(h, &ref));
+        HIPCHK(hipEventRecord(ref, s));
+        h->ref_evs.push_back(ref);
+    }
+    const int T = h->cfg.num_classes * h->cfg.max_boxes_per_class;
+    HIPCHK(hipEventRecord(h->ev_start, s));
+    for (size_t k = 0; k < h->plans.size(); ++k) {
+        Plan &pl = *h->plans[k];
+        hipStream_t sm = pl.s_main ? pl.s_main : s;
+        if (k > 0) {
+            // staggered start: after the caller's prior work, and once the previous sub-batch
+            // has left its backbone + FPN (so this backbone runs beneath that one's heads)
+            HIPCHK(hipStreamWaitEvent(sm, h->ev_start, 0));
+            HIPCHK(hipStreamWaitEvent(sm, h->plans[k - 1]->ev_fpn, 0));
+        }
+        HIPCHK(hipEventRecord(pl.ev_begin, sm));
+        // option streams = 1: every op on the plan's main stream, in plan order (a valid order: an op's dependencies precede it) --
+        // a measurement aid that shows what the kernels cost without each other beside them
+        const bool single = ssd_opt(h, OPT_STREAMS, 0) == 1;
+        bool aux_used = false, started[4] = {true, false, false, false};
+        for (const Op &op : pl.ops) {
+            const int os = single ? 0 : op.stream;
+            hipStream_t st = os == 0 ? sm : (os == 1 ? pl.s_aux : pl.s_bb[os - 2]);
+            if (!started[os] && op.deps.empty())                    // a chain that starts on another stream:
+                HIPCHK(hipStreamWaitEvent(st, pl.ev_begin, 0));     // behind the plan's own start
+            started[os] = true;
+            for (int d : op.deps)           // (same stream: already ordered -- and a captured self-wait corrupted the ROCm 7.2 graph runtime's heap)
+                if (!single && pl.ops[d].stream != op.stream) HIPCHK(hipStreamWaitEvent(st, pl.ops[d].done, 0));
+            HIPCHK(run_op(h, op, st));
+            if (op.done && !single) HIPCHK(hipEventRecord(op.done, st));
+            if (op.fpn_end) HIPCHK(hipEventRecord(pl.ev_fpn, sm));
+            aux_used |= os == 1;
+        }
+        if (aux_used) {                             // join before the post-processing reads the logits
+            HIPCHK(hipEventRecord(pl.ev_join, pl.s_aux));
+            HIPCHK(hipStreamWaitEvent(sm, pl.ev_join, 0));
+        }
+        for (int c = 2; c < 4; ++c)                 // ... and the third / fourth stream, when the plan ends chains there
+            if (pl.tail_on[c - 2] && !single) {
+                HIPCHK(hipEventRecord(pl.ev_join_bb[c - 2], pl.s_bb[c - 2]));
+                HIPCHK(hipStreamWaitEvent(sm, pl.ev_join_bb[c - 2], 0));
+            }
+        PostArgs p = pl.post;
+        p.boxes = boxes_dev + (size_t)pl.img0 * T * 4;
+        p.labels = labels_dev + (size_t)pl.img0 * T;
+        p.scores = scores_dev + (size_t)pl.img0 * T;
+        p.num = num_boxes_dev + pl.img0;
+        p.logit_lo = conservative_logit_bound(p.score_thr);
+        Op pop;
+        pop.cls = 4;
+        pop.flops = 0;
+        pop.bytes = (double)pl.B * p.N * (p.C + 8) * 4.0;
+        pop.run = [p](hipStream_t st) { return launch_postprocess(p, st); };
+        HIPCHK(run_op(h, pop, sm));
+        if (k > 0) HIPCHK(hipEventRecord(pl.ev_done, sm));
+    }
+    for (size_t k = 1; k < h->plans.size(); ++k) HIPCHK(hipStreamWaitEvent(s, h->plans[k]->ev_done, 0));
+    return SSD_OK;
+}

@@ -100,8 +100,9 @@ __device__ __forceinline__ void emit_candidate(const PostArgs &p, unsigned elem,
 #define SCAN_Q (2048 + 256 * SCAN_U * 4)
 __global__ __launch_bounds__(256) void post_scan_kernel(const PostArgs p)
 {
-    __shared__ unsigned q_elem[SCAN_Q];
+    __shared__ unsigned q_elem[SCAN_Q > 8192 ? SCAN_Q : 8192];      // fused path: the octet queue of a pass (256 words x 32 octets)
     __shared__ float q_val[SCAN_Q];
+    __shared__ unsigned q_cand[4096];                               // fused path: element index of a queued candidate
     __shared__ int q_n;
     const int C = p.C;
     const bool vec = (C & 3) == 0;
@@ -120,31 +121,61 @@ __global__ __launch_bounds__(256) void post_scan_kernel(const PostArgs p)
         q_elem[slot] = elem;
         q_val[slot] = v;
     };
+    auto push_c = [&](unsigned elem, float v) {
+        const int slot = atomicAdd(&q_n, 1);
+        q_cand[slot] = elem;
+        q_val[slot] = v;
+    };
+    auto drain_c = [&]() {
+        const int n = q_n;
+        for (int t = threadIdx.x; t < n; t += 256) emit_candidate(p, q_cand[t], q_val[t]);
+        __syncthreads();
+        if (threadIdx.x == 0) q_n = 0;
+        __syncthreads();
+    };
     if (p.scan_fused) {
-        // The logits convolution marked the octets that hold a candidate (igemm16.hip): read the bitmap (B*N*C/64
-        // bytes) and the marked octets only.  Same filter, same emit_candidate: the per-class lists hold the same set.
+        // The logits convolution marked the octets that hold a candidate (igemm.hip / igemm16.hip / igemm_lat.hip epilogues):
+        // read the bitmap (B*N*C/64 bytes) and the marked octets only.  Same filter, same emit_candidate: the per-class
+        // lists hold the same set.  Three dense phases per 256 bitmap words: (1) every thread queues the marked octets of
+        // its word, (2) the octet queue is read densely, 512 octets at a time -- all logit loads of a pass in flight
+        // together -- and the values above the bound go to the candidate queue, (3) dense drain.  (The first form walked
+        // one marked octet per thread and round with two block-wide votes per round: a chain of dependent loads as long
+        // as the busiest thread's word; batch 1: 52 us.)  The words are cleared on the way: the bitmap is clean again for
+        // the next forward's logits convolution without a memset.
+        unsigned *oq = q_elem;                               // octet queue: at most 256 * 32 entries; candidates go to q_val / q_cand
+        __shared__ int oq_n;
         const long long nwords = ((long long)p.B * p.N * C / 8 + 31) / 32;
         for (long long w0 = (long long)blockIdx.x * 256; w0 < nwords; w0 += (long long)gridDim.x * 256) {
             const long long w = w0 + threadIdx.x;
+            if (threadIdx.x == 0) oq_n = 0;
+            __syncthreads();
             unsigned bits = w < nwords ? p.scan_bits[w] : 0u;
-            // one marked octet per thread and round: at most 256 * 8 pushes between two looks at the queue
-            // (capacity 2048 + 4096), however dense the marks are (saturated logits mark every octet)
-            while (__syncthreads_or(bits != 0)) {
-                if (bits) {
-                    const int k = __builtin_ctz(bits);
+            if (bits) {
+                p.scan_bits[w] = 0u;
+                const int base = atomicAdd(&oq_n, __builtin_popcount(bits));
+                int k = 0;
+                while (bits) {
+                    const int bpos = __builtin_ctz(bits);
                     bits &= bits - 1;
-                    const long long e0 = (w * 32 + k) * 8;
+                    oq[base + k++] = (unsigned)((w - w0) * 32 + bpos);          // octet index relative to this pass
+                }
+            }
+            __syncthreads();
+            const int no = oq_n;
+            for (int o0 = 0; o0 < no; o0 += 512) {                              // <= 512 * 8 candidates per pass: fits the queue
+                for (int t = o0 + threadIdx.x; t < no && t < o0 + 512; t += 256) {
+                    const long long e0 = (w0 * 32 + oq[t]) * 8;
                     const v4f x0 = *(const v4f *)(p.logits + e0), x1 = *(const v4f *)(p.logits + e0 + 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (x0[j] >= p.logit_lo) push((unsigned)(e0 + j), x0[j]);
-                        if (x1[j] >= p.logit_lo) push((unsigned)(e0 + 4 + j), x1[j]);
+                        if (x0[j] >= p.logit_lo) push_c((unsigned)(e0 + j), x0[j]);
+                        if (x1[j] >= p.logit_lo) push_c((unsigned)(e0 + 4 + j), x1[j]);
                     }
                 }
-                if (__syncthreads_or(q_n > 2048)) drain();
+                __syncthreads();
+                drain_c();
             }
         }
-        drain();
         return;
     }
     const long long stride = (long long)gridDim.x * 256 * SCAN_U;
@@ -197,6 +228,34 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v)
 
 #define NMS_R 8      // candidates per thread kept in registers
 #define NMS_BIG 1024 // threads of the large-list kernel
+#define NMS_MID 256  // threads of the per-pair kernel: lists up to 64 * NMS_R stay in wave 0, up to NMS_MID * NMS_R in the block
+
+// The box of the round's winner without a trip to memory: exactly one (lane, slot) of the wave holds `best` (keys are
+// unique: the anchor index is part of the key); that lane selects its box, a ballot names it, v_readlane broadcasts it.
+// (The first form re-read dec[] from global memory every round: a dependent ~1.2 us load in each of up to 25 rounds.)
+template <int R>
+__device__ __forceinline__ v4f winner_box(const u64 (&key)[R], const v4f (&box)[R], u64 best, bool &found)
+{
+    v4f mine = {0.f, 0.f, 0.f, 0.f};
+    found = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool hit = key[r] == best;
+        found |= hit;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mine[e] = hit ? box[r][e] : mine[e];
+    }
+    return mine;
+}
+__device__ __forceinline__ v4f wave_broadcast_box(v4f mine, bool found)
+{
+    const unsigned long long m = __ballot(found);
+    const int src = m ? (int)__builtin_ctzll(m) : 0;
+    v4f wb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wb[e] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mine[e]), src));
+    return wb;
+}
 
 // Greedy NMS of one (image, class) list by ONE wavefront with R candidates per lane in registers.  keys and boxes are
 // immutable; liveness is one bit per register slot.  (A version that zeroed key[r] under `key == best || iou > thr` was
@@ -226,7 +285,9 @@ __device__ __forceinline__ int nms_one_wave(const PostArgs &p, const u64 *keys, 
         }
         best = wave_max_u64(best);
         if (best == 0) break;
-        const v4f wb = *(const v4f *)(dec + (long long)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFu)) * 4);
+        bool found;
+        const v4f mine = winner_box<R>(key, box, best, found);
+        const v4f wb = wave_broadcast_box(mine, found);
         if (lane == 0) {
             *(v4f *)(ob + kept * 4) = wb;
             os[kept] = __uint_as_float((unsigned)(best >> 32));
@@ -243,27 +304,92 @@ __device__ __forceinline__ int nms_one_wave(const PostArgs &p, const u64 *keys, 
     return kept;
 }
 
-// K9c, lists of up to 64*NMS_R candidates: one wavefront, everything in registers.  (Measured and not adopted: the same wave
-// with 32 candidates per lane for lists of 513 .. 2 048 instead of the 1 024-thread kernel -- batch-1 post-processing 0.22 ->
-// 0.28 ms: 32 IoU tests per lane and round cost more than the block kernel's barrier per round.)
-__global__ __launch_bounds__(64) void post_nms_small_kernel(const PostArgs p)
+// K9c, one block of NMS_MID threads per (image, class) pair.
+//   n <= fast_max (64 * NMS_R)      wave 0 alone, everything in registers, no barrier (the other waves leave at once)
+//   n <= mid_max (NMS_MID * NMS_R)  the block's four waves, NMS_R candidates per thread, one barrier per round: each wave's
+//                                   lane 0 posts (wave best, its box) in LDS, every thread takes the block's best and box
+//                                   from there (double-buffered by round parity)
+//   longer                          onto the work list of post_nms_big_kernel
+// (Measured and not adopted, round 2: ONE wave with 32 candidates per lane for lists of 513 .. 2 048 -- 0.22 -> 0.28 ms:
+//  32 IoU tests per lane and round.  Four waves keep 8 per lane; the 1 024-thread kernel they replace for these lengths
+//  paid a 16-wave barrier and a global box load per round: batch-1 post-processing 96 us for two or three such lists.)
+__global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
 {
+    __shared__ u64 wbest[2][NMS_MID / 64];
+    __shared__ v4f wbox[2][NMS_MID / 64];
     const int bc = blockIdx.x;              // b*C + c
     const int b = bc / p.C;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int n = p.counts[bc];
     if (n > p.N) n = p.N;
-    if (n > p.fast_max) {                   // handled by post_nms_big_kernel: put the pair on its work list
-        if (lane == 0) p.big_list[atomicAdd(p.big_n, 1)] = bc;
+    if (n > p.mid_max) {                    // handled by post_nms_big_kernel: put the pair on its work list
+        if (tid == 0) p.big_list[atomicAdd(p.big_n, 1)] = bc;
         return;
     }
     const u64 *keys = p.keys + (long long)bc * p.N;
     const float *dec = p.dec + (long long)b * p.N * 4;
     float *ob = p.cls_boxes + (long long)bc * p.max_per_class * 4;
     float *os = p.cls_scores + (long long)bc * p.max_per_class;
+    if (n <= p.fast_max) {                  // block-uniform
+        if (wave != 0) return;
+        int kept = 0;
+        if (n > 0) kept = nms_one_wave<NMS_R>(p, keys, dec, n, lane, ob, os);
+        if (lane == 0) p.cls_counts[bc] = kept;
+        return;
+    }
+    u64 key[NMS_R];
+    v4f box[NMS_R];
+    unsigned alive = 0;
+#pragma unroll
+    for (int r = 0; r < NMS_R; ++r) {
+        const int i = tid + NMS_MID * r;
+        const bool ok = i < n;
+        key[r] = ok ? keys[ok ? i : 0] : 0ull;
+        const unsigned anchor = 0xFFFFFFFFu - (unsigned)(key[r] & 0xFFFFFFFFu);
+        box[r] = *(const v4f *)(dec + (long long)(ok ? anchor : 0u) * 4);
+        alive |= ok ? (1u << r) : 0u;
+    }
     int kept = 0;
-    if (n > 0) kept = nms_one_wave<NMS_R>(p, keys, dec, n, lane, ob, os);
-    if (lane == 0) p.cls_counts[bc] = kept;
+    while (kept < p.max_per_class) {        // uniform trip count: `best` is block-uniform
+        u64 best = 0;
+#pragma unroll
+        for (int r = 0; r < NMS_R; ++r) {
+            const u64 k = ((alive >> r) & 1u) ? key[r] : 0ull;
+            best = k > best ? k : best;
+        }
+        best = wave_max_u64(best);
+        bool found;
+        const v4f mine = winner_box<NMS_R>(key, box, best, found);
+        const v4f wv = wave_broadcast_box(mine, found & (best != 0));
+        const int buf = kept & 1;
+        if (lane == 0) { wbest[buf][wave] = best; wbox[buf][wave] = wv; }
+        __syncthreads();
+        v4f wb = wbox[buf][0];
+        best = wbest[buf][0];
+#pragma unroll
+        for (int w = 1; w < NMS_MID / 64; ++w) {
+            const u64 o = wbest[buf][w];
+            const v4f ov = wbox[buf][w];
+            const bool gt = o > best;
+            best = gt ? o : best;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wb[e] = gt ? ov[e] : wb[e];
+        }
+        if (best == 0) break;
+        if (tid == 0) {
+            *(v4f *)(ob + kept * 4) = wb;
+            os[kept] = __uint_as_float((unsigned)(best >> 32));
+        }
+        ++kept;
+        unsigned kill = 0;
+#pragma unroll
+        for (int r = 0; r < NMS_R; ++r) {
+            const bool k = (key[r] == best) | iou_greater(box[r], wb, p.iou_thr);
+            kill |= k ? (1u << r) : 0u;
+        }
+        alive &= ~kill;
+    }
+    if (tid == 0) p.cls_counts[bc] = kept;
 }
 
 // K9c, longer lists: 1024 threads per (image, class).  Up to 1024*NMS_R candidates live in
@@ -437,6 +563,12 @@ __global__ __launch_bounds__(256) void post_pack_kernel(const PostArgs p)
         scores[d] = 0.0f;
         labels[d] = 0;
     }
+    if (p.self_clean) {
+        // the last kernel of the post-processing leaves the counters as the next forward's scan expects them (the plan
+        // zeroed them once when it was built): no memset launches in front of the scan
+        for (int c = threadIdx.x; c < C; c += blockDim.x) p.counts[b * C + c] = 0;
+        if (b == 0 && threadIdx.x == 0) *p.big_n = 0;
+    }
 }
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -474,31 +606,36 @@ void post_carve(PostArgs &p, void *ws)
 hipError_t launch_postprocess(const PostArgs &pin, hipStream_t s)
 {
     PostArgs p = pin;
-    // lists up to fast_max candidates stay in one wave's registers; the caller may lower it (tests route every
-    // list through the 1024-thread kernel), 0 / out of range = the default
-    if (p.fast_max < 1 || p.fast_max > 64 * NMS_R) p.fast_max = pin.fast_max == -1 ? 0 : 64 * NMS_R;
+    // lists up to fast_max candidates stay in one wave's registers, up to mid_max in one 256-thread block; the caller may
+    // lower the hand-over point (tests route every list through the 1024-thread kernel): then longer lists go straight to
+    // that kernel as before.  0 / out of range = the defaults
+    if (p.fast_max < 1 || p.fast_max > 64 * NMS_R) {
+        p.fast_max = pin.fast_max == -1 ? 0 : 64 * NMS_R;
+        p.mid_max = pin.fast_max == -1 ? 0 : NMS_MID * NMS_R;
+    } else {
+        p.mid_max = p.fast_max < 64 * NMS_R ? p.fast_max : NMS_MID * NMS_R;
+    }
     if (p.B < 1 || p.N < 1 || p.C < 1 || p.max_per_class < 1) return hipErrorInvalidValue;
     if ((long long)p.B * p.N * p.C >= (1LL << 32)) return hipErrorInvalidValue;   // 32-bit element index in the scan queue
-    hipError_t e = hipMemsetAsync(p.counts, 0, (size_t)p.B * p.C * sizeof(int), s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(p.big_n, 0, sizeof(int), s);
-    if (e != hipSuccess) return e;
+    hipError_t e;
+    if (!p.self_clean) {         // a caller's workspace (ssd_postprocess): nothing is known about its contents
+        e = hipMemsetAsync(p.counts, 0, (size_t)p.B * p.C * sizeof(int), s);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(p.big_n, 0, sizeof(int), s);
+        if (e != hipSuccess) return e;
+    }
     const long long units = (long long)p.B * p.N * ((p.C & 3) ? p.C : p.C / 4);
     long long blocks = (units + 256 * SCAN_U - 1) / (256 * SCAN_U);
     if (blocks > 256 * 32) blocks = 256 * 32;
-    if (p.scan_fused) {          // bitmap walk: one resident round of blocks (48 KB of LDS each: three per CU)
+    if (p.scan_fused) {          // bitmap walk: one resident round of blocks (72 KB of LDS each: two per CU)
         const long long nwords = ((long long)p.B * p.N * p.C / 8 + 31) / 32;
         blocks = (nwords + 255) / 256;
-        if (blocks > 768) blocks = 768;
+        if (blocks > 512) blocks = 512;
     }
     hipLaunchKernelGGL(post_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(post_nms_small_kernel, dim3((unsigned)(p.B * p.C)), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(post_nms_kernel, dim3((unsigned)(p.B * p.C)), dim3(NMS_MID), 0, s, p);
     const int big_blocks = p.B * p.C < 512 ? p.B * p.C : 512;     // two resident blocks per CU
     hipLaunchKernelGGL(post_nms_big_kernel, dim3((unsigned)big_blocks), dim3(NMS_BIG), 0, s, p);
     hipLaunchKernelGGL(post_pack_kernel, dim3((unsigned)p.B), dim3(256), (p.C + 1) * sizeof(int), s, p);
-    if (p.scan_fused) {          // clean bitmap for the next forward's logits convolution (ordered behind this stream)
-        e = hipMemsetAsync(p.scan_bits, 0, post_scan_bitmap_bytes(p.B, p.N, p.C), s);
-        if (e != hipSuccess) return e;
-    }
     return hipGetLastError();
 }

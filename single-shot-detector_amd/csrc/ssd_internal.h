@@ -79,10 +79,19 @@ struct IgemmArgs {
 };
 
 // tile variants of the implicit-GEMM kernel: BM x BN
-enum IgemmTile { IGEMM_128x128 = 0, IGEMM_128x64 = 1, IGEMM_128x32 = 2, IGEMM_128x256 = 3, IGEMM_256x128 = 4, IGEMM_64x64 = 5, IGEMM_128x96 = 6 };
+enum IgemmTile { IGEMM_128x128 = 0, IGEMM_128x64 = 1, IGEMM_128x32 = 2, IGEMM_128x256 = 3, IGEMM_256x128 = 4, IGEMM_64x64 = 5, IGEMM_128x96 = 6,
+                 IGEMM_64x64D = 7 /* 64x64 with the wide tiles' two register sets: loads three K-steps ahead */ };
 int igemm_tile_bm(int tile);
 int igemm_tile_bn(int tile);
 hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s);
+// igemm_lat.hip: the latency form for small launches (v_mfma_f32_16x16x4_f32, one wave per block, no LDS): wave tile
+// PT x 16 positions by CT x 16 channels; tile_begin of the levels counts PT*16-row tiles, n_tiles_n = CoutPad / (CT*16)
+enum IgemmLatTile { IGEMM_LAT_1x1 = 20, IGEMM_LAT_1x2 = 21, IGEMM_LAT_2x1 = 22, IGEMM_LAT_2x2 = 23 };
+static inline bool igemm_is_lat(int tile) { return tile >= IGEMM_LAT_1x1 && tile <= IGEMM_LAT_2x2; }
+int igemm_lat_bm(int tile);
+int igemm_lat_bn(int tile);
+bool igemm_lat_supports(const IgemmArgs &a);
+hipError_t launch_igemm_lat(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s);
 // igemm16.hip: 256 x 256 tiles, one block per CU, S16 in / S16 out with batch norm (towers, FPN outputs);
 // tile_begin of the levels counts 256-row tiles, n_tiles_n = CoutPad / 256
 #define IGEMM16_TILE 100
@@ -137,7 +146,10 @@ struct PostArgs {
     float score_thr, iou_thr;
     float logit_lo;        // conservative logit bound below which sigmoid(x) <= score_thr
     int max_per_class;
-    int fast_max;          // candidate lists up to this length are processed in registers
+    int fast_max;          // candidate lists up to this length are processed in one wave's registers
+    int mid_max;           // ... up to this length in one 256-thread block (set by launch_postprocess)
+    int self_clean;        // 1: the workspace belongs to a layer plan that zeroed counts / big_n / scan_bits once; the kernels leave
+                           // them zeroed for the next forward (no memset launches).  0: a caller's workspace, cleared per call
     float box_scaler[4];
     float *boxes; int32_t *labels; float *scores; int32_t *num;
     // workspace carve-up

@@ -56,17 +56,10 @@ class Detector:
         self.engine = Engine(self.params, weights, device=device, precision=precision)
         self.device = device
 
-    def detect_batch(self, images):
-        """images: uint8 ndarray [B,H,W,3] (or CUDA tensor), any H, W (the graph's
-        resize_keeping_aspect_ratio is fused into the first kernel) -> the graph outputs
-        (boxes [B,T,4], labels [B,T], scores [B,T], num_boxes [B]) as numpy arrays
-        (model.py:70-73)."""
-        _torch()
-        if isinstance(images, np.ndarray):
-            if images.dtype != np.uint8 or images.ndim != 4 or images.shape[3] != 3:
-                raise ValueError("images must be a uint8 array of shape [B, height, width, 3]")
-        boxes, labels, scores, num = self.engine.forward_cached(images)
-        out = boxes.cpu().numpy(), labels.cpu().numpy(), scores.cpu().numpy(), num.cpu().numpy()
+    def _detect_views(self, images):
+        """The graph outputs of one host batch as numpy VIEWS of the engine's pinned result block (valid until the next
+        call); the caller holds self.engine.lock."""
+        out = self.engine.detect_host(images)
         if self.engine.precision == "f16x3" and self.engine.status() & 1:
             # an activation exceeded +-65504 and was clamped (ssd_hip.h ssd_status): these results are not
             # trustworthy -- this detector continues in the exact mode
@@ -74,9 +67,31 @@ class Detector:
             warnings.warn("single-shot-detector_amd: activation outside the fp16 range in precision mode "
                           "f16x3; switching this Detector to f32")
             self.engine.set_precision("f32")
-            boxes, labels, scores, num = self.engine.forward_cached(images)
-            out = boxes.cpu().numpy(), labels.cpu().numpy(), scores.cpu().numpy(), num.cpu().numpy()
+            out = self.engine.detect_host(images)
         return out
+
+    def detect_batch(self, images):
+        """images: uint8 ndarray [B,H,W,3] (or CUDA tensor), any H, W (the graph's
+        resize_keeping_aspect_ratio is fused into the first kernel) -> the graph outputs
+        (boxes [B,T,4], labels [B,T], scores [B,T], num_boxes [B]) as numpy arrays
+        (model.py:70-73).  Thread-safe, like sess.run on a shared tf.Session (inference/detector.py:34,52)."""
+        torch = _torch()
+        if isinstance(images, torch.Tensor):
+            with self.engine.lock:
+                return tuple(t.cpu().numpy() for t in self.engine.forward_cached(images))
+        with self.engine.lock:
+            return tuple(np.array(v) for v in self._detect_views(images))
+
+    def detect_stream(self, batches):
+        """Steady-state serving: an iterable of host uint8 batches [B,H,W,3] -> a generator of the graph outputs per
+        batch, in order, with the host-to-device and device-to-host copies of neighbouring batches hidden under the
+        compute of the current one (Engine.detect_stream).  Mode f32 (mode f16x3 needs the per-batch status check of
+        detect_batch and is served by that method)."""
+        if self.engine.precision != "f32":
+            for images in batches:
+                yield self.detect_batch(images)
+            return
+        yield from self.engine.detect_stream(batches)
 
     def __call__(self, image, score_threshold=0.1):
         """
@@ -97,10 +112,11 @@ class Detector:
         image = np.asarray(image)
         if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
             raise ValueError("image must be a uint8 array of shape [height, width, 3]")
-        boxes, labels, scores, n = self.detect_batch(np.expand_dims(image, 0))
-        n = n[0]  # inference/detector.py:54-58
-        to_keep = scores[0][:n] > score_threshold
-        boxes = boxes[0][:n][to_keep]
-        labels = labels[0][:n][to_keep]
-        scores = scores[0][:n][to_keep]
+        with self.engine.lock:      # the views below live in the engine's pinned result block until the next call
+            boxes, labels, scores, n = self._detect_views(image[None])
+            n = n[0]  # inference/detector.py:54-58
+            to_keep = scores[0][:n] > score_threshold
+            boxes = boxes[0][:n][to_keep]         # (boolean indexing copies)
+            labels = labels[0][:n][to_keep]
+            scores = scores[0][:n][to_keep]
         return boxes, labels, scores

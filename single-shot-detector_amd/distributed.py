@@ -42,21 +42,27 @@ def gather_records(rec, group=None):
     """ONE all-gather of the [B_local, 6T+1] int32 records -> [world*B_local, 6T+1], rank order."""
     world = dist.get_world_size(group)
     out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    # One-buffer form everywhere (RCCL has it, and so does this image's gloo); only a backend that says it does not
+    # implement it takes the list form.  Any other error is a real failure and propagates unchanged.
     try:
         dist.all_gather_into_tensor(out, rec, group=group)
-    except (RuntimeError, NotImplementedError):
+    except NotImplementedError:
         parts = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(parts, rec, group=group)
         out = torch.cat(parts, 0)
     return out
 
 
-def all_gather_detections(boxes, labels, scores, num, group=None, total=None):
+def all_gather_detections(boxes, labels, scores, num, group=None, total=None, force=False):
     """Every rank contributes the records of its B_local images and receives all records in
     rank order.  `total` = the global image count when the shards are uneven
     (shard_range(total, rank, world)): the records are padded to the largest shard for the ONE
-    all-gather (fixed-size operands) and the pad rows are dropped afterwards."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    all-gather (fixed-size operands) and the pad rows are dropped afterwards.
+    A group of one rank needs no exchange and returns its inputs; `force` runs the pack -> all-gather ->
+    unpack path even then (bench.py --force-dist: the collective path through RCCL on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return boxes, labels, scores, num
+    if dist.get_world_size(group) == 1 and not force:
         return boxes, labels, scores, num
     world = dist.get_world_size(group)
     rec = pack_detections(boxes, labels, scores, num)
@@ -72,8 +78,8 @@ def all_gather_detections(boxes, labels, scores, num, group=None, total=None):
     return unpack_detections(torch.cat(rows, 0))
 
 
-def detect_sharded(engine, images_local, group=None, total=None):
+def detect_sharded(engine, images_local, group=None, total=None, force=False):
     """One data-parallel step: this rank's shard through the HIP path, then the all-gather.
-    images_local: uint8 CUDA tensor [B_local,H,W,3]; `total`: see all_gather_detections."""
+    images_local: uint8 CUDA tensor [B_local,H,W,3]; `total`, `force`: see all_gather_detections."""
     boxes, labels, scores, num = engine.forward(images_local)
-    return all_gather_detections(boxes, labels, scores, num, group=group, total=total)
+    return all_gather_detections(boxes, labels, scores, num, group=group, total=total, force=force)

@@ -3,6 +3,7 @@ detector/utils/nms.py on top of libssd_hip.so.  Tensors are torch CUDA (= HIP) t
 torch only provides the memory and the stream.
 """
 import ctypes
+import threading
 
 import numpy as np
 
@@ -254,6 +255,8 @@ class Engine:
             raise
         self.T = int(params["num_classes"]) * int(params["max_boxes_per_class"])
         self._static = {}
+        self._copy_streams = None
+        self.lock = threading.RLock()       # serialises the calls on this engine (tf.Session.run is thread-safe)
 
     @property
     def precision(self):
@@ -261,13 +264,15 @@ class Engine:
         return {n: k for k, n in self.PRECISIONS.items()}[v]
 
     def set_precision(self, precision):
-        check(lib().ssd_set_precision(self._h, self.PRECISIONS[precision]))
+        with self.lock:
+            check(lib().ssd_set_precision(self._h, self.PRECISIONS[precision]))
 
     def status(self):
         """Synchronises; returns and clears the handle's status word (bit 0: an f16x3 activation
         left the fp16 range and was clamped -- re-run those forwards with precision "f32")."""
         v = ctypes.c_int32()
-        check(lib().ssd_status(self._h, ctypes.byref(v)))
+        with self.lock:
+            check(lib().ssd_status(self._h, ctypes.byref(v)))
         return v.value
 
     def close(self):
@@ -281,9 +286,17 @@ class Engine:
         except Exception:
             pass
 
+    def set_option(self, key, value):
+        """ssd_set_option on this engine's handle (include/ssd_hip.h lists the keys): a kernel / schedule selector that
+        does not change a result bit in mode f32.  Synchronises and drops the cached layer plan."""
+        with self.lock:
+            _lib.set_option(key, value, self._h)
+
     def forward(self, images, out=None):
         """images: uint8 CUDA tensor [B,H,W,3] -> (boxes [B,T,4], labels [B,T] i32,
-        scores [B,T], num_boxes [B] i32) CUDA tensors; asynchronous on the current stream."""
+        scores [B,T], num_boxes [B] i32) CUDA tensors; asynchronous on the current stream.
+        Thread-safe like tf.Session.run (inference/detector.py:34,52): calls on one engine are serialised (here and by the
+        handle's own mutex), and the library orders the GPU work of consecutive forwards even across streams."""
         torch = _torch()
         _check_dev(torch, images, torch.uint8, "images")
         if images.dim() != 4 or images.shape[3] != 3:
@@ -291,41 +304,142 @@ class Engine:
         B, H, W, _ = images.shape
         dev = images.device
         if out is None:
-            out = (torch.empty((B, self.T, 4), dtype=torch.float32, device=dev),
-                   torch.empty((B, self.T), dtype=torch.int32, device=dev),
-                   torch.empty((B, self.T), dtype=torch.float32, device=dev),
-                   torch.empty((B,), dtype=torch.int32, device=dev))
+            out = self._new_outputs(torch, B, dev)[1]
         boxes, labels, scores, num = out
-        check(lib().ssd_forward(self._h, _ptr(images), B, H, W, _ptr(boxes), _ptr(labels),
-                                _ptr(scores), _ptr(num), _stream(torch)))
+        with self.lock:
+            check(lib().ssd_forward(self._h, _ptr(images), B, H, W, _ptr(boxes), _ptr(labels),
+                                    _ptr(scores), _ptr(num), _stream(torch)))
         return boxes, labels, scores, num
+
+    def _new_outputs(self, torch, B, dev):
+        """The four graph outputs as views of ONE int32 device block [boxes B*T*4 | labels B*T | scores B*T | num B]:
+        one copy moves all of them to the host."""
+        T = self.T
+        block = torch.empty((B * (6 * T + 1),), dtype=torch.int32, device=dev)
+        boxes = block[:B * T * 4].view(torch.float32).view(B, T, 4)
+        labels = block[B * T * 4:B * T * 5].view(B, T)
+        scores = block[B * T * 5:B * T * 6].view(torch.float32).view(B, T)
+        num = block[B * T * 6:]
+        return block, (boxes, labels, scores, num)
+
+    def _split_host(self, blk, B):
+        """numpy views of a host copy of such a block."""
+        T = self.T
+        return (blk[:B * T * 4].view(np.float32).reshape(B, T, 4), blk[B * T * 4:B * T * 5].reshape(B, T),
+                blk[B * T * 5:B * T * 6].view(np.float32).reshape(B, T), blk[B * T * 6:])
+
+    def _slot(self, key, index=0):
+        """Persistent serving buffers of one input shape: device image, pinned host staging for the image, the packed
+        device outputs and their pinned host copy."""
+        torch = _torch()
+        slot = self._static.get((key, index))
+        if slot is None:
+            dev = "cuda:%d" % self.device
+            B = key[0]
+            block, views = self._new_outputs(torch, B, dev)
+            pin_in = torch.empty(key, dtype=torch.uint8).pin_memory()
+            pin_out = torch.empty(block.shape, dtype=torch.int32).pin_memory()
+            slot = {"dev_in": torch.empty(key, dtype=torch.uint8, device=dev), "pin_in": pin_in, "pin_in_np": pin_in.numpy(),
+                    "block": block, "views": views, "pin_out": pin_out, "host": self._split_host(pin_out.numpy(), B)}
+            while len(self._static) >= 8:
+                self._static.pop(next(iter(self._static)))
+            self._static[(key, index)] = slot
+        return slot
 
     def forward_cached(self, images):
         """Serving form of `forward`: `images` (uint8 numpy array or tensor [B,H,W,3]) is copied
         into a persistent device buffer and the outputs live in persistent buffers too, so every
-        call with the same shape presents the same pointers to ssd_forward and is replayed
-        as a hipGraph from the second repetition on.  The returned tensors are overwritten
-        by the next call: consume (e.g. `.cpu()`) before calling again."""
+        call with the same shape presents the same pointers to ssd_forward (a hipGraph replay with
+        option graph = 1).  The returned tensors are overwritten by the next call: consume (e.g.
+        `.cpu()`) before calling again."""
         torch = _torch()
         if isinstance(images, np.ndarray):
             images = torch.from_numpy(np.ascontiguousarray(images))
         if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[3] != 3:
             raise ValueError("images must be uint8 with shape [B,H,W,3]")
-        key = tuple(images.shape)
-        slot = self._static.get(key)
-        if slot is None:
-            dev = "cuda:%d" % self.device
-            B = key[0]
-            slot = (torch.empty(key, dtype=torch.uint8, device=dev),
-                    (torch.empty((B, self.T, 4), dtype=torch.float32, device=dev),
-                     torch.empty((B, self.T), dtype=torch.int32, device=dev),
-                     torch.empty((B, self.T), dtype=torch.float32, device=dev),
-                     torch.empty((B,), dtype=torch.int32, device=dev)))
-            if len(self._static) >= 4:
-                self._static.pop(next(iter(self._static)))
-            self._static[key] = slot
-        slot[0].copy_(images, non_blocking=True)
-        return self.forward(slot[0], out=slot[1])
+        with self.lock:
+            slot = self._slot(tuple(images.shape))
+            cur = torch.cuda.current_stream()
+            if slot.get("ev") is not None:      # another thread's stream may still be using these buffers
+                cur.wait_event(slot["ev"])
+            else:
+                slot["ev"] = torch.cuda.Event()
+            slot["dev_in"].copy_(images, non_blocking=True)
+            out = self.forward(slot["dev_in"], out=slot["views"])
+            slot["ev"].record(cur)
+            return out
+
+    def detect_host(self, images):
+        """The boundary's own form (inference/detector.py:51-52: a host ndarray in, numpy out on every call), at its best
+        case: host uint8 [B,H,W,3] -> pinned staging -> HBM, forward, ONE device-to-host copy of the packed outputs into
+        pinned memory, one stream synchronisation.  Returns numpy VIEWS of that pinned block (boxes, labels, scores,
+        num_boxes), valid until the next call with this shape: copy or reduce them before calling again."""
+        torch = _torch()
+        images = np.asarray(images)
+        if images.dtype != np.uint8 or images.ndim != 4 or images.shape[3] != 3:
+            raise ValueError("images must be a uint8 array of shape [B, height, width, 3]")
+        with self.lock:
+            slot = self._slot(tuple(images.shape))
+            np.copyto(slot["pin_in_np"], images)
+            slot["dev_in"].copy_(slot["pin_in"], non_blocking=True)
+            self.forward(slot["dev_in"], out=slot["views"])
+            slot["pin_out"].copy_(slot["block"], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return slot["host"]
+
+    def detect_stream(self, batches):
+        """Host-fed steady-state serving: an iterable of host uint8 arrays [B,H,W,3] -> a generator of (boxes, labels,
+        scores, num_boxes) numpy arrays, in order.  Two sets of buffers and two copy streams: the host-to-device copy of
+        batch k+1 and the device-to-host copy of the packed outputs of batch k-1 run under the compute of batch k, so the
+        host feed costs (almost) nothing against frames already resident in HBM.  Results are bit-identical to
+        detect_host on the same batches (same kernels, same order)."""
+        torch = _torch()
+        dev = torch.device("cuda", self.device)
+        if self._copy_streams is None:
+            self._copy_streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        s_in, s_out = self._copy_streams
+        s_c = torch.cuda.current_stream(dev)
+        ev = None
+        pending = None                       # (slot, B) of the batch whose outputs are still on their way
+        k = 0
+
+        def collect(p):
+            slot, B, e = p
+            e["d2h"].synchronize()
+            return tuple(np.array(v) for v in slot["host"])
+
+        for images in batches:
+            images = np.asarray(images)
+            if images.dtype != np.uint8 or images.ndim != 4 or images.shape[3] != 3:
+                raise ValueError("every batch must be a uint8 array of shape [B, height, width, 3]")
+            key = tuple(images.shape)
+            j = k & 1
+            slot = self._slot(key, index=1 + j)
+            e = slot.setdefault("events", None)
+            if e is None:
+                e = slot["events"] = {n: torch.cuda.Event() for n in ("h2d", "cmp", "d2h")}
+                for n in e:
+                    e[n].record(s_c)
+            e["h2d"].synchronize()           # the staging buffer's previous upload has left it
+            e["d2h"].synchronize()           # ... and the previous results of this slot have been collected below
+            np.copyto(slot["pin_in_np"], images)
+            with torch.cuda.stream(s_in):
+                s_in.wait_event(e["cmp"])    # the forward that read this device image two batches ago is over
+                slot["dev_in"].copy_(slot["pin_in"], non_blocking=True)
+                e["h2d"].record(s_in)
+            s_c.wait_event(e["h2d"])
+            self.forward(slot["dev_in"], out=slot["views"])
+            e["cmp"].record(s_c)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(e["cmp"])
+                slot["pin_out"].copy_(slot["block"], non_blocking=True)
+                e["d2h"].record(s_out)
+            if pending is not None:
+                yield collect(pending)
+            pending = (slot, key[0], e)
+            k += 1
+        if pending is not None:
+            yield collect(pending)
 
     def get_tensor(self, name):
         """Retained intermediate of the last forward as a numpy array [B,H,W,C]."""
@@ -333,8 +447,9 @@ class Engine:
         cap = 1 << 20
         while True:
             buf = np.empty((cap,), np.float32)
-            rc = lib().ssd_get_tensor(self._h, name.encode(),
-                                      buf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), cap, dims)
+            with self.lock:
+                rc = lib().ssd_get_tensor(self._h, name.encode(),
+                                          buf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), cap, dims)
             if rc != 0 and b"too small" in (lib().ssd_last_error() or b"") and cap < (1 << 34):
                 cap *= 8
                 continue
@@ -346,8 +461,9 @@ class Engine:
         torch = _torch()
         out = torch.empty(tuple(shape), dtype=torch.float32, device="cuda:%d" % self.device)
         dims = (ctypes.c_int32 * 4)()
-        check(lib().ssd_get_tensor_dev(self._h, name.encode(), _ptr(out), out.numel(), dims,
-                                       _stream(torch)))
+        with self.lock:
+            check(lib().ssd_get_tensor_dev(self._h, name.encode(), _ptr(out), out.numel(), dims,
+                                           _stream(torch)))
         return out
 
     # profiling (bench.py roofline leg)

@@ -38,6 +38,23 @@ def test_single_rank_needs_no_launcher():
     assert res["n_gpus"] == 1 and res["ranks_seen"] == [0] and res["config"]["global_batch"] == 2
 
 
+def test_force_dist_runs_the_collective_path_at_world_size_1():
+    """--force-dist (and WORLD_SIZE=1 from `torch.distributed.run --nproc-per-node 1`): process group, ranks_seen gather,
+    the all-gather of the detection records, the all-reduces and the final barrier all run with ONE rank."""
+    res = run(["--steps", "2", "--warmup", "1", "--batch", "3", "--force-dist"])
+    assert res["n_gpus"] == 1 and res["ranks_seen"] == [0] and res["collective_path"] is True
+    assert res["config"]["global_batch"] == 3 and res["config"]["shards"] == [[0, 3]]
+    plain = run(["--steps", "2", "--warmup", "1", "--batch", "3"])
+    assert plain["collective_path"] is False
+
+
+def test_arguments_that_would_leave_a_rank_without_images_are_refused():
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, STUB, "--gpus", "2", "--global-batch", "1"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "empty shard" in r.stderr
+
+
 def test_bench_refuses_without_gpu():
     # the product bench has no CPU path: without a HIP device it must stop, not fall back
     import torch

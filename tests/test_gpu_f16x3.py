@@ -22,14 +22,14 @@ CONV_TOL = 2e-5     # one convolution, relative to max(1, max |ref|)
 
 @pytest.mark.parametrize("tile", ["128", "64", "256"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
-def test_conv2d_f16x3(cuda, ssd, oracle_ops, case, tile, monkeypatch):
+def test_conv2d_f16x3(cuda, ssd, oracle_ops, case, tile, libopt):
     # "256": the one-block-per-CU 256x256-tile kernel (igemm16.hip) wherever its form applies (batch norm,
     # output width a multiple of 256); the library otherwise keeps it for launches with >= 512 tiles
     if tile == "256":
-        monkeypatch.setenv("SSD_IGEMM16", "1")
+        libopt(igemm16=1)
     else:
-        monkeypatch.setenv("SSD_IGEMM16", "0")
-        monkeypatch.setenv("SSD_IGEMM_TILE", tile)
+        libopt(igemm16=0)
+        libopt(igemm_tile=int(tile, 0))
     B, H, W, Cin, Cout, k, stride, mode, use_bn, use_bias, act, use_up = case
     rng = np.random.default_rng(100 + CONV_CASES.index(case))
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
@@ -64,10 +64,10 @@ def test_conv2d_f16x3(cuda, ssd, oracle_ops, case, tile, monkeypatch):
 
 @pytest.mark.parametrize("shape", [(3, 40, 56, 256, 256, 3, 1), (2, 20, 28, 1024, 256, 3, 2), (1, 80, 112, 256, 512, 1, 1),
                                    (5, 17, 13, 96, 256, 1, 1)])
-def test_conv2d_f16x3_large_tiles(cuda, ssd, oracle_ops, shape, monkeypatch):
+def test_conv2d_f16x3_large_tiles(cuda, ssd, oracle_ops, shape, libopt):
     """igemm16.hip on shapes with several 256-row tiles, ragged last tiles, two column tiles, the
     explicit-pad stride-2 form (fpn p6) and the shortest K loop it accepts (3 K-steps)."""
-    monkeypatch.setenv("SSD_IGEMM16", "1")
+    libopt(igemm16=1)
     B, H, W, Cin, Cout, k, stride = shape
     rng = np.random.default_rng(sum(shape))
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
@@ -301,17 +301,16 @@ def _same_within_tolerance(a, b, what):
 
 @pytest.mark.parametrize("backbone,B,H,W,env", [
     ("mobilenet", 40, 256, 384, {}),                       # 40 images: the 256x256-tile kernel carries towers, p3 and logits
-    ("mobilenet", 40, 256, 384, {"SSD_IGEMM16": "0"}),     # the same on the 128x128 kernel's S16 path
-    ("mobilenet", 5, 256, 128, {"SSD_NSUB": "3"}),         # staggered sub-batch plans
+    ("mobilenet", 40, 256, 384, {"igemm16": 0}),     # the same on the 128x128 kernel's S16 path
+    ("mobilenet", 5, 256, 128, {"nsub": 3}),         # staggered sub-batch plans
     ("mobilenet", 2, 300, 500, {}),                        # resize_keeping_aspect_ratio path (min_dimension 256)
-    ("mobilenet", 1, 256, 256, {"SSD_GRAPH": "1"}),        # hipGraph replay of the two-stream forward
-    ("mobilenet", 8, 256, 256, {"SSD_GRAPH": "1"}),        # ... with the backbone as two chains and the memsets captured
-    ("mobilenet", 8, 256, 256, {"SSD_BACKBONE_SPLIT": "4"}),   # four backbone chains on four streams
+    ("mobilenet", 1, 256, 256, {"graph": 1}),        # hipGraph replay of the two-stream forward
+    ("mobilenet", 8, 256, 256, {"graph": 1}),        # ... with the backbone as two chains and the memsets captured
+    ("mobilenet", 8, 256, 256, {"backbone_split": 4}),   # four backbone chains on four streams
     ("shufflenet", 6, 256, 256, {}),
 ])
-def test_f16x3_against_f32_engine(cuda, ssd, monkeypatch, backbone, B, H, W, env):
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+def test_f16x3_against_f32_engine(cuda, ssd, libopt, backbone, B, H, W, env):
+    libopt(**env)
     params = {"backbone": backbone, "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
               "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 256}
     Wt = ssd.synthetic_weights(params, seed=17, logits_bias=-6.0)
@@ -321,7 +320,7 @@ def test_f16x3_against_f32_engine(cuda, ssd, monkeypatch, backbone, B, H, W, env
     e32.close()
     e16 = ssd.Engine(params, Wt, precision="f16x3")
     out = None
-    for rep in range(3 if env.get("SSD_GRAPH") else 1):    # graph capture happens at the second repetition
+    for rep in range(3 if env.get("graph") else 1):    # graph capture happens at the second repetition
         out = [t.cpu().numpy() for t in e16.forward_cached(img)]
     assert e16.status() == 0
     assert ref[3].sum() > 0
@@ -329,11 +328,11 @@ def test_f16x3_against_f32_engine(cuda, ssd, monkeypatch, backbone, B, H, W, env
     e16.close()
 
 
-def test_igemm16_repeatable(cuda, ssd, monkeypatch):
+def test_igemm16_repeatable(cuda, ssd, libopt):
     """Race screen for the LDS-DMA pipeline of igemm16.hip (the DMA of a stage is ordered for its readers only
     by the issuing wave's vmcnt wait plus a barrier): the same launch repeated must give the same bits, on a
     shape with many 256-row tiles per CU so that blocks start and finish at different phases."""
-    monkeypatch.setenv("SSD_IGEMM16", "1")
+    libopt(igemm16=1)
     rng = np.random.default_rng(77)
     x = dev(cuda, rng.standard_normal((24, 40, 56, 256)).astype(np.float32))
     w = (rng.standard_normal((3, 3, 256, 256)) * np.sqrt(2.0 / 2304)).astype(np.float32)
@@ -405,9 +404,9 @@ def test_f16x3_batch_independence_full_size(cuda, ssd):
     eng.close()
 
 
-def test_igemm16_overflow_is_reported(cuda, ssd, monkeypatch):
+def test_igemm16_overflow_is_reported(cuda, ssd, libopt):
     """The 256x256-tile kernel's own range check (a running maximum instead of per-value clamps)."""
-    monkeypatch.setenv("SSD_IGEMM16", "1")
+    libopt(igemm16=1)
     x = cuda.full((1, 8, 8, 256), 100.0, dtype=cuda.float32, device="cuda")
     w = np.full((1, 1, 256, 256), 1.0, np.float32)                    # sums of 25 600
     ones, zeros = np.ones(256, np.float32), np.zeros(256, np.float32)

@@ -101,10 +101,10 @@ def test_forward_other_widths_and_class_counts(cuda, ssd, oracle_graph, backbone
     eng.close()
 
 
-def test_coarse_levels_as_their_own_launches(cuda, ssd, oracle_graph, monkeypatch):
-    """SSD_LEVEL_SPLIT=1 (a batch-1 latency experiment that measured slower and is off by default): the
+def test_coarse_levels_as_their_own_launches(cuda, ssd, oracle_graph, libopt):
+    """option level_split = 1 (a batch-1 latency experiment that measured slower and is off by default): the
     head towers of levels 6-7 run as separate launches on the third / fourth stream.  Same bits."""
-    monkeypatch.setenv("SSD_LEVEL_SPLIT", "1")
+    libopt(level_split=1)
     params = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
               "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
     Wt = ssd.synthetic_weights(params, seed=12, logits_bias=-4.0)
@@ -118,10 +118,10 @@ def test_coarse_levels_as_their_own_launches(cuda, ssd, oracle_graph, monkeypatc
     eng.close()
 
 
-def test_sub_batch_plans(cuda, ssd, oracle_graph, monkeypatch):
-    """SSD_NSUB splits a batch into staggered sub-batch plans (uneven split 5 = 2+2+1): same
+def test_sub_batch_plans(cuda, ssd, oracle_graph, libopt):
+    """option nsub splits a batch into staggered sub-batch plans (uneven split 5 = 2+2+1): same
     results, same retained tensors."""
-    monkeypatch.setenv("SSD_NSUB", "3")
+    libopt(nsub=3)
     params = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
               "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
     Wt = ssd.synthetic_weights(params, seed=12, logits_bias=-4.0)
@@ -205,8 +205,8 @@ def test_detector_drop_in(cuda, ssd, oracle_graph, tmp_path):
 
 
 @pytest.mark.parametrize("cfg", ["config_mobilenet.json", "config_shufflenet.json"])
-def test_fused_depthwise_pointwise_plan(cuda, ssd, monkeypatch, cfg):
-    # SSD_FUSE_DW picks the blocks that run as one dw+pw launch (MobileNet: bit i = Conv2d_{i+1};
+def test_fused_depthwise_pointwise_plan(cuda, ssd, libopt, cfg):
+    # option fuse_dw picks the blocks that run as one dw+pw launch (MobileNet: bit i = Conv2d_{i+1};
     # ShuffleNet: non-zero = every unit): any choice gives the same bits
     params = ssd.load_config(os.path.join(HERE, "golden", cfg))
     Wt = ssd.synthetic_weights(params, seed=11, logits_bias=-4.0)
@@ -214,7 +214,7 @@ def test_fused_depthwise_pointwise_plan(cuda, ssd, monkeypatch, cfg):
     img = cuda.from_numpy(rng.integers(0, 256, (2, 256, 384, 3), dtype=np.uint8)).cuda()
     outs = []
     for mask in ("0", "0x1fff", "0x15"):
-        monkeypatch.setenv("SSD_FUSE_DW", mask)
+        libopt(fuse_dw=int(mask, 0))
         eng = ssd.Engine(params, Wt)
         o = [t.cpu().numpy() for t in eng.forward(img)]
         outs.append(o + [eng.get_tensor("c3"), eng.get_tensor("c4"), eng.get_tensor("c5")])
@@ -223,10 +223,10 @@ def test_fused_depthwise_pointwise_plan(cuda, ssd, monkeypatch, cfg):
             assert np.array_equal(a, b)
 
 
-def test_graph_replay(cuda, ssd, monkeypatch):
-    """SSD_GRAPH=1: the serving path (persistent buffers) is captured into a hipGraph at its
+def test_graph_replay(cuda, ssd, libopt):
+    """option graph = 1: the serving path (persistent buffers) is captured into a hipGraph at its
     second repetition and replayed; results stay identical to the eager forward."""
-    monkeypatch.setenv("SSD_GRAPH", "1")
+    libopt(graph=1)
     params = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
               "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
     Wt = ssd.synthetic_weights(params, seed=21, logits_bias=-4.0)

@@ -151,10 +151,10 @@ def test_f16x3_lateral_input_overflow_is_reported(cuda, ssd):
     eng.close()
 
 
-def test_f16x3_nan_is_reported_by_the_large_tile_kernel(cuda, ssd, monkeypatch):
+def test_f16x3_nan_is_reported_by_the_large_tile_kernel(cuda, ssd, libopt):
     """igemm16's range check is a running fmax, which drops NaN operands; a NaN result must still fail
     loudly (batch-norm beta = NaN, no activation: the value reaches the S16 store as NaN or as -inf after the clamps)."""
-    monkeypatch.setenv("SSD_IGEMM16", "1")
+    libopt(igemm16=1)
     x = cuda.ones((1, 8, 8, 256), dtype=cuda.float32, device="cuda")
     w = np.full((1, 1, 256, 256), 0.01, np.float32)
     ones, zeros = np.ones(256, np.float32), np.zeros(256, np.float32)
@@ -162,6 +162,6 @@ def test_f16x3_nan_is_reported_by_the_large_tile_kernel(cuda, ssd, monkeypatch):
     beta[7] = np.nan
     with pytest.raises(ssd.SsdError, match="fp16 range"):
         ssd.ssd.conv2d(x, w, 1, "SAME", bn=(zeros, ones, beta), act=None, precision="f16x3")
-    monkeypatch.setenv("SSD_IGEMM16", "0")          # the 128x128 kernel's S16 epilogue
+    libopt(igemm16=0)          # the 128x128 kernel's S16 epilogue
     with pytest.raises(ssd.SsdError, match="fp16 range"):
         ssd.ssd.conv2d(x, w, 1, "SAME", bn=(zeros, ones, beta), act=None, precision="f16x3")

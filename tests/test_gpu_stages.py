@@ -59,12 +59,14 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", ["128", "64"])
+@pytest.mark.parametrize("tile", ["128", "64", "20", "21", "22", "23"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
-def test_conv2d(cuda, ssd, oracle_ops, case, tile, monkeypatch):
+def test_conv2d(cuda, ssd, oracle_ops, case, tile, libopt):
     # the library picks 64x64 tiles for small problems and 128x128 for large ones: pin each
-    # in turn so both kernels see every shape (narrow outputs keep their 128x64 / 128x32 tiles)
-    monkeypatch.setenv("SSD_IGEMM_TILE", tile)
+    # in turn so both kernels see every shape (narrow outputs keep their 128x64 / 128x32 tiles);
+    # 20 .. 23: the four wave tiles of the latency form (igemm_lat.hip, v_mfma_f32_16x16x4_f32), which
+    # takes every case whose output rows are 16-byte aligned -- the same bits from all of them
+    libopt(igemm_tile=int(tile, 0))
     B, H, W, Cin, Cout, k, stride, mode, use_bn, use_bias, act, use_up = case
     rng = np.random.default_rng(100 + CONV_CASES.index(case))
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
@@ -96,7 +98,7 @@ def test_conv2d(cuda, ssd, oracle_ops, case, tile, monkeypatch):
 
 @pytest.mark.parametrize("act", ["relu", "relu6"])
 @pytest.mark.parametrize("shape", [(2, 20, 28, 64, 128, 3), (1, 12, 12, 64, 64, 1)])
-def test_conv2d_nan_inf(cuda, ssd, oracle_ops, shape, act):
+def test_conv2d_nan_inf(cuda, ssd, oracle_ops, shape, act, libopt):
     """Non-finite inputs through the batch-norm + activation epilogues (the wide-tile form clamps with v_med3_f32, the
     others with two selects): a NaN must come out as 0, +inf as the upper bound, exactly as the oracle's act_apply
     (`v > 0 ? v : 0`, then `v < 6 ? v : 6`) produces them."""
@@ -111,21 +113,18 @@ def test_conv2d_nan_inf(cuda, ssd, oracle_ops, shape, act):
     with np.errstate(all="ignore"):
         ref = oracle_ops.bn_act(oracle_ops.conv2d(x, w, 1, "SAME"), g, b, m, v, act)
     assert not np.isnan(ref).any() and (ref == 0).any()      # (ReLU keeps +inf; ReLU6 turns it into 6)
-    for tile in ("128", "64"):
-        os.environ["SSD_IGEMM_TILE"] = tile
-        try:
-            got = ssd.ssd.conv2d(dev(cuda, x), w, 1, "SAME", bn=(m, oracle_ops.bn_scale(g, v), b), act=act).cpu().numpy()
-        finally:
-            del os.environ["SSD_IGEMM_TILE"]
-        assert np.array_equal(got, ref), "tile %s: %d of %d values differ" % (tile, int((got != ref).sum()), ref.size)
+    for tile in (128, 64, 20, 23):
+        libopt(igemm_tile=tile)
+        got = ssd.ssd.conv2d(dev(cuda, x), w, 1, "SAME", bn=(m, oracle_ops.bn_scale(g, v), b), act=act).cpu().numpy()
+        assert np.array_equal(got, ref), "tile %d: %d of %d values differ" % (tile, int((got != ref).sum()), ref.size)
 
 
 @pytest.mark.parametrize("cout", [96, 192, 480])
 @pytest.mark.parametrize("use96", ["0", "1"])
-def test_conv2d_96_wide_tiles(cuda, ssd, oracle_ops, cout, use96, monkeypatch):
+def test_conv2d_96_wide_tiles(cuda, ssd, oracle_ops, cout, use96, libopt):
     # output widths that 96 divides and 128 does not (class logits 480, ShuffleNet 96/192) run on
-    # 128x96 tiles; SSD_IGEMM_96=0 keeps the zero-padded 128-wide tiles.  Same bits either way.
-    monkeypatch.setenv("SSD_IGEMM_96", use96)
+    # 128x96 tiles; option igemm_96 = 0 keeps the zero-padded 128-wide tiles.  Same bits either way.
+    libopt(igemm_96=int(use96, 0))
     rng = np.random.default_rng(cout)
     x = rng.standard_normal((2, 19, 23, 64)).astype(np.float32)
     w = (rng.standard_normal((3, 3, 64, cout)) * np.sqrt(2.0 / (9 * 64))).astype(np.float32)
@@ -368,7 +367,7 @@ def test_postprocess_fuzz(cuda, ssd, oracle_ops, seed):
     run_post(cuda, ssd, oracle_ops, codes, logits, anc, thr=thr, iou=iou, m=m, scaler=scaler)
 
 
-def test_postprocess_long_lists(cuda, ssd, oracle_ops, monkeypatch):
+def test_postprocess_long_lists(cuda, ssd, oracle_ops, libopt):
     """Candidate lists longer than the one-wave path: > 512 (block kernel, registers) and > 8192 (block kernel, keys in
     global memory); and the block kernel forced on shorter lists."""
     rng = np.random.default_rng(7)
@@ -382,9 +381,9 @@ def test_postprocess_long_lists(cuda, ssd, oracle_ops, monkeypatch):
     logits[1, 20000:45000, 42] = rng.uniform(-1.5, 4.0, 25000).astype(np.float32)  # n > 8192
     logits[1, :, 3] = 5.0                                                          # every anchor, all ties
     run_post(cuda, ssd, oracle_ops, codes, logits, anc)
-    monkeypatch.setenv("SSD_NMS_FAST_MAX", "200")          # a lower hand-over point: same results
+    libopt(nms_fast_max=200)          # a lower hand-over point: same results
     run_post(cuda, ssd, oracle_ops, codes, logits, anc)
-    monkeypatch.setenv("SSD_NMS_FAST_MAX", "0")
+    libopt(nms_fast_max=0)
     codes, logits = synth_heads(rng, 2, N, 80, frac=0.002)
     codes *= 0.3
     run_post(cuda, ssd, oracle_ops, codes, logits, anc)

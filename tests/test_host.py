@@ -117,6 +117,33 @@ def test_abi_exports_every_declared_symbol(ssd):
         assert switch not in blob, switch
 
 
+def test_library_reads_one_environment_variable_and_options_go_through_the_abi(ssd):
+    """The shipped library's configuration surface: SSD_PRECISION is the only environment variable it reads; every kernel /
+    schedule selector is an ssd_set_option key (process-wide with a NULL handle, no GPU needed for that)."""
+    csrc = os.path.join(ROOT, "single-shot-detector_amd", "csrc")
+    n = 0
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            src = open(os.path.join(csrc, f)).read()
+            src = re.sub(r"#ifdef SSD_DIAG.*?#e(?:lse|ndif)", "", src, flags=re.S)     # diagnostics build only
+            n += len(re.findall(r"\bgetenv\s*\(", src))
+    assert n == 1, n
+    blob = open(ssd.lib_path(), "rb").read()
+    for gone in (b"SSD_IGEMM_TILE", b"SSD_IGEMM16", b"SSD_NSUB", b"SSD_FUSE_DW", b"SSD_GRAPH", b"SSD_NMS_FAST_MAX", b"SSD_DEBUG_SYNC",
+                 b"SSD_LEVEL_SPLIT", b"SSD_BACKBONE_SPLIT", b"SSD_LATERAL_SPLIT", b"SSD_IGEMM_96"):
+        assert gone not in blob, gone
+    unset = -2 ** 31
+    for key in ("igemm_tile", "igemm_lat", "igemm_deep64", "streams", "igemm16", "igemm_96", "lateral_split", "backbone_split", "nsub", "level_split",
+                "nms_fast_max", "fuse_dw", "graph", "debug_sync"):
+        assert ssd.get_option(key) == unset
+        ssd.set_option(key, 3)
+        assert ssd.get_option(key) == 3
+        ssd.set_option(key, unset)
+        assert ssd.get_option(key) == unset
+    with pytest.raises(ssd.SsdError, match="unknown option"):
+        ssd.set_option("no_such_switch", 1)
+
+
 def test_anchors_host_side(ssd, oracle_ops):
     """ssd_anchors is host arithmetic (no GPU needed): identical to the oracle's table."""
     for H, W in [(640, 896), (640, 640), (128, 128), (256, 384)]:
