@@ -1,11 +1,13 @@
 #!/bin/bash
-# Run ON THE GPU BOX (through gpurun): the round's bench line, the rocprofv3 kernel-trace
-# summary of the same command, and separate PMC passes (HBM traffic, MFMA busy) for it.
+# Run ON THE GPU BOX (through gpurun): the bench line of the command WITHOUT a profiler (bench.json -- the clean
+# measurement), the rocprofv3 kernel-trace summary of the same command (bench_traced.json is the line printed UNDER the
+# profiler: perturbed, for cross-checking kernel names only) and separate PMC passes (HBM traffic, MFMA busy) for it.
 #   usage: BENCH_ARGS="..." bash scripts/collect_profiles.sh <tag>      outputs under gpurun_out/<tag>/
 R=$GRAFT_REPO_ROOT; TAG=${1:-r01}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 # BENCH_ARGS selects what the traced / counted runs measure, e.g. "--no-other-precision --no-shufflenet" (mode f32 of the
 # headline workload alone) or "--config shufflenet --no-other-precision" (BASELINE config 4 alone)
+python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-latency $BENCH_ARGS > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-latency $BENCH_ARGS > $OUT/bench_traced.json 2> $OUT/trace.err
 i=0

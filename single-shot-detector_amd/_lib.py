@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SOURCES = ["abi.hip", "weights.hip", "plan.hip", "stages.hip", "igemm.hip", "igemm_lat.hip", "igemm16.hip", "dwpw_stream.hip",
+_SOURCES = ["abi.hip", "weights.hip", "plan.hip", "stages.hip", "igemm.hip", "igemm_lat.hip", "igemm_s.hip", "igemm16.hip", "dwpw_stream.hip",
             "elementwise.hip", "postprocess.hip"]
 _LIB_PATH = os.path.join(_CSRC, "libssd_hip.so")
 _DIAG_PATH = os.path.join(_CSRC, "libssd_hip_diag.so")       # -DSSD_DIAG build, scripts/ only
@@ -33,7 +33,7 @@ def build(force=False, verbose=False, diag=False):
     the same sources with -DSSD_DIAG (ablation kernels, tile overrides, phase stamps, ssd_bench_*;
     include/ssd_hip_diag.h) for scripts/ -- never loaded by the product."""
     srcs = [os.path.join(_CSRC, s) for s in _SOURCES]
-    deps = srcs + [os.path.join(_CSRC, "ssd_internal.h"), os.path.join(_CSRC, "host.h"),
+    deps = srcs + [os.path.join(_CSRC, "ssd_internal.h"), os.path.join(_CSRC, "host.h"), os.path.join(_CSRC, "igemm_mfma16.h"),
                    os.path.join(_HERE, "..", "include", "ssd_hip.h"),
                    os.path.join(_HERE, "..", "include", "ssd_hip_diag.h")]
     target = _DIAG_PATH if diag else _LIB_PATH
@@ -179,7 +179,19 @@ def lib():
     Raises if impossible: there is no fallback."""
     global _lib
     if _lib is None:
-        path = build(diag=_diag)
+        target = _DIAG_PATH if _diag else _LIB_PATH
+        try:
+            path = build(diag=_diag)
+        except (FileNotFoundError, subprocess.CalledProcessError, OSError) as e:
+            # a deployment that ships the package with a prebuilt library and no sources / headers / hipcc: its
+            # freshness cannot be checked -- load it and say so; only a missing library is fatal
+            if not os.path.exists(target):
+                raise RuntimeError("single-shot-detector_amd: %s is missing and cannot be built here (%r); there is no "
+                                   "fallback" % (os.path.basename(target), e)) from e
+            import warnings
+            warnings.warn("single-shot-detector_amd: loading the existing %s without a freshness check (%r)"
+                          % (os.path.basename(target), e))
+            path = target
         _lib = ctypes.CDLL(path)
         sigs = dict(SIGNATURES, **DIAG_SIGNATURES) if _diag else SIGNATURES
         for name, (res, args) in sigs.items():

@@ -94,7 +94,13 @@ __global__ __launch_bounds__(256, (STRIDE == 1 && WN == 1) ? 3 : 2) void dwpw_st
     for (int k = 0; k < KP; ++k) {
         const int slot = (wave + 4 * k) * 8 + (lane >> 3);
         const bool ok = wave + 4 * k < NPI && slot < NSLOT;
-        const int r = slot / PW, c = slot - r * PW;
+        // Stride 2: a patch row is kept de-interleaved in LDS -- its even columns first (9 of them), then the odd ones.  The
+        // depthwise phase reads columns 2 tx + kx for eight tx at once: in patch order all eight pixels have the same parity
+        // of their 128-byte slot index, i.e. they share one half of the 256-byte bank row, and a 16-lane group of a
+        // ds_read_b128 (4 pixels x 4 chunks) hits every bank twice (SQ_LDS_BANK_CONFLICT = 20 % of the LDS cycles,
+        // profiles/r02_f32_pmc_summary.txt).  De-interleaved, consecutive tx alternate between the halves: conflict-free.
+        const int r = slot / PW, lc = slot - r * PW;             // lc: position inside the LDS row, c: patch column
+        const int c = STRIDE == 2 ? (lc < (PW + 1) / 2 ? 2 * lc : 2 * (lc - (PW + 1) / 2) + 1) : lc;
         pr[k] = ok ? r : (1 << 20);                  // a row that fails every bounds check
         pc[k] = c;
         prel[k] = ((r * W + c) * K + (lane & 7) * 4) * 4;
@@ -196,6 +202,7 @@ __global__ __launch_bounds__(256, (STRIDE == 1 && WN == 1) ? 3 : 2) void dwpw_st
     const int c4 = lane & 7, tx = lane >> 3;
     const int ty0 = STRIDE == 1 ? wave * 2 : wave;
     constexpr int NOUT = STRIDE == 1 ? 2 : 1;        // outputs per thread (vertically adjacent: shared patch rows)
+    auto pcol = [](int col) { return STRIDE == 2 ? ((col & 1) ? (PW + 1) / 2 + (col >> 1) : (col >> 1)) : col; };   // LDS position of a patch column
     constexpr int NROW = STRIDE == 1 ? 4 : 3;
     // epilogue position of this lane: accumulator column lane & 31 = tile row wave_m * 32 + (lane & 31) = (ty, tx)
     const int ety = wave_m * 4 + ((lane & 31) >> 3), etx = lane & 7, eh = lane >> 5;
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(256, (STRIDE == 1 && WN == 1) ? 3 : 2) void dwpw_st
             for (int rr = 0; rr < NROW; ++rr)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
-                    x[rr][kx] = *(const v4f *)(pb_ + ((ty0 * STRIDE + rr) * PW + tx * STRIDE + kx) * 128);
+                    x[rr][kx] = *(const v4f *)(pb_ + ((ty0 * STRIDE + rr) * PW + pcol(tx * STRIDE + kx)) * 128);
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) {
                 v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -375,12 +382,11 @@ static hipError_t launch_s(const DwPwSArgs &a, hipStream_t s)
     constexpr int NPI = (((TY - 1) * STRIDE + 3) * ((TX - 1) * STRIDE + 3) + 7) / 8;
     constexpr int lds_bytes = 2 * NPI * 1024 + 2048 + TY * TX * 128 + 2 * BN * 128 + BN * 16;
     constexpr int PER_CU = (STRIDE == 1 && WN == 1) ? 3 : 2;        // resident blocks per CU (LDS)
-    static bool attr_set = false;
+    static std::atomic<unsigned> attr_done{0};
     auto k = dwpw_stream_kernel<STRIDE, WN, OMAP>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    {
+        hipError_t e = ssd_allow_lds((const void *)k, lds_bytes, attr_done);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
 #ifdef SSD_DIAG
     {

@@ -166,7 +166,12 @@ __global__ __launch_bounds__(256) void first_conv_px_kernel(const uint8_t *__res
     const long long total = (long long)B * OH * OW;
     const float inv255 = (float)(1.0 / 255.0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rowf = Cout + FC_ROWPAD;
+    // 32 channels (MobileNet): rows of exactly 128 B with the 16-byte chunk c of pixel p at slot c ^ (p & 7) -- both the
+    // writes (8 consecutive lanes = 8 pixels, same chunk) and the reads (a 16-lane group = chunk halves of 4 pixels) are
+    // conflict-free; the padded rows of the general case cost the ds_read_b128 of the write-out two banks' worth of overlap
+    // per group (SQ_LDS_BANK_CONFLICT 25 % of this kernel's LDS cycles, profiles/r02_f32_pmc_summary.txt).
+    constexpr bool SWZ = COUT == 32;
+    const int rowf = SWZ ? 32 : Cout + FC_ROWPAD;
     float *reg = fc_tr + (size_t)wave * 64 * rowf;
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, (int)((long long)B * H * W * 3), 0x00020000);
     const long long nwave = (long long)gridDim.x * 4;
@@ -228,7 +233,10 @@ __global__ __launch_bounds__(256) void first_conv_px_kernel(const uint8_t *__res
                 acc[i] = act_apply(acc[i], act);
             }
 #pragma unroll
-            for (int i = 0; i < CH; i += 4) *(v4f *)(reg + lane * rowf + ch + i) = (v4f){acc[i], acc[i + 1], acc[i + 2], acc[i + 3]};
+            for (int i = 0; i < CH; i += 4) {
+                const int c = SWZ ? ((((ch + i) >> 2) ^ (lane & 7)) << 2) : ch + i;
+                *(v4f *)(reg + lane * rowf + c) = (v4f){acc[i], acc[i + 1], acc[i + 2], acc[i + 3]};
+            }
         }
         // the wave's rows -> 64 * Cout * 4 consecutive bytes of the output, 16 B per lane and instruction (wave-private LDS
         // region: the wave's own ds_writes are ordered before its ds_reads by the counter wait the compiler places)
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256) void first_conv_px_kernel(const uint8_t *__res
         float *obase = out + wbase * Cout;
         for (int q = lane; q < 64 * LP; q += 64) {
             const int p = q / LP, c4 = q - p * LP;
-            const v4f v = *(const v4f *)(reg + p * rowf + c4 * 4);
+            const v4f v = *(const v4f *)(reg + p * rowf + (SWZ ? ((c4 ^ (p & 7)) << 2) : c4 * 4));
             if (q < nlive) *(v4f *)(obase + (long long)q * 4) = v;
         }
     }
@@ -258,13 +266,21 @@ hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int 
         const long long px = (long long)B * (H / 2) * (W / 2);
         blocks = (px + 255) / 256;
         if (blocks > 256 * 32) blocks = 256 * 32;
-        const size_t lds = (size_t)256 * (Cout + FC_ROWPAD) * sizeof(float);
+        const size_t lds = (size_t)256 * (Cout == 32 ? 32 : Cout + FC_ROWPAD) * sizeof(float);
         if (Cout == 32)        // MobileNet-v1 at depth multiplier 1
             hipLaunchKernelGGL(first_conv_px_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, s, img, B, H, W, w, Cout, mean, sf, beta, act, out);
         else if (Cout == 24)   // ShuffleNet-v2
             hipLaunchKernelGGL(first_conv_px_kernel<24>, dim3((unsigned)blocks), dim3(256), lds, s, img, B, H, W, w, Cout, mean, sf, beta, act, out);
-        else
+        else {
+            // wider first layers (depth multiplier 2: 64 channels = 68 KB, up to 128 = 135 KB): above the 64 KB a kernel gets
+            // without asking, so ask -- per device
+            static std::atomic<unsigned> attr_done{0};
+            if (lds > 65536) {
+                hipError_t e = ssd_allow_lds((const void *)first_conv_px_kernel<0>, (int)lds, attr_done);
+                if (e != hipSuccess) return e;
+            }
             hipLaunchKernelGGL(first_conv_px_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, s, img, B, H, W, w, Cout, mean, sf, beta, act, out);
+        }
     } else if (srcH == nh && nh == H && srcW == nw && nw == W)
         hipLaunchKernelGGL(first_conv_kernel<true>, dim3((unsigned)blocks), dim3(256), 27 * Cout * sizeof(float), s, img, B,
                            srcH, srcW, nh, nw, H, W, hs, ws, w, Cout, mean, sf, beta, act, out);

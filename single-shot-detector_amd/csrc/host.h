@@ -47,6 +47,9 @@ enum SsdOpt {
     OPT_IGEMM_LAT,          // 1 (default) | 0: tiny exact-fp32 launches on the latency form (igemm_lat.hip)
     OPT_IGEMM_DEEP64,       // -1 auto | 0 | 1: 64x64 tiles with loads three K-steps ahead
     OPT_STREAMS,            // 0 auto | 1: every op of a plan on one stream (measurement aid)
+    OPT_FPN_GROUP,          // -1 auto | 0 | 1: fpn p3 + p4 + p5 as one grouped launch (exact fp32)
+    OPT_HEAD_SERIAL,        // -1 auto | 0 | 1: the box head behind the class logits on one stream instead of beside them
+    OPT_IGEMM_SMALL,        // 1 (default) | 0: 32x32 tiles on v_mfma_f32_16x16x4_f32 for mid-size batch-1 launches (igemm_s.hip)
     OPT_COUNT
 };
 #define SSD_OPT_UNSET INT_MIN
@@ -146,6 +149,7 @@ struct LevelDesc {
     long long in_off, out_off, out_bstride;
     int out_rstride, param_off;
     long long res_off;
+    long long wt_off = 0;           // float offset of this level's kernel inside the ConvW (grouped launches; 0 = shared)
 };
 
 // in_fmt / out_fmt / res_fmt: 0 fp32 rows, 1 split-fp16 rows (ssd_internal.h); flags: the handle's status word
@@ -213,6 +217,7 @@ struct ssd_handle {
     std::vector<DwW> dw;                // depthwise layers in execution order
     std::vector<ConvW> pw;              // backbone pointwise layers in execution order
     ConvW lat[3], pconv[5];             // fpn lateral3..5, p3..p7
+    ConvW pgroup;                       // fpn p3 | p4 | p5 kernels and batch norms behind one pointer each: one grouped launch at batch 1
     ConvW tower[2][4], final_[2];       // [box, class]
     std::vector<int *> tabs;            // shufflenet gather tables (device)
     int c_ch[3] = {0, 0, 0};            // logical channels of c3, c4, c5

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(a.in + L.in_off), 0, (int)((long long)a.B * H * W * Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)a.wt, 0, (int)((long long)TAPS * a.CoutPad * Cin * 4), 0x00020000);
+        (void *)(a.wt + L.wt_off), 0, (int)((long long)TAPS * a.CoutPad * Cin * 4), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     // Per row: byte offset of its tap (0,0) (used only where that tap exists) and 9 bits "tap t reads inside the image"; the
     // offset of tap t is then one wave-uniform displacement away.  (A tap change used to redo the coordinate arithmetic
@@ -747,12 +747,11 @@ static hipError_t launch_tt(const IgemmArgs &a, int total_tiles_m, hipStream_t s
 {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
     constexpr int lds_bytes = 2 * (BM + BN) * 128;
-    static bool attr_set = false;
+    static std::atomic<unsigned> attr_done{0};
     auto k = igemm_kernel<WAVES_M, WAVES_N, WM, WN, TAPS, DBG, S16>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    {
+        hipError_t e = ssd_allow_lds((const void *)k, lds_bytes, attr_done);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const long long nblk = (long long)total_tiles_m * a.n_tiles_n;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;

@@ -451,12 +451,11 @@ template <int TAPS, int DBG = 0>
 static hipError_t launch16_t(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 {
     constexpr int lds_bytes = 2 * (256 + 256) * 128;
-    static bool attr_set = false;
+    static std::atomic<unsigned> attr_done{0};
     auto k = igemm16_kernel<TAPS, DBG>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    {
+        hipError_t e = ssd_allow_lds((const void *)k, lds_bytes, attr_done);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const long long nblk = (long long)total_tiles_m * a.n_tiles_n;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;

@@ -93,6 +93,7 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
         L.out_rstride = lv[i].out_rstride;
         L.in_off = lv[i].in_off; L.out_off = lv[i].out_off; L.out_bstride = lv[i].out_bstride;
         L.res_off = lv[i].res_off;
+        L.wt_off = lv[i].wt_off;
         rows += L.M;
         inb += (double)B * L.H * L.W * cw.Cin_l * 4.0;
     }
@@ -104,16 +105,28 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
     // its own operands in fragment shape, ~70 cycles per 1-KB load instruction, and only a launch of at most one or two
     // waves per CU keeps that under its MFMA chain.  Option igemm_lat = 0 switches the form off, igemm_tile = 20 .. 23
     // pins a wave tile wherever the form applies (tests run every shape on all four).
-    if (igemm_is_lat(tile)) {            // (diagnostics: ssd_bench_conv asked for this wave tile)
-        if (!igemm_lat_supports(a)) tile = IGEMM_128x128;
+    if (igemm_is_lat(tile) || igemm_is_s(tile)) {            // (diagnostics: ssd_bench_conv asked for this tile)
+        if (!igemm_lat_supports(a) || cw.CoutPad % (igemm_is_s(tile) ? igemm_s_bn(tile) : igemm_lat_bn(tile))) tile = IGEMM_128x128;
     } else if (tile != IGEMM16_TILE && g_force_tile < 0 && igemm_lat_supports(a)) {
         const int pin = ssd_opt(h, OPT_IGEMM_TILE, 0);
-        if (igemm_is_lat(pin)) tile = pin;
+        if ((igemm_is_lat(pin) && cw.CoutPad % igemm_lat_bn(pin) == 0) || (igemm_is_s(pin) && cw.CoutPad % igemm_s_bn(pin) == 0)) tile = pin;
         else if (pin == 0 && ssd_opt(h, OPT_IGEMM_LAT, 1)) {
             long long waves = 0;
             for (size_t i = 0; i < lv.size(); ++i) waves += (((long long)a.lv[i].M + 15) / 16) * (cw.CoutPad / 16);
             if (waves <= 320) tile = IGEMM_LAT_1x1;
         }
+    }
+    // 1x1 convolutions of at most ~1.2 64x64 tiles per CU, and 3x3 ones of a few dozen (batch 1: Conv2d_6 .. 11 pointwise,
+    // lateral5; fpn p5 at batch 2): 32x32 tiles on v_mfma_f32_16x16x4_f32 (igemm_s.hip).  A 64x64 tile's K loop cannot be
+    // shorter than 1 024 cycles per K-step and 280 tiles leave 24 CUs with two of them; the same work in 1 120 tiles of a
+    // quarter of the chain splits evenly.  Alone on the chip (profiles/r03_conv_small_tiles.log): 512 -> 512 at 40x56
+    // 22 -> 19 us, 256 -> 512 14 -> 12, lateral5 20 -> 12, p5 39 -> 23 us; equal for the 144-tile and the 560-tile layers, slower
+    // for p4 (42 -> 46): those stay.  Same bits.
+    if (tile == IGEMM_64x64 && !in_fmt && g_force_tile < 0 && igemm_lat_supports(a) && ssd_opt(h, OPT_IGEMM_TILE, 0) == 0 &&
+        ssd_opt(h, OPT_IGEMM_SMALL, 1) && cw.CoutPad % 32 == 0) {
+        long long b64 = 0;
+        for (size_t i = 0; i < lv.size(); ++i) b64 += (((long long)a.lv[i].M + 63) / 64) * (cw.CoutPad / 64);
+        if ((cw.taps == 1 && (b64 <= 40 || (b64 >= 200 && b64 <= 300))) || (cw.taps == 9 && b64 <= 40)) tile = IGEMM_S_32x32;
     }
     // 64x64 tiles of a launch that leaves the chip mostly empty (at most ~2.5 blocks per CU: the FPN and pointwise layers of
     // a batch-1 forward): the instance with two register sets, loads three K-steps ahead.  In the network these launches'
@@ -127,11 +140,11 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
         if (pin >= 0) deep = pin != 0;
         if (deep) tile = IGEMM_64x64D;
     }
-    const bool lat = igemm_is_lat(tile);
-    a.n_tiles_n = a.CoutPad / (tile == IGEMM16_TILE ? 256 : (lat ? igemm_lat_bn(tile) : igemm_tile_bn(tile)));
+    const bool lat = igemm_is_lat(tile), sml = igemm_is_s(tile);
+    a.n_tiles_n = a.CoutPad / (tile == IGEMM16_TILE ? 256 : (lat ? igemm_lat_bn(tile) : (sml ? igemm_s_bn(tile) : igemm_tile_bn(tile))));
     a.dN = ssd_udiv_make((unsigned)a.n_tiles_n);
     int tiles = 0;
-    const int BM = tile == IGEMM16_TILE ? 256 : (lat ? igemm_lat_bm(tile) : igemm_tile_bm(tile));
+    const int BM = tile == IGEMM16_TILE ? 256 : (lat ? igemm_lat_bm(tile) : (sml ? igemm_s_bm(tile) : igemm_tile_bm(tile)));
     for (size_t i = 0; i < lv.size(); ++i) {
         a.lv[i].tile_begin = tiles;
         tiles += (a.lv[i].M + BM - 1) / BM;
@@ -142,6 +155,7 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
     op.bytes = inb + rows * cw.Cout_l * 4.0 + (double)cw.taps * cw.Cin_l * cw.Cout_l * 4.0;
     op.run = [a, tile, tiles](hipStream_t s) {
         if (tile == IGEMM16_TILE) return launch_igemm16(a, tiles, s);
+        if (igemm_is_s(tile)) return launch_igemm_s(tile, a, tiles, s);
         return igemm_is_lat(tile) ? launch_igemm_lat(tile, a, tiles, s) : launch_igemm(tile, a, tiles, s);
     };
     return op;
@@ -251,6 +265,7 @@ LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long in_off,
     d.out_rstride = CoutP;
     d.param_off = param_off;
     d.res_off = res_off;
+    d.wt_off = 0;
     return d;
 }
 
@@ -590,7 +605,20 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         d7.out_off = py.off[4];
         id_p7 = push(make_conv_op(h, h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true, X16, X16, 0, FL), s6);
     }
-    {   // p5 = conv(x5)
+    // Batch 1 in exact fp32: p3, p4 and p5 (the same 3x3 256 -> 256 + batch norm + ReLU on x3, x4, x5) as ONE launch behind
+    // lateral3, each level with its own kernel (IgemmLevel::wt_off into h->pgroup) and batch norm.  Measured, one stream
+    // (profiles/r03_batch1_timeline_single_stream.txt): p3 105 us (560 tiles of 64x64: 2.2 per CU), p4 38, p5 38 us alone;
+    // beside each other on three streams they stretched to 129 / 73 / 61 us and the towers started 266 us after c5.  The
+    // grouped launch is 736 tiles -- a tower-sized launch, ~108 us -- and nothing else competes with the lateral chain.
+    // Option fpn_group = 0 / 1 pins it.
+    bool grouped = false;
+    if (!X16 && h->pgroup.wt) {
+        const long long b64 = (((long long)B * py.h[0] * py.w[0] + 63) / 64) * (256 / 64);
+        grouped = b64 <= 640;
+        const int pin = ssd_opt(h, OPT_FPN_GROUP, -1);
+        if (pin >= 0) grouped = pin != 0;
+    }
+    if (!grouped) {   // p5 = conv(x5)
         LevelDesc d = lvl(2, 256);
         d.out_off = py.off[2];
         push(make_conv_op(h, h->pconv[2], X5, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 1, {id_l5});
@@ -603,16 +631,30 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     if (!ssd_opt(h, OPT_LATERAL_SPLIT, 1)) LF = 0;       // A/B runs: 0 keeps them on the exact MFMA
     const int id_l4 = push(make_conv_op(h, h->lat[1], C4, X4, nullptr, X5, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true, LF, X16, X16, FL), 0);
     int id_p4, id_p3;
-    {
+    if (!grouped) {
         LevelDesc d = lvl(1, 256);
         d.out_off = py.off[1];
         id_p4 = push(make_conv_op(h, h->pconv[1], X4, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 1, {id_l4});
     }
     push(make_conv_op(h, h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true, LF, X16, X16, FL), 0);
-    {
+    if (!grouped) {
         LevelDesc d = lvl(0, 256);
         d.out_off = py.off[0];
         id_p3 = push(make_conv_op(h, h->pconv[0], X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 0);
+        pl.ops[id_p3].fpn_end = true;
+    } else {
+        const ConvW &g = h->pgroup;
+        const float *xin[3] = {X3, X4, X5};
+        std::vector<LevelDesc> lv3;
+        for (int l = 0; l < 3; ++l) {
+            LevelDesc d = lvl(l, 256);
+            d.in_off = xin[l] - X3;                         // the three inputs are separate allocations: offsets from x3
+            d.out_off = py.off[l];
+            d.param_off = l * g.CoutP;
+            d.wt_off = (long long)l * g.taps * g.CoutPad * g.CinP;
+            lv3.push_back(d);
+        }
+        id_p3 = id_p4 = push(make_conv_op(h, g, X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv3, true), 0);
         pl.ops[id_p3].fpn_end = true;
     }
     for (int l = 0; l < 5; ++l) {
@@ -701,11 +743,23 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     // second stream (and, unless the coarse levels run apart, p6, p7 from the third); the first class-tower layer (second
     // stream) needs p3 from the main stream (and p6, p7).  Coarse-level chains: box on the third stream (behind p7, same
     // stream), class on the fourth (waits for p7).
+    // Option head_serial = 1: the box head (24 of 32 columns, 1.3 GFLOP) BEHIND the class logits on the second stream instead
+    // of beside them.  Batch 1, alone: logits 203 us, box head 41 us; side by side 293 / 168 us when the class tower finishes
+    // first -- but when the box tower does, the box head runs beside the class tower's last layer and the logits run alone:
+    // measured on one box, serial 1 823 us per forward, side by side 1 782 us (profiles/r03_batch1_timeline_*.txt).  Off.
+    bool head_serial = false;
+    { const int pin = ssd_opt(h, OPT_HEAD_SERIAL, -1); if (pin >= 0) head_serial = pin != 0 && !split_levels; }
+    int id_box_last = -1;
     for (size_t i = 0; i < tower_ops[0][0].size(); ++i)
         for (int t = 1; t >= 0; --t) {
             std::vector<int> deps;
             if (i == 0) { deps.push_back(t == 0 ? id_p4 : id_p3); if (!split_levels) deps.push_back(id_p7); }
-            push(tower_ops[t][0][i], t, deps);
+            if (head_serial && t == 0 && i + 1 == tower_ops[0][0].size()) {
+                push(tower_ops[0][0][i], 1, {id_box_last});          // behind the logits (pushed just before), after the box tower
+                continue;
+            }
+            const int id = push(tower_ops[t][0][i], t, deps);
+            if (t == 0) id_box_last = id;
             if (split_levels) {
                 std::vector<int> d2;
                 if (i == 0) d2.push_back(id_p7);

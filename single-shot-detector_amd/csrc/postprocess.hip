@@ -76,110 +76,141 @@ __device__ __forceinline__ bool iou_greater(const v4f bi, const v4f bj, float th
     return valid & (iou > thr);
 }
 
-// One candidate (logit above the conservative bound): exact score, strict threshold,
-// append to its (image, class) list, decode the anchor's box.
-__device__ __forceinline__ void emit_candidate(const PostArgs &p, unsigned elem, float logit)
-{
-    const float s = sigmoid_cr(logit);
-    if (!(s > p.score_thr)) return;
-    const int c = (int)(elem % (unsigned)p.C);
-    const unsigned row = elem / (unsigned)p.C;
-    const int i = (int)(row % (unsigned)p.N), b = (int)(row / (unsigned)p.N);
-    const int slot = atomicAdd(&p.counts[b * p.C + c], 1);
-    p.keys[((long long)b * p.C + c) * p.N + slot] = ((u64)__float_as_uint(s) << 32) | (u64)(0xFFFFFFFFu - (unsigned)i);
-    const v4f code = *(const v4f *)(p.codes + ((long long)b * p.N + i) * 4);
-    const v4f anc = *(const v4f *)(p.anchors + (long long)i * 4);
-    *(v4f *)(p.dec + ((long long)b * p.N + i) * 4) = decode_clip(code, anc);
-}
-
-// K9a.  The scan itself is a pure HBM stream; the rare logits above the bound are pushed
-// into a per-block LDS queue and the queue is drained DENSELY by all 256 threads (the
-// double-precision sigmoid / exp and the atomics would otherwise run with one active lane
-// per wave).  The element index fits 32 bits (host check: B*N*C < 2^32).
-#define SCAN_U 4                       // 16-B loads in flight per thread
+// K9a.  Candidates = (anchor, class) pairs with score > threshold.  A logit below a conservative bound is skipped without
+// evaluating the sigmoid; the survivors are queued in LDS and drained DENSELY by all 256 threads (the double-precision
+// sigmoid / exp would otherwise run with one active lane per wave).  The element index fits 32 bits (host check).
+//
+// Drain with block-aggregated list appends: untrained or real, the scores of a frame concentrate on a few classes (bench
+// frames: 4 085 and 1 246 of 6 503 candidates in two of 80 classes), and one returning global atomic per candidate on the
+// class counter serialised there -- the scan took 52 us at batch 1 whatever its loads did.  Now every candidate takes its
+// slot from an LDS counter of its (image, class), one thread per used counter reserves the block's range with ONE global
+// atomic, and the candidates write at base + slot.  The list ORDER was and stays unspecified (the NMS is an arg-max).
+#define SCAN_U 4                       // 16-B loads in flight per thread (plain path)
 #define SCAN_Q (2048 + 256 * SCAN_U * 4)
+#define SCAN_TAB 1024                  // LDS counters: (images spanned by a pass) x C must fit, else direct global atomics
+#define SCAN_OQ 4096                   // fused path: marked octets of a pass of 128 bitmap words
 __global__ __launch_bounds__(256) void post_scan_kernel(const PostArgs p)
 {
-    __shared__ unsigned q_elem[SCAN_Q > 8192 ? SCAN_Q : 8192];      // fused path: the octet queue of a pass (256 words x 32 octets)
+    __shared__ unsigned q_elem[SCAN_Q];
     __shared__ float q_val[SCAN_Q];
-    __shared__ unsigned q_cand[4096];                               // fused path: element index of a queued candidate
-    __shared__ int q_n;
+    __shared__ unsigned q_slot[SCAN_Q];
+    __shared__ unsigned oq[SCAN_OQ];
+    __shared__ int tab_cnt[SCAN_TAB], tab_base[SCAN_TAB];
+    __shared__ int q_n, oq_n;
     const int C = p.C;
+    const unsigned NC = (unsigned)p.N * (unsigned)C;
     const bool vec = (C & 3) == 0;
     const long long total = vec ? (long long)p.B * p.N * (C >> 2) : (long long)p.B * p.N * C;
     if (threadIdx.x == 0) q_n = 0;
     __syncthreads();
-    auto drain = [&]() {
-        const int n = q_n;
-        for (int t = threadIdx.x; t < n; t += 256) emit_candidate(p, q_elem[t], q_val[t]);
-        __syncthreads();
-        if (threadIdx.x == 0) q_n = 0;
-        __syncthreads();
-    };
     auto push = [&](unsigned elem, float v) {
         const int slot = atomicAdd(&q_n, 1);
         q_elem[slot] = elem;
         q_val[slot] = v;
     };
-    auto push_c = [&](unsigned elem, float v) {
-        const int slot = atomicAdd(&q_n, 1);
-        q_cand[slot] = elem;
-        q_val[slot] = v;
-    };
-    auto drain_c = [&]() {
+    // e_lo / e_hi: first and last element index the queued candidates can have
+    auto drain = [&](unsigned e_lo, unsigned e_hi) {
         const int n = q_n;
-        for (int t = threadIdx.x; t < n; t += 256) emit_candidate(p, q_cand[t], q_val[t]);
+        if (n == 0) return;                                             // block-uniform
+        const int b_first = (int)(e_lo / NC), nb = (int)(e_hi / NC) - b_first + 1;
+        const int ntab = nb * C;
+        const bool agg = ntab <= SCAN_TAB;
+        if (agg) {
+            for (int t = threadIdx.x; t < ntab; t += 256) tab_cnt[t] = 0;
+            __syncthreads();
+        }
+        for (int t = threadIdx.x; t < n; t += 256) {
+            const unsigned elem = q_elem[t];
+            const float sc = sigmoid_cr(q_val[t]);
+            unsigned tag = 0xFFFFFFFFu;
+            if (sc > p.score_thr) {
+                const int c = (int)(elem % (unsigned)C);
+                const int b = (int)(elem / NC);
+                if (agg) {
+                    const int hidx = (b - b_first) * C + c;
+                    tag = ((unsigned)hidx << 16) | (unsigned)atomicAdd(&tab_cnt[hidx], 1);
+                } else {
+                    tag = (unsigned)atomicAdd(&p.counts[b * C + c], 1);     // slot in the global list, directly
+                }
+            }
+            q_slot[t] = tag;
+            q_val[t] = sc;
+        }
+        __syncthreads();
+        if (agg) {
+            for (int t = threadIdx.x; t < ntab; t += 256) {
+                const int cnt = tab_cnt[t];
+                if (cnt) tab_base[t] = atomicAdd(&p.counts[b_first * C + t], cnt);
+            }
+            __syncthreads();
+        }
+        for (int t = threadIdx.x; t < n; t += 256) {
+            const unsigned tag = q_slot[t];
+            if (tag == 0xFFFFFFFFu) continue;
+            const unsigned elem = q_elem[t];
+            const int c = (int)(elem % (unsigned)C);
+            const unsigned row = elem / (unsigned)C;
+            const int i = (int)(row % (unsigned)p.N), b = (int)(row / (unsigned)p.N);
+            const int slot = agg ? tab_base[tag >> 16] + (int)(tag & 0xFFFFu) : (int)tag;
+            p.keys[((long long)b * C + c) * p.N + slot] = ((u64)__float_as_uint(q_val[t]) << 32) | (u64)(0xFFFFFFFFu - (unsigned)i);
+            const v4f code = *(const v4f *)(p.codes + ((long long)b * p.N + i) * 4);
+            const v4f anc = *(const v4f *)(p.anchors + (long long)i * 4);
+            *(v4f *)(p.dec + ((long long)b * p.N + i) * 4) = decode_clip(code, anc);
+        }
         __syncthreads();
         if (threadIdx.x == 0) q_n = 0;
         __syncthreads();
     };
     if (p.scan_fused) {
         // The logits convolution marked the octets that hold a candidate (igemm.hip / igemm16.hip / igemm_lat.hip epilogues):
-        // read the bitmap (B*N*C/64 bytes) and the marked octets only.  Same filter, same emit_candidate: the per-class
-        // lists hold the same set.  Three dense phases per 256 bitmap words: (1) every thread queues the marked octets of
-        // its word, (2) the octet queue is read densely, 512 octets at a time -- all logit loads of a pass in flight
-        // together -- and the values above the bound go to the candidate queue, (3) dense drain.  (The first form walked
-        // one marked octet per thread and round with two block-wide votes per round: a chain of dependent loads as long
-        // as the busiest thread's word; batch 1: 52 us.)  The words are cleared on the way: the bitmap is clean again for
-        // the next forward's logits convolution without a memset.
-        unsigned *oq = q_elem;                               // octet queue: at most 256 * 32 entries; candidates go to q_val / q_cand
-        __shared__ int oq_n;
+        // read the bitmap (B*N*C/64 bytes) and the marked octets only.  Same filter, same candidates.  Dense phases per pass
+        // of 128 bitmap words: (1) every thread queues the marked octets of its word, (2) the octet queue is read densely,
+        // 256 octets at a time -- all logit loads of a round in flight together -- and the values above the bound go to the
+        // candidate queue, (3) drain.  The words are cleared on the way: the bitmap is clean again for the next forward's
+        // logits convolution without a memset.
         const long long nwords = ((long long)p.B * p.N * C / 8 + 31) / 32;
-        for (long long w0 = (long long)blockIdx.x * 256; w0 < nwords; w0 += (long long)gridDim.x * 256) {
-            const long long w = w0 + threadIdx.x;
+        for (long long w0 = (long long)blockIdx.x * 128; w0 < nwords; w0 += (long long)gridDim.x * 128) {
             if (threadIdx.x == 0) oq_n = 0;
             __syncthreads();
-            unsigned bits = w < nwords ? p.scan_bits[w] : 0u;
+            const long long w = w0 + threadIdx.x;
+            unsigned bits = (threadIdx.x < 128 && w < nwords) ? p.scan_bits[w] : 0u;
             if (bits) {
                 p.scan_bits[w] = 0u;
-                const int base = atomicAdd(&oq_n, __builtin_popcount(bits));
-                int k = 0;
+                int k = atomicAdd(&oq_n, __builtin_popcount(bits));
                 while (bits) {
                     const int bpos = __builtin_ctz(bits);
                     bits &= bits - 1;
-                    oq[base + k++] = (unsigned)((w - w0) * 32 + bpos);          // octet index relative to this pass
+                    oq[k++] = (unsigned)(threadIdx.x * 32 + bpos);      // octet index relative to this pass
                 }
             }
             __syncthreads();
             const int no = oq_n;
-            for (int o0 = 0; o0 < no; o0 += 512) {                              // <= 512 * 8 candidates per pass: fits the queue
-                for (int t = o0 + threadIdx.x; t < no && t < o0 + 512; t += 256) {
+            const long long last = (w0 + 128) * 256 - 1, tot_e = (long long)p.B * NC - 1;
+            const unsigned e_lo = (unsigned)(w0 * 256), e_hi = (unsigned)(last < tot_e ? last : tot_e);
+            for (int o0 = 0; o0 < no; o0 += 256) {                      // <= 256 * 8 candidates per round
+                const int t = o0 + threadIdx.x;
+                if (t < no) {
                     const long long e0 = (w0 * 32 + oq[t]) * 8;
                     const v4f x0 = *(const v4f *)(p.logits + e0), x1 = *(const v4f *)(p.logits + e0 + 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (x0[j] >= p.logit_lo) push_c((unsigned)(e0 + j), x0[j]);
-                        if (x1[j] >= p.logit_lo) push_c((unsigned)(e0 + 4 + j), x1[j]);
+                        if (x0[j] >= p.logit_lo) push((unsigned)(e0 + j), x0[j]);
+                        if (x1[j] >= p.logit_lo) push((unsigned)(e0 + 4 + j), x1[j]);
                     }
                 }
-                __syncthreads();
-                drain_c();
+                // the decision must be block-uniform AND separated by a barrier from the next round's pushes (a fast wave's
+                // atomicAdd on q_n could otherwise flip it for a slow wave: divergent barriers inside drain)
+                const bool full = __syncthreads_or(q_n > 2048);
+                if (full || o0 + 256 >= no) drain(e_lo, e_hi);
             }
         }
         return;
     }
     const long long stride = (long long)gridDim.x * 256 * SCAN_U;
+    const long long per = vec ? 4 : 1;                                  // elements per unit
+    unsigned e_lo = 0xFFFFFFFFu;                                        // first element of the oldest undrained iteration
     for (long long base = (long long)blockIdx.x * 256 * SCAN_U; base < total; base += stride) {
+        if (e_lo == 0xFFFFFFFFu) e_lo = (unsigned)(base * per);
         if (vec) {
             v4f x[SCAN_U];
 #pragma unroll
@@ -207,11 +238,13 @@ __global__ __launch_bounds__(256) void post_scan_kernel(const PostArgs p)
                 }
             }
         }
-        // the decision must be block-uniform AND separated by a barrier from the next iteration's pushes (a fast
-        // wave's atomicAdd on q_n could otherwise flip it for a slow wave: divergent __syncthreads in drain)
-        if (__syncthreads_or(q_n > 2048)) drain();
+        // the decision must be block-uniform AND separated by a barrier from the next iteration's pushes
+        const long long endu = base + 256 * SCAN_U < total ? base + 256 * SCAN_U : total;
+        if (__syncthreads_or(q_n > 2048)) { drain(e_lo, (unsigned)(endu * per - 1)); e_lo = 0xFFFFFFFFu; }
     }
-    drain();
+    // the queue may still hold candidates of iterations since the last drain: their elements lie between e_lo and the end
+    __syncthreads();
+    if (q_n > 0) drain(e_lo == 0xFFFFFFFFu ? 0u : e_lo, (unsigned)(total * per - 1));
 }
 
 __device__ __forceinline__ u64 wave_max_u64(u64 v)
@@ -304,45 +337,20 @@ __device__ __forceinline__ int nms_one_wave(const PostArgs &p, const u64 *keys, 
     return kept;
 }
 
-// K9c, one block of NMS_MID threads per (image, class) pair.
-//   n <= fast_max (64 * NMS_R)      wave 0 alone, everything in registers, no barrier (the other waves leave at once)
-//   n <= mid_max (NMS_MID * NMS_R)  the block's four waves, NMS_R candidates per thread, one barrier per round: each wave's
-//                                   lane 0 posts (wave best, its box) in LDS, every thread takes the block's best and box
-//                                   from there (double-buffered by round parity)
-//   longer                          onto the work list of post_nms_big_kernel
-// (Measured and not adopted, round 2: ONE wave with 32 candidates per lane for lists of 513 .. 2 048 -- 0.22 -> 0.28 ms:
-//  32 IoU tests per lane and round.  Four waves keep 8 per lane; the 1 024-thread kernel they replace for these lengths
-//  paid a 16-wave barrier and a global box load per round: batch-1 post-processing 96 us for two or three such lists.)
-__global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
+// Greedy NMS of one list by a block of NT threads, NMS_R candidates per thread in registers, one barrier per round: each
+// wave's lane 0 posts (wave best, its box) in LDS, every thread takes the block's best and its box from there
+// (double-buffered by round parity).  Returns the number of boxes kept (block-uniform).
+template <int NT>
+__device__ __forceinline__ int nms_block(const PostArgs &p, const u64 *keys, const float *dec, int n, int tid, float *ob, float *os,
+                                         u64 (*wbest)[NT / 64], v4f (*wbox)[NT / 64])
 {
-    __shared__ u64 wbest[2][NMS_MID / 64];
-    __shared__ v4f wbox[2][NMS_MID / 64];
-    const int bc = blockIdx.x;              // b*C + c
-    const int b = bc / p.C;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int n = p.counts[bc];
-    if (n > p.N) n = p.N;
-    if (n > p.mid_max) {                    // handled by post_nms_big_kernel: put the pair on its work list
-        if (tid == 0) p.big_list[atomicAdd(p.big_n, 1)] = bc;
-        return;
-    }
-    const u64 *keys = p.keys + (long long)bc * p.N;
-    const float *dec = p.dec + (long long)b * p.N * 4;
-    float *ob = p.cls_boxes + (long long)bc * p.max_per_class * 4;
-    float *os = p.cls_scores + (long long)bc * p.max_per_class;
-    if (n <= p.fast_max) {                  // block-uniform
-        if (wave != 0) return;
-        int kept = 0;
-        if (n > 0) kept = nms_one_wave<NMS_R>(p, keys, dec, n, lane, ob, os);
-        if (lane == 0) p.cls_counts[bc] = kept;
-        return;
-    }
+    const int lane = tid & 63, wave = tid >> 6;
     u64 key[NMS_R];
     v4f box[NMS_R];
     unsigned alive = 0;
 #pragma unroll
     for (int r = 0; r < NMS_R; ++r) {
-        const int i = tid + NMS_MID * r;
+        const int i = tid + NT * r;
         const bool ok = i < n;
         key[r] = ok ? keys[ok ? i : 0] : 0ull;
         const unsigned anchor = 0xFFFFFFFFu - (unsigned)(key[r] & 0xFFFFFFFFu);
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
         v4f wb = wbox[buf][0];
         best = wbest[buf][0];
 #pragma unroll
-        for (int w = 1; w < NMS_MID / 64; ++w) {
+        for (int w = 1; w < NT / 64; ++w) {
             const u64 o = wbest[buf][w];
             const v4f ov = wbox[buf][w];
             const bool gt = o > best;
@@ -389,10 +397,135 @@ __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
         }
         alive &= ~kill;
     }
+    return kept;
+}
+
+// K9c, one block of NMS_MID threads per (image, class) pair.
+//   n <= fast_max (64 * NMS_R)      wave 0 alone, everything in registers, no barrier (the other waves leave at once)
+//   n <= mid_max (NMS_MID * NMS_R)  the block's four waves (nms_block)
+//   longer                          onto the work list of post_nms_big_kernel
+// (Measured and not adopted, round 2: ONE wave with 32 candidates per lane for lists of 513 .. 2 048 -- 0.22 -> 0.28 ms:
+//  32 IoU tests per lane and round.  Four waves keep 8 per lane.)
+__global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
+{
+    __shared__ u64 wbest[2][NMS_MID / 64];
+    __shared__ v4f wbox[2][NMS_MID / 64];
+    const int bc = blockIdx.x;              // b*C + c
+    const int b = bc / p.C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int n = p.counts[bc];
+    if (n > p.N) n = p.N;
+    if (n > p.mid_max && p.fast_max < 64 * NMS_R) {    // a lowered hand-over point (tests): straight onto the work list of the
+        if (tid == 0) p.big_list[atomicAdd(p.big_n, 1)] = bc;    // 1 024-thread kernels, no trial here
+        return;
+    }
+    const u64 *keys = p.keys + (long long)bc * p.N;
+    const float *dec = p.dec + (long long)b * p.N * 4;
+    float *ob = p.cls_boxes + (long long)bc * p.max_per_class * 4;
+    float *os = p.cls_scores + (long long)bc * p.max_per_class;
+    if (n <= p.fast_max) {                  // block-uniform
+        if (wave != 0) return;
+        int kept = 0;
+        if (n > 0) kept = nms_one_wave<NMS_R>(p, keys, dec, n, lane, ob, os);
+        if (lane == 0) p.cls_counts[bc] = kept;
+        return;
+    }
+    // A long list: greedy NMS consumes candidates in descending score order and stops at max_per_class kept boxes, so first
+    // try the TOP scores alone -- a score histogram picks the largest score cut that leaves at most 64 * NMS_R candidates,
+    // those are compacted into LDS and wave 0 runs the one-wave rounds on them.  If that keeps max_per_class boxes the result
+    // is exactly the full list's (every candidate below the cut has a strictly smaller key than every one above it, and the
+    // greedy order never reached them); otherwise -- massive ties or massive suppression -- the full list is processed below.
+    // (Bench frames: ONE class holds 4 085 of a frame's 6 503 candidates; on the 1 024-thread in-register kernel its 25 rounds
+    //  took 98 us -- 8 IoU tests x 16 waves on one CU per round -- and decided the post-processing's time.)
+    {
+        constexpr int TCAP = 64 * NMS_R, NBIN = 2048;
+        __shared__ unsigned hist[NBIN];
+        __shared__ u64 chunk[TCAP];
+        __shared__ int chunk_n, cut_bin, trial_kept;
+        const unsigned lo_bits = __float_as_uint(p.score_thr > 0.0f ? p.score_thr : 0.0f);
+        int shift = 0;
+        while (((0x3F800000u - lo_bits) >> shift) >= (unsigned)NBIN) ++shift;
+        for (int i = tid; i < NBIN; i += NMS_MID) hist[i] = 0;
+        if (tid == 0) { chunk_n = 0; trial_kept = -1; }
+        __syncthreads();
+        for (int i = tid; i < n; i += NMS_MID) atomicAdd(&hist[((unsigned)(keys[i] >> 32) - lo_bits) >> shift], 1u);
+        __syncthreads();
+        // cut_bin = the smallest bin whose suffix count (candidates in bins >= it) is still <= TCAP.  Wave 0, lane l owns
+        // bins 32 l .. 32 l + 31: lane totals, a suffix scan over the lanes, and the one lane whose range holds the cut walks
+        // its 32 bins.  (One thread walking the histogram down from the top took 85 us: scores crowd just above the
+        // threshold, so the walk covered nearly all 2 048 bins, a dependent LDS read each.)
+        if (wave == 0) {
+            static_assert(NBIN == 64 * 32, "one lane per 32 bins");
+            unsigned mine = 0;
+            for (int k = 0; k < 32; ++k) mine += hist[lane * 32 + k];
+            unsigned above = mine;                              // becomes the count in bins >= 32 * lane
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_down(above, off, 64);
+                above += (lane + off < 64) ? o : 0u;
+            }
+            const unsigned higher = above - mine;               // count in bins >= 32 * (lane + 1)
+            if (lane == 0) cut_bin = above <= (unsigned)TCAP ? 0 : NBIN;
+            if (higher <= (unsigned)TCAP && above > (unsigned)TCAP) {      // exactly one lane, unless every bin fits (cut 0, set above)
+                unsigned cum = higher;
+                int bin = lane * 32 + 32;
+                while (bin > lane * 32 && cum + hist[bin - 1] <= (unsigned)TCAP) { cum += hist[bin - 1]; --bin; }
+                cut_bin = bin;
+            }
+        }
+        __syncthreads();
+        const int cb = cut_bin;
+        for (int i = tid; i < n; i += NMS_MID) {
+            const u64 k = keys[i];
+            if ((int)(((unsigned)(k >> 32) - lo_bits) >> shift) >= cb) chunk[atomicAdd(&chunk_n, 1)] = k;
+        }
+        __syncthreads();
+        const int nn = chunk_n;
+        if (nn >= p.max_per_class && cb > 0) {          // (fewer than the cap can never fill it; cb == 0: the cut kept everything)
+            if (wave == 0) {
+                const int kept = nms_one_wave<NMS_R>(p, chunk, dec, nn, lane, ob, os);
+                if (lane == 0) trial_kept = kept;
+            }
+            __syncthreads();
+            if (trial_kept >= p.max_per_class) {        // block-uniform
+                if (tid == 0) p.cls_counts[bc] = trial_kept;
+                return;
+            }
+        }
+    }
+    if (n > p.mid_max) {                    // too long for this block's registers: post_nms_regs_kernel / post_nms_big_kernel
+        if (tid == 0) p.big_list[atomicAdd(p.big_n, 1)] = bc;
+        return;
+    }
+    const int kept = nms_block<NMS_MID>(p, keys, dec, n, tid, ob, os, wbest, wbox);
     if (tid == 0) p.cls_counts[bc] = kept;
 }
 
-// K9c, longer lists: 1024 threads per (image, class).  Up to 1024*NMS_R candidates live in
+// K9c, lists of NMS_MID * NMS_R < n <= NMS_BIG * NMS_R candidates (the work list post_nms_kernel filled): 1 024 threads, the
+// same in-register rounds (nms_block).  A kernel of its own: beside the global-memory path of post_nms_big_kernel the
+// 128-register budget of a 1 024-thread block spilled into the rounds (that kernel took 96 us for ONE list of 4 085
+// candidates at batch 1: 3.8 us per round).
+__global__ __launch_bounds__(NMS_BIG) void post_nms_regs_kernel(const PostArgs p)
+{
+    __shared__ u64 rbest[2][NMS_BIG / 64];
+    __shared__ v4f rbox[2][NMS_BIG / 64];
+    const int tid = threadIdx.x;
+    const int nbig = *p.big_n;
+    for (int item = blockIdx.x; item < nbig; item += gridDim.x) {
+        const int bc = p.big_list[item];
+        const int b = bc / p.C;
+        int n = p.counts[bc];
+        if (n > p.N) n = p.N;
+        if (n > NMS_BIG * NMS_R) continue;   // post_nms_big_kernel's (block-uniform)
+        const int kept = nms_block<NMS_BIG>(p, p.keys + (long long)bc * p.N, p.dec + (long long)b * p.N * 4, n, tid,
+                                            p.cls_boxes + (long long)bc * p.max_per_class * 4, p.cls_scores + (long long)bc * p.max_per_class,
+                                            rbest, rbox);
+        if (tid == 0) p.cls_counts[bc] = kept;
+        __syncthreads();                     // the shared arrays are reused by the next pair
+    }
+}
+
+// K9c, still longer lists (beyond the register capacity of 1 024 threads): 1024 threads per (image, class).  Up to 1024*NMS_R candidates live in
 // registers (same scheme, block-wide arg-max through LDS); beyond that the keys stay in
 // global memory and dead candidates are zeroed there.
 // The blocks take their (image, class) pairs from the work list the small kernel filled: most lists are short
@@ -412,6 +545,7 @@ __global__ __launch_bounds__(NMS_BIG) void post_nms_big_kernel(const PostArgs p)
     const float *dec = p.dec + (long long)b * p.N * 4;
     float *ob = p.cls_boxes + (long long)bc * p.max_per_class * 4;
     float *os = p.cls_scores + (long long)bc * p.max_per_class;
+    if (n <= NMS_BIG * NMS_R) continue;      // post_nms_regs_kernel's (block-uniform)
     // Lists longer than the register capacity: greedy NMS only consumes candidates in
     // descending score order until max_per_class boxes are kept, so first try the top
     // scores alone -- a score histogram picks the largest score cut that leaves at most
@@ -635,7 +769,8 @@ hipError_t launch_postprocess(const PostArgs &pin, hipStream_t s)
     hipLaunchKernelGGL(post_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
     hipLaunchKernelGGL(post_nms_kernel, dim3((unsigned)(p.B * p.C)), dim3(NMS_MID), 0, s, p);
     const int big_blocks = p.B * p.C < 512 ? p.B * p.C : 512;     // two resident blocks per CU
-    hipLaunchKernelGGL(post_nms_big_kernel, dim3((unsigned)big_blocks), dim3(NMS_BIG), 0, s, p);
+    hipLaunchKernelGGL(post_nms_regs_kernel, dim3((unsigned)big_blocks), dim3(NMS_BIG), 0, s, p);
+    hipLaunchKernelGGL(post_nms_big_kernel, dim3((unsigned)(big_blocks < 64 ? big_blocks : 64)), dim3(NMS_BIG), 0, s, p);
     hipLaunchKernelGGL(post_pack_kernel, dim3((unsigned)p.B), dim3(256), (p.C + 1) * sizeof(int), s, p);
     return hipGetLastError();
 }

@@ -18,6 +18,21 @@ static inline int ssd_logical_of_phys(int p) { int o = p & ~7, r = p & 7; return
 
 #define SSD_MAX_LEVELS 5
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, DEVICE): the attribute belongs to the device's copy of
+// the function, so a second engine on another GPU of the same process needs its own call.  `done` is one word per
+// kernel instance, one bit per device.
+#include <atomic>
+static inline hipError_t ssd_allow_lds(const void *fn, int bytes, std::atomic<unsigned> &done)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 32 && ((done.load(std::memory_order_relaxed) >> dev) & 1u)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 32) done.fetch_or(1u << dev, std::memory_order_relaxed);
+    return e;
+}
+
 // floor(n / d) for 0 <= n < 2^31 without a division (Granlund-Montgomery: l = ceil(log2 d), mag = ceil(2^(31+l) / d) < 2^32,
 // q = mulhi(n, mag) >> (l - 1); d == 1: sh < 0, q = n).  The compiler's run-time division is ~22 vector instructions, this
 // is 2-3; the kernels' prologues and epilogues are paid in issue slots.  Host side fills, device side divides.
@@ -44,6 +59,8 @@ struct IgemmLevel {
     long long out_off;     // float offset of output (image 0, position 0)
     long long out_bstride; // floats between images in the output
     long long res_off;     // float offset of the coarse tensor [B,OH/2,OW/2,Cout] (upsample-add)
+    long long wt_off;      // float offset of THIS level's kernel inside `wt` (0: one kernel shared by all levels, the head towers;
+                           // grouped launches -- fpn p3 + p4 + p5 at batch 1 -- give every level its own [taps][CoutPad][Cin])
     UDiv dP, dOW;          // division by OH*OW and by OW
 };
 
@@ -92,6 +109,12 @@ int igemm_lat_bm(int tile);
 int igemm_lat_bn(int tile);
 bool igemm_lat_supports(const IgemmArgs &a);
 hipError_t launch_igemm_lat(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s);
+// igemm_s.hip: small LDS-staged tiles on v_mfma_f32_16x16x4_f32 (BM positions x BN channels); tile_begin counts BM-row tiles
+enum IgemmSTile { IGEMM_S_32x32 = 30, IGEMM_S_32x64 = 31, IGEMM_S_64x32 = 32, IGEMM_S_64x64 = 33 };
+static inline bool igemm_is_s(int tile) { return tile >= IGEMM_S_32x32 && tile <= IGEMM_S_64x64; }
+int igemm_s_bm(int tile);
+int igemm_s_bn(int tile);
+hipError_t launch_igemm_s(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s);
 // igemm16.hip: 256 x 256 tiles, one block per CU, S16 in / S16 out with batch norm (towers, FPN outputs);
 // tile_begin of the levels counts 256-row tiles, n_tiles_n = CoutPad / 256
 #define IGEMM16_TILE 100

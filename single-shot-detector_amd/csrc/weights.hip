@@ -328,6 +328,25 @@ static int finalize_fpn_heads(ssd_handle *h)
         snprintf(b, sizeof b, "fpn/p%d_batch_norm", i + 3);
         SSDCHK(load_conv(h, n, b, 3, i == 3 ? h->c_ch[2] : 256, 256, h->pconv[i]));
     }
+    {   // p3 | p4 | p5 again behind one pointer each (same shapes: 3x3, 256 -> 256, batch norm + ReLU): at batch 1 the three
+        // convolutions run as ONE launch whose levels carry their own kernel offset (plan.hip, IgemmLevel::wt_off)
+        ConvW &g = h->pgroup;
+        g = h->pconv[0];
+        g.wt16 = g.wt16w = nullptr;         // (exact fp32 only: the split-fp16 packs carry a per-convolution scale)
+        const size_t wn = (size_t)g.taps * g.CoutPad * g.CinP, pn = (size_t)g.CoutP;
+        if (h->pconv[1].CoutPad != g.CoutPad || h->pconv[2].CoutPad != g.CoutPad || h->pconv[1].CinP != g.CinP || h->pconv[2].CinP != g.CinP)
+            return ssd_fail(SSD_ERR_WEIGHT, "fpn p3 / p4 / p5 kernels differ in shape");
+        SSDCHK(h->wpool.alloc((void **)&g.wt, 3 * wn * sizeof(float)));
+        SSDCHK(h->wpool.alloc((void **)&g.mean, 3 * pn * sizeof(float)));
+        SSDCHK(h->wpool.alloc((void **)&g.sf, 3 * pn * sizeof(float)));
+        SSDCHK(h->wpool.alloc((void **)&g.beta, 3 * pn * sizeof(float)));
+        for (int i = 0; i < 3; ++i) {
+            HIPCHK(hipMemcpy(g.wt + i * wn, h->pconv[i].wt, wn * sizeof(float), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(g.mean + i * pn, h->pconv[i].mean, pn * sizeof(float), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(g.sf + i * pn, h->pconv[i].sf, pn * sizeof(float), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(g.beta + i * pn, h->pconv[i].beta, pn * sizeof(float), hipMemcpyDeviceToDevice));
+        }
+    }
     // box_predictor.py:107-155: conv weights shared across levels, batch norm per level
     const char *nets[2] = {"box_net", "class_net"};
     const int A = 6, C = h->cfg.num_classes;

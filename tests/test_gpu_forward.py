@@ -194,6 +194,15 @@ def test_detector_drop_in(cuda, ssd, oracle_graph, tmp_path):
     det_pb = ssd.Detector(str(tmp_path / "model.pb"))
     b3, l3, s3 = det_pb(img, score_threshold=0.2)
     assert np.array_equal(b3, boxes) and np.array_equal(l3, labels) and np.array_equal(s3, scores)
+    # ... and the same graph serialised by an encoder this repository did not write: google.protobuf's own, over TF's
+    # GraphDef message family declared at test time (tests/helpers/tf_protos.py) -- `import/` prefix, /read Identity nodes,
+    # consumers with list / string / bool attributes, non-float Consts, unpacked repeated fields
+    from helpers.tf_protos import frozen_graph
+    with open(tmp_path / "official.pb", "wb") as f:
+        f.write(frozen_graph(Wt, prefix="import/", unpacked=True))
+    det_pb2 = ssd.Detector(str(tmp_path / "official.pb"), config=str(tmp_path / "config.json"))
+    b4, l4, s4 = det_pb2(img, score_threshold=0.2)
+    assert np.array_equal(b4, boxes) and np.array_equal(l4, labels) and np.array_equal(s4, scores)
     # SSD mirror (ssd.py:10-69): raw predictions + get_predictions with other thresholds
     s = ssd.SSD(cuda.from_numpy(img[None].copy()).cuda(), det.engine)
     pred = s.get_predictions(score_threshold=0.3, iou_threshold=0.5, max_boxes_per_class=10)

@@ -59,13 +59,14 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", ["128", "64", "20", "21", "22", "23"])
+@pytest.mark.parametrize("tile", ["128", "64", "20", "21", "22", "23", "30", "31", "32", "33"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
 def test_conv2d(cuda, ssd, oracle_ops, case, tile, libopt):
     # the library picks 64x64 tiles for small problems and 128x128 for large ones: pin each
     # in turn so both kernels see every shape (narrow outputs keep their 128x64 / 128x32 tiles);
-    # 20 .. 23: the four wave tiles of the latency form (igemm_lat.hip, v_mfma_f32_16x16x4_f32), which
-    # takes every case whose output rows are 16-byte aligned -- the same bits from all of them
+    # 20 .. 23: the four wave tiles of the latency form (igemm_lat.hip), 30 .. 33: the four LDS-staged small tiles
+    # (igemm_s.hip) -- both on v_mfma_f32_16x16x4_f32, both take every case whose output rows are 16-byte
+    # aligned -- the same bits from all of them
     libopt(igemm_tile=int(tile, 0))
     B, H, W, Cin, Cout, k, stride, mode, use_bn, use_bias, act, use_up = case
     rng = np.random.default_rng(100 + CONV_CASES.index(case))
@@ -113,7 +114,7 @@ def test_conv2d_nan_inf(cuda, ssd, oracle_ops, shape, act, libopt):
     with np.errstate(all="ignore"):
         ref = oracle_ops.bn_act(oracle_ops.conv2d(x, w, 1, "SAME"), g, b, m, v, act)
     assert not np.isnan(ref).any() and (ref == 0).any()      # (ReLU keeps +inf; ReLU6 turns it into 6)
-    for tile in (128, 64, 20, 23):
+    for tile in (128, 64, 20, 23, 30, 33):
         libopt(igemm_tile=tile)
         got = ssd.ssd.conv2d(dev(cuda, x), w, 1, "SAME", bn=(m, oracle_ops.bn_scale(g, v), b), act=act).cpu().numpy()
         assert np.array_equal(got, ref), "tile %d: %d of %d values differ" % (tile, int((got != ref).sum()), ref.size)
@@ -214,6 +215,37 @@ def test_dw_pw_fused_repeatable(cuda, ssd, oracle_ops, shape):
         again = ssd.ssd.dw_pw(x, wd, stride, bn1, "relu6", wp, bn2, "relu6")
         assert cuda.equal(first, again), rep
     cuda.cuda.synchronize()
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("act", ["relu", "relu6"])
+def test_dw_pw_nan_inf(cuda, ssd, oracle_ops, stride, act):
+    """Non-finite inputs through dwpw_stream.hip, whose two activations are v_med3_f32(x, 0, hi) on uniform bounds: a NaN
+    must come out of an activation as 0 and +inf as the upper bound, exactly as the oracle's act_apply (`v > 0 ? v : 0`,
+    then `v < 6 ? v : 6`) and the two-kernel pair produce them -- a compiler or IEEE-mode change of med3's NaN behaviour
+    would show here."""
+    B, H, W, C, Cout = 2, 16, 24, 64, 96
+    rng = np.random.default_rng(40 + stride)
+    x = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    x[0, 3, 4, 5] = np.nan
+    x[0, 8, 7, 9] = np.inf
+    x[1, 9, 2, 1] = -np.inf
+    x[1, 0, 0, 33] = np.nan                           # a corner: the zero padding of the patch beside it
+    wd = rng.standard_normal((3, 3, C, 1)).astype(np.float32)
+    wp = (rng.standard_normal((1, 1, C, Cout)) * np.sqrt(2.0 / C)).astype(np.float32)
+    g1, b1, m1, v1 = bn_params(rng, C)
+    g2, b2, m2, v2 = bn_params(rng, Cout)
+    bn1, bn2 = (m1, oracle_ops.bn_scale(g1, v1), b1), (m2, oracle_ops.bn_scale(g2, v2), b2)
+    with np.errstate(all="ignore"):
+        mid = oracle_ops.bn_act(oracle_ops.depthwise3x3(x, wd, stride), g1, b1, m1, v1, act)
+        ref = oracle_ops.bn_act(oracle_ops.conv2d(mid, wp, 1, "SAME"), g2, b2, m2, v2, act)
+    assert not np.isnan(mid).any() and (mid == 0).any()          # the depthwise activation already removed every NaN
+    if act == "relu":
+        assert np.isinf(mid).any()                                # ... ReLU keeps +inf (ReLU6 turns it into 6)
+    got = ssd.ssd.dw_pw(dev(cuda, x), wd, stride, bn1, act, wp, bn2, act).cpu().numpy()
+    sep = ssd.ssd.conv2d(ssd.ssd.depthwise3x3(dev(cuda, x), wd, stride, bn=bn1, act=act), wp, 1, "SAME", bn=bn2, act=act).cpu().numpy()
+    assert np.array_equal(got, sep, equal_nan=True), int((got != sep).sum())
+    assert np.array_equal(got, ref, equal_nan=True), int((got != ref).sum())
 
 
 def test_dw_pw_unsupported_shapes_fail_loudly(cuda, ssd):

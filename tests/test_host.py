@@ -81,6 +81,38 @@ def test_frozen_graph_reader(ssd, tmp_path):
         ssd.read_frozen_graph(data[:len(data) // 2 + 3])
 
 
+@pytest.mark.parametrize("unpacked", [False, True])
+@pytest.mark.parametrize("prefix", ["", "import/"])
+def test_frozen_graph_reader_against_the_official_protobuf_encoder(ssd, unpacked, prefix):
+    """pb_import.py (a hand-written wire-format reader) against google.protobuf's own encoder over TF's GraphDef message
+    family (tests/helpers/tf_protos.py), in the shape create_pb.py:57-85 leaves a frozen graph: Const + `/read` Identity
+    pairs (optionally under `import/`, inference/detector.py:13-19), a uint8 Placeholder whose shape has unknown (-1)
+    dimensions, Conv2D / FusedBatchNorm consumers carrying list / string / bool / float attributes, int32 / int64 / string
+    Consts that are not weights, constant-filled batch-norm vectors in TF's one-value form, tensors as float_val lists
+    (packed, and unpacked with `unpacked`), everything else as tensor_content."""
+    from helpers.tf_protos import frozen_graph
+    p = {"backbone": "shufflenet", "depth_multiplier": 0.5, "num_classes": 2, "score_threshold": 0.1,
+         "iou_threshold": 0.5, "max_boxes_per_class": 5, "min_dimension": 128}
+    W = ssd.synthetic_weights(p, seed=4)
+    names = list(W)
+    splat = {n for n in names if n.endswith("moving_variance")}
+    for n in splat:
+        W[n] = np.full_like(W[n], 1.0)                    # e.g. an untrained moving variance: TF stores ONE float_val
+    as_vals = set(names[::9]) - splat
+    data = frozen_graph(W, prefix=prefix, unpacked=unpacked, splat=splat, as_vals=as_vals)
+    consts = ssd.read_frozen_graph(data)
+    assert set(W) <= set(consts) and "images" not in consts and "Assert/data_0" not in consts
+    assert np.array_equal(consts["resize/size"], np.array([640, 896], np.int32))
+    L = ssd.load_pb_weights(data, p)
+    assert set(L) == set(W) and all(np.array_equal(W[k], L[k]) and L[k].dtype == np.float32 and L[k].shape == W[k].shape for k in W)
+    # the official encoder and this repository's test writer agree on what a plain graph is
+    from helpers.pb_writer import write_frozen_graph as own
+    small = {k: W[k] for k in names[:4]}
+    assert ssd.read_frozen_graph(own(small)).keys() >= small.keys()
+    with pytest.raises(ValueError):
+        ssd.read_frozen_graph(data[:len(data) // 3 + 1])
+
+
 def test_coco_records(ssd):
     """evaluate_on_COCO.ipynb cell 10 record construction (no GPU: a stub detector)."""
     def det(image, score_threshold=0.15):
@@ -133,7 +165,7 @@ def test_library_reads_one_environment_variable_and_options_go_through_the_abi(s
                  b"SSD_LEVEL_SPLIT", b"SSD_BACKBONE_SPLIT", b"SSD_LATERAL_SPLIT", b"SSD_IGEMM_96"):
         assert gone not in blob, gone
     unset = -2 ** 31
-    for key in ("igemm_tile", "igemm_lat", "igemm_deep64", "streams", "igemm16", "igemm_96", "lateral_split", "backbone_split", "nsub", "level_split",
+    for key in ("igemm_tile", "igemm_lat", "igemm_deep64", "streams", "fpn_group", "head_serial", "igemm_small", "igemm16", "igemm_96", "lateral_split", "backbone_split", "nsub", "level_split",
                 "nms_fast_max", "fuse_dw", "graph", "debug_sync"):
         assert ssd.get_option(key) == unset
         ssd.set_option(key, 3)
