@@ -112,6 +112,7 @@ int ssd_get_precision(ssd_handle *h);
  *   "streams"         0 auto | 1: every kernel of a forward on one stream, in plan order                 (0)
  *   "fpn_group"       -1 auto | 0 | 1: fpn p3 + p4 + p5 as one grouped launch (batch 1, F32)             (-1)
  *   "head_serial"     -1 auto | 0 | 1: the box head behind the class logits instead of beside them       (-1)
+ *   "side_priority"   0 | 1: the streams of fpn p6 / p7 at the lowest dispatch priority                  (0)
  *   "igemm16"         -1 auto | 0 | 1: F16X3 launches on the 256x256-tile kernel                         (-1)
  *   "igemm_96"        1 | 0: 128x96 tiles for widths 96 divides and 128 does not (read by ssd_finalize)  (1)
  *   "lateral_split"   1 | 0: F16X3 laterals split fp32 rows while staging them                           (1)

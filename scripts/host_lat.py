@@ -28,3 +28,9 @@ ts = []
 for _ in range(110):
     t0 = time.perf_counter(); det(img, score_threshold=0.5); ts.append((time.perf_counter() - t0) * 1e3)
 print("Detector.__call__ p50 %.3f ms (mean %.3f)" % (np.percentile(ts[10:], 50), np.mean(ts[10:])))
+for nc in (1, 2, 3, 4, 6):
+    e.h2d_chunks = nc
+    ts = []
+    for _ in range(110):
+        t0 = time.perf_counter(); det(img, score_threshold=0.5); ts.append((time.perf_counter() - t0) * 1e3)
+    print("h2d_chunks %d: Detector.__call__ p50 %.3f ms" % (nc, np.percentile(ts[10:], 50)))

@@ -50,6 +50,7 @@ enum SsdOpt {
     OPT_FPN_GROUP,          // -1 auto | 0 | 1: fpn p3 + p4 + p5 as one grouped launch (exact fp32)
     OPT_HEAD_SERIAL,        // -1 auto | 0 | 1: the box head behind the class logits on one stream instead of beside them
     OPT_IGEMM_SMALL,        // 1 (default) | 0: 32x32 tiles on v_mfma_f32_16x16x4_f32 for mid-size batch-1 launches (igemm_s.hip)
+    OPT_SIDE_PRIORITY,      // 0 (default) | 1: the plan's third / fourth stream at the lowest dispatch priority
     OPT_COUNT
 };
 #define SSD_OPT_UNSET INT_MIN

@@ -853,7 +853,15 @@ int make_plans(ssd_handle *h, int B, int H, int W)
         h->plans.push_back(pl);
         if (k > 0) HIPCHK(hipStreamCreateWithFlags(&pl->s_main, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&pl->s_aux, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&pl->s_bb[i], hipStreamNonBlocking));
+        {   // option side_priority = 1: the third / fourth stream (fpn p6 -> p7 at batch 1) at the lowest dispatch priority, so
+            // that its waves yield to the lateral chain they run beside (measurement: DESIGN section 8)
+            int least = 0, greatest = 0;
+            const bool low = ssd_opt(h, OPT_SIDE_PRIORITY, 0) == 1 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+            for (int i = 0; i < 2; ++i) {
+                if (low) HIPCHK(hipStreamCreateWithPriority(&pl->s_bb[i], hipStreamNonBlocking, least));
+                else HIPCHK(hipStreamCreateWithFlags(&pl->s_bb[i], hipStreamNonBlocking));
+            }
+        }
         HIPCHK(hipEventCreateWithFlags(&pl->ev_fpn, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&pl->ev_done, hipEventDisableTiming));
