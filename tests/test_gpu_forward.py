@@ -135,6 +135,49 @@ def test_sub_batch_plans(cuda, ssd, oracle_graph, libopt):
     eng.close()
 
 
+@pytest.mark.parametrize("H,W,B", [(256, 384, 1), (640, 896, 1), (256, 256, 2)])
+def test_small_batch_plan_variants_are_bit_identical(cuda, ssd, oracle_graph, H, W, B):
+    """The batch-1 / batch-2 plan (round 3) picks other kernels and another launch structure than the serving plan: the
+    latency form of the implicit GEMM for fpn p6 / p7 (igemm_lat.hip), 32x32 tiles on v_mfma_f32_16x16x4_f32 for mid-size 1x1
+    layers (igemm_s.hip), fpn p3 + p4 + p5 as one grouped launch, 64x64 tiles with deep prefetch.  Every one of them is
+    bit-identical to what it replaces by construction (the same k-ordered fmaf chain per output): switching each off, all of
+    them off, or everything onto one stream changes no bit of any retained tensor or output -- and the default equals the
+    oracle."""
+    params = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
+              "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": min(H, W)}
+    Wt = ssd.synthetic_weights(params, seed=11, logits_bias=-6.0)
+    img = np.random.default_rng(H + W + B).integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    dimg = cuda.from_numpy(img).cuda()
+    names = ["c3", "c4", "c5", "p3", "p4", "p5", "p6", "p7", "encoded_boxes", "class_predictions"]
+    eng = ssd.Engine(params, Wt, precision="f32")
+
+    def run():
+        out = [t.cpu().numpy() for t in eng.forward(dimg)]
+        return out, {n: eng.get_tensor(n) for n in names}
+    base_out, base_t = run()
+    assert int(base_out[3].sum()) > 10
+    if H * W <= 256 * 384:            # (the oracle at full size runs in test_forward_vs_oracle_full_size)
+        keep = {}
+        ref = oracle_graph.forward(img, Wt, params, keep)
+        compare_outputs(base_out, ref, "small-batch plan %dx%d B=%d" % (H, W, B))
+        assert all(np.array_equal(a, ref[k]) for a, k in zip(base_out, ("boxes", "labels", "scores", "num_boxes")))
+        for n in names:
+            assert np.array_equal(base_t[n], keep[n].reshape(base_t[n].shape)), n
+    variants = [{"igemm_lat": 0}, {"igemm_small": 0}, {"fpn_group": 0}, {"igemm_deep64": 0}, {"streams": 1}, {"head_serial": 1},
+                {"side_priority": 1}, {"igemm_lat": 0, "igemm_small": 0, "fpn_group": 0, "igemm_deep64": 0}]
+    for v in variants:
+        for k, val in v.items():
+            eng.set_option(k, val)
+        out, t = run()
+        for a, b in zip(out, base_out):
+            assert np.array_equal(a, b), v
+        for n in names:
+            assert np.array_equal(t[n], base_t[n]), (v, n)
+        for k in v:
+            eng.set_option(k, -2 ** 31)           # back to "unset"
+    eng.close()
+
+
 @pytest.mark.parametrize("cfg,H,W", [("config_mobilenet.json", 640, 896), ("config_shufflenet.json", 640, 640)])
 def test_forward_vs_oracle_full_size(cuda, ssd, oracle_graph, cfg, H, W):
     """BASELINE config 2 (MobileNet-v1 + FPN + heads at 640x896, batch 1) and config 4's
