@@ -104,10 +104,8 @@ int ssd_get_precision(ssd_handle *h);
  * which a handle falls back to for an option it has not been given itself; with a handle the call synchronises and drops
  * the cached layer plan.  Keys (value; default):
  *   "igemm_tile"      0 auto | 128 | 64 pin the tile of the 128x128-class launches | 20..23 pin a wave tile of the latency
- *                     form (1x1, 1x2, 2x1, 2x2 sixteen-wide units), 30..33 a small tile (32x32, 32x64, 64x32,
- *                     64x64) wherever those forms apply                                                  (0)
+ *                     form (1x1, 1x2, 2x1, 2x2 sixteen-wide units) wherever that form applies           (0)
  *   "igemm_lat"       1 | 0: tiny exact-fp32 launches on the latency form (v_mfma_f32_16x16x4_f32)      (1)
- *   "igemm_small"     1 | 0: mid-size batch-1 launches on 32x32 tiles of the same instruction            (1)
  *   "igemm_deep64"    -1 auto | 0 | 1: 64x64 tiles with operand loads three K-steps ahead                (-1)
  *   "streams"         0 auto | 1: every kernel of a forward on one stream, in plan order                 (0)
  *   "fpn_group"       -1 auto | 0 | 1: fpn p3 + p4 + p5 as one grouped launch (batch 1, F32)             (-1)

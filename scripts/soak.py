@@ -1,7 +1,7 @@
 """Race screen at full size: N forwards of the bench workload (32 frames of 640x896, precision f16x3, two
 streams, 256x256-tile kernel with LDS-DMA staging and the fused candidate bitmap) on the same input must all
 give the same bits as the first.  usage: python scripts/soak.py [N] [f16x3|f32] [mobilenet|shufflenet] [batch]
-(batch 1 / 2 screen the small-batch plan of round 3: grouped FPN launch, igemm_lat / igemm_s kernels, the post-processing's LDS-aggregated list appends and its top-score trial)"""
+(batch 1 / 2 screen the small-batch plan of round 3: grouped FPN launch, igemm_lat kernel, the post-processing's LDS-aggregated list appends and its top-score trial)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

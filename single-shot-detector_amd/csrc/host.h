@@ -49,7 +49,6 @@ enum SsdOpt {
     OPT_STREAMS,            // 0 auto | 1: every op of a plan on one stream (measurement aid)
     OPT_FPN_GROUP,          // -1 auto | 0 | 1: fpn p3 + p4 + p5 as one grouped launch (exact fp32)
     OPT_HEAD_SERIAL,        // -1 auto | 0 | 1: the box head behind the class logits on one stream instead of beside them
-    OPT_IGEMM_SMALL,        // 1 (default) | 0: 32x32 tiles on v_mfma_f32_16x16x4_f32 for mid-size batch-1 launches (igemm_s.hip)
     OPT_SIDE_PRIORITY,      // 0 (default) | 1: the plan's third / fourth stream at the lowest dispatch priority
     OPT_COUNT
 };
@@ -99,6 +98,7 @@ struct BnHost { std::vector<float> mean, sf, beta; };
 
 struct ConvW {
     float *wt = nullptr, *mean = nullptr, *sf = nullptr, *beta = nullptr, *bias = nullptr;
+    float *wlat = nullptr;     // the same kernel in igemm_lat.hip's lane-order pieces (tiny launches, exact fp32)
     float *wt16 = nullptr;     // the same rows in split-fp16 form, scaled by 2^s (precision mode f16x3)
     float *wt16w = nullptr;    // wide outputs whose width 256 does not divide (480 class logits): the S16 rows again,
     int CoutPad16 = 0;         //   padded to CoutPad16 = a multiple of 256 rows per tap for the 256x256-tile kernel

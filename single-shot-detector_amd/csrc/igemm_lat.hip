@@ -1,42 +1,53 @@
-// Latency form of the implicit-GEMM convolution for SMALL launches (batch 1-2: fpn p4..p7 and laterals, the late
-// MobileNet pointwise layers, coarse pyramid levels): v_mfma_f32_16x16x4_f32, one wave per block, operands straight
-// from global memory into MFMA registers -- no LDS, no barrier.
+// Latency form of the implicit-GEMM convolution for TINY launches (batch 1-2: fpn p6 and p7 -- 140 and 35 positions per
+// image; coarse pyramid levels): v_mfma_f32_16x16x4_f32, ONE wave per block, no barrier.
 //
-// Why a second kernel.  The time of a small launch on the 32x32x2 kernel (igemm.hip) is the length of ONE accumulator's
+// Why a second kernel.  The time of a tiny launch on the 32x32x2 kernel (igemm.hip) is the length of ONE accumulator's
 // K chain: an accumulator of v_mfma_f32_32x32x2_f32 advances k by 2 per 64 pipe cycles, so fpn p6 at batch 1
-// (k = 9 x 1024) is 4 608 dependent MFMAs = 123 us at 2.4 GHz on 12 tiles, whatever else is done well (measured 199 us,
-// profiles/r03_batch1_timeline_before.txt), and every K-step pays a barrier + LDS round trip on top.
-// v_mfma_f32_16x16x4_f32 advances k by 4 per 32 cycles -- a quarter of the chain -- on 16x16 tiles, i.e. four times as
-// many independent chains for the 256 CUs, and it is bit for bit the same k-ascending fmaf chain
+// (k = 9 x 1024) is 4 608 dependent MFMAs = 123 us at 2.4 GHz on 12 tiles, whatever else is done well (measured 199 us in
+// the network, profiles/r03_batch1_timeline_before.txt), and every K-step pays a barrier + LDS round trip on top.
+// v_mfma_f32_16x16x4_f32 advances k by 4 per 32 cycles -- a quarter of the chain -- on 16x16 tiles, i.e. sixteen times as
+// many independent chains as 64x64 tiles give the 256 CUs, and it is bit for bit the same k-ascending fmaf chain
 // (scripts/experiments/mfma_16x16x4_probe.hip, profiles/r03_mfma_16x16x4_probe.log: 256 of 256 outputs equal to the
 // chain at K = 4 .. 2304; one dependent accumulator issues every 32.0 cycles).  Results are therefore bit-identical
 // to igemm.hip and to the oracle; tests compare all three.
 //
 //   GEMM view   as igemm.hip: rows m = (image, oy, ox), cols n = output channel (physical order), k = (ky, kx, ci)
 //   wave tile   PT x 16 positions  x  CT x 16 channels, PT*CT accumulators of 4 registers
-//   product     TRANSPOSED: the weights are the MFMA's A operand (rows of D = channels), the activations its B operand
-//               (columns of D = positions); fma(w, x, acc) == fma(x, w, acc).  A lane then holds 4 CONSECUTIVE channels
-//               of one position: batch norm with vector parameter loads and 16-byte stores straight from the
-//               accumulators, no transpose.
-//   operands    lane l = (i = l & 15, kk = l >> 4) supplies k = 4t + kk of MFMA t.  With the physical channel order of
-//               ssd_internal.h (octet = logical [0,2,4,6,1,3,5,7]) the lane's two values of an octet, logical kk and
-//               4 + kk, sit 8 bytes apart: ONE 16-byte load at  row + octet*32 + (kk & 1)*16 + (kk >> 1)*4  brings both
-//               (elements 0 and 2; lanes kk >= 2 load at a 4-byte-shifted address, which a dword-aligned
-//               buffer_load_dwordx4 allows, so every lane finds its operands in the same registers: no select).
-//               The shifted load of a tensor's last chunk touches 4 bytes behind it: every allocation of the library
-//               carries that slack (DevPool) and the descriptors here are 4 bytes longer; the value is never used.
-//   pipeline    the loads of K-step s + D are issued behind the MFMAs of K-step s (D = 2 .. 4 register sets); waits are
-//               the compiler's counted vmcnt.  Zero padding and rows past M are the buffer range check, tap changes a
-//               per-row mask (as igemm.hip).
+//   product     transposed (weights = the MFMA's A operand), epilogue straight from the accumulators: igemm_mfma16.h
+//   weights     a second packing made at ssd_finalize (ConvW::wlat): per (tap, 16-channel tile, K-step of 32 channels) two
+//               1-KB pieces in LANE order -- lane (i, kk) finds its operands t = 0..3 / 4..7 (k = 4 t + kk) of channel i at
+//               lane * 16: a fragment is TWO perfectly coalesced loads straight into MFMA registers
+//   positions   coalesced too: 8 rows x 128 B per load instruction (zero padding = buffer range check, per-row tap masks, as
+//               igemm.hip), regrouped by MFMA role through a wave-private LDS image: a row's 32 channels stored as
+//               [kk = channel & 3][t = channel >> 2].  In the physical channel order a lane's 16-byte chunk (octet o, half h)
+//               holds logical 8o + {0,2,4,6} + h: elements (0,2) go to kk = h at t = 2o, 2o+1, elements (1,3) to kk = h + 2
+//               -- two 8-byte writes per load; lane (i, kk) reads its eight operands with two ds_read_b128.  The 16-byte
+//               slot (2 kk + half) of row r sits at slot ^ ((r >> 1) & 7) ^ (2 * ((r >> 2) & 1)): conflict-free for the four
+//               16-lane groups of ds_read_b128 (MI355X_MICROARCH.md LDS table).  No barrier: LDS operations of one wave
+//               execute in order
+//   pipeline    D register sets: the loads of K-step s + D are issued behind the MFMAs of K-step s; the positions of step
+//               s + 1 go to the other LDS stage before the MFMAs of step s and are read back behind them; waits are the
+//               compiler's counted vmcnt / lgkmcnt.
+// (The first form of this kernel, round 3, loaded every fragment in MFMA lane order straight from the activation / weight
+//  rows -- 16 rows x 4 lanes per instruction, half of each 16-byte load unused: such a load costs ~64 cycles of the CU's
+//  address path, a K-step 8 of them against 256 cycles of MFMA; p6 65 us alone, and the laterals running beside it lost
+//  25 us to its loads.  This form issues 4 coalesced loads per K-step.)
 #include "igemm_mfma16.h"
 #include <type_traits>
+
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int PT, int CT, int TAPS, int D>
 __global__ __launch_bounds__(64) void igemm_lat_kernel(const IgemmArgs a)
 {
+    static_assert(D == 2 || D == 4 || D == 8, "the loop is unrolled over D register sets and two LDS stages");
+    // (Beside a launch that saturates the matrix pipe -- fpn p6 beside the grouped p3+p4+p5 launch -- this kernel's dependent
+    //  32-cycle MFMAs queue behind the other waves' 64-cycle ones: p6 59 us alone, 172 us there, with or without s_setprio 3,
+    //  4 or 8 K-steps of loads in flight, a high-priority stream: DESIGN section 8.)
     constexpr int BM = PT * 16, BN = CT * 16;
-    const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
-    const int sub = (kk & 1) * 16 + (kk >> 1) * 4;            // byte offset of the lane's operands inside an octet
+    constexpr int NX = 2 * PT;                    // position loads per K-step: 8 rows x 128 B each
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PT * 2048];
+    const int lane = threadIdx.x;
 
     // blocks b, b+8, ... share an XCD: consecutive tiles (the channel tiles of one position tile first) per XCD
     int swz;
@@ -54,30 +65,33 @@ __global__ __launch_bounds__(64) void igemm_lat_kernel(const IgemmArgs a)
     const IgemmLevel L = a.lv[lvl];
     const int H = L.H, W = L.W, OW = L.OW, M = L.M, P = L.OH * L.OW, Cin = a.Cin;
     const int m0 = (tile_m - L.tile_begin) * BM, n0 = tile_n * BN;
+    const int KC = Cin >> 5, KS = TAPS * KC;
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(a.in + L.in_off), 0, (int)((long long)a.B * H * W * Cin * 4 + 4), 0x00020000);
+        (void *)(a.in + L.in_off), 0, (int)((long long)a.B * H * W * Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(a.wt + L.wt_off), 0, (int)((long long)TAPS * a.CoutPad * Cin * 4 + 4), 0x00020000);
+        (void *)(a.wt_lat + L.wt_off), 0, (int)((long long)TAPS * a.CoutPad * Cin * 4), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
-    // ---- positions: byte offset of tap (0,0) of row m0 + p*16 + i, and "tap t reads inside the image" bits
-    int xbase[PT];
-    unsigned xmask[PT];
+    // ---- positions: load u covers rows 8 u + (lane >> 3), chunk lane & 7
+    int xbase[NX];
+    unsigned xmask[NX];
+    int woff_lo[NX], woff_hi[NX];
     const bool dense1x1 = TAPS == 1 && a.stride == 1 && a.pad == 0 && L.OH == H && OW == W;
 #pragma unroll
-    for (int p = 0; p < PT; ++p) {
-        const int m = m0 + p * 16 + i;
+    for (int u = 0; u < NX; ++u) {
+        const int r = 8 * u + (lane >> 3), c = lane & 7;
+        const int m = m0 + r;
         const bool rowok = m < M;
         const int mm = rowok ? m : 0;
         if (dense1x1) {
-            xbase[p] = mm * Cin * 4 + sub;
-            xmask[p] = rowok ? 1u : 0u;
+            xbase[u] = (mm * Cin + c * 4) * 4;
+            xmask[u] = rowok ? 1u : 0u;
         } else {
             const int b = (int)udivl((unsigned)mm, L.dP), pp = mm - b * P;
             const int oy = (int)udivl((unsigned)pp, L.dOW), ox = pp - oy * OW;
             const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-            xbase[p] = (b * H * W + iy0 * W + ix0) * Cin * 4 + sub;
+            xbase[u] = ((b * H * W + iy0 * W + ix0) * Cin + c * 4) * 4;
             unsigned vx = 0, mk = 0;
 #pragma unroll
             for (int k = 0; k < (TAPS == 9 ? 3 : 1); ++k)
@@ -85,82 +99,122 @@ __global__ __launch_bounds__(64) void igemm_lat_kernel(const IgemmArgs a)
 #pragma unroll
             for (int k = 0; k < (TAPS == 9 ? 3 : 1); ++k)
                 if ((unsigned)(iy0 + k) < (unsigned)H) mk |= vx << (3 * k);
-            xmask[p] = rowok ? mk : 0u;
+            xmask[u] = rowok ? mk : 0u;
         }
+        // LDS image: octet o, half h of the row -> elements (0,2) at role kk = h, (1,3) at kk = h + 2
+        const int o = c >> 1, hh = c & 1;
+        const int f = ((r >> 1) & 7) ^ (2 * ((r >> 2) & 1));
+        woff_lo[u] = r * 128 + ((((hh) * 2 + (o >> 1)) ^ f) << 4) + (o & 1) * 8;
+        woff_hi[u] = r * 128 + ((((hh + 2) * 2 + (o >> 1)) ^ f) << 4) + (o & 1) * 8;
     }
-    auto tap_offsets = [&](int t, unsigned (&off)[PT]) {
+    auto tap_offsets = [&](int t, unsigned (&off)[NX]) {
         const int tky = TAPS == 9 ? t / 3 : 0, tkx = TAPS == 9 ? t - 3 * tky : 0;
         const int d = (tky * W + tkx) * Cin * 4;
 #pragma unroll
-        for (int p = 0; p < PT; ++p) off[p] = ((xmask[p] >> t) & 1u) ? (unsigned)(xbase[p] + d) : OOB;
+        for (int u = 0; u < NX; ++u) off[u] = ((xmask[u] >> t) & 1u) ? (unsigned)(xbase[u] + d) : OOB;
     };
-    // ---- weights: row n0 + c*16 + i of wt [tap][CoutPad][Cin]
+    int roff[2];
+    {
+        const int i = lane & 15, kk = lane >> 4;
+        const int f = ((i >> 1) & 7) ^ (2 * ((i >> 2) & 1));
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) roff[hf] = i * 128 + (((2 * kk + hf) ^ f) << 4);
+    }
+    // ---- weights: piece (tap, channel tile, K-step, half) of wlat at lane * 16
     int wbase[CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) wbase[c] = (n0 + c * 16 + i) * Cin * 4 + sub;
+    for (int c = 0; c < CT; ++c) wbase[c] = ((n0 >> 4) + c) * KC * 2048 + lane * 16;
     const int w_tapstride = a.CoutPad * Cin * 4;
 
-    const int KC = Cin >> 5, KS = TAPS * KC;
-    unsigned offc[PT], offn[PT];
+    unsigned offc[NX], offn[NX];
     int ltap = 0, lkc = 0, kload = 0;
     tap_offsets(0, offc);
     tap_offsets(1, offn);
-    v4f xr[D][PT][4], wr[D][CT][4];
-    auto load = [&](auto slot_tag) __attribute__((always_inline)) {
-        constexpr int S = decltype(slot_tag)::value;
-        const int so = lkc * 128, wso = ltap * w_tapstride + so;
+    v4f xr[D][NX], wr[D][CT][2];
+    auto gload = [&](auto set_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_tag)::value;
+        const int so = lkc * 128, wso = ltap * w_tapstride + lkc * 2048;
 #pragma unroll
         for (int c = 0; c < CT; ++c)
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
-                wr[S][c][o] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wbase[c] + o * 32, wso, 0));
+            for (int hf = 0; hf < 2; ++hf)
+                wr[S][c][hf] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wbase[c] + hf * 1024, wso, 0));
 #pragma unroll
-        for (int p = 0; p < PT; ++p)
-#pragma unroll
-            for (int o = 0; o < 4; ++o)
-                xr[S][p][o] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)offc[p] + o * 32, so, 0));
-        // advance the load stream; past the last step the counters stay put (the surplus prefetch re-reads valid memory)
-        if (++kload < KS) {
+        for (int u = 0; u < NX; ++u)
+            xr[S][u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)offc[u], so, 0));
+        if (++kload < KS) {          // advance the load stream (past the end the counters stay put: valid memory is re-read)
             if (++lkc == KC) {
                 lkc = 0;
                 ++ltap;
 #pragma unroll
-                for (int p = 0; p < PT; ++p) offc[p] = offn[p];
+                for (int u = 0; u < NX; ++u) offc[u] = offn[u];
                 tap_offsets(ltap + 1, offn);
             }
         }
+    };
+    auto lstore = [&](int stage, auto set_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_tag)::value;
+        unsigned char *base = lds + stage * (PT * 2048);
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            *(v2f *)(base + woff_lo[u]) = v2f{xr[S][u][0], xr[S][u][2]};
+            *(v2f *)(base + woff_hi[u]) = v2f{xr[S][u][1], xr[S][u][3]};
+        }
+    };
+    v4f xf[2][PT][2];                // fragments by LDS stage
+    auto lread = [&](auto stage_tag) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_tag)::value;
+        const unsigned char *base = lds + ST * (PT * 2048);
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) xf[ST][p][hf] = *(const v4f *)(base + p * 2048 + roff[hf]);
     };
     v4f acc[CT][PT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int p = 0; p < PT; ++p) acc[c][p] = v4f{0.f, 0.f, 0.f, 0.f};
-    // one K-step = 32 channels = 8 MFMAs per accumulator: octet o, then its two halves (elements 0 and 2 of the lane's load)
-    auto compute = [&](auto slot_tag) __attribute__((always_inline)) {
-        constexpr int S = decltype(slot_tag)::value;
+    auto mfmas = [&](auto set_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_tag)::value;
 #pragma unroll
-        for (int o = 0; o < 4; ++o)
+        for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-            for (int e = 0; e < 4; e += 2)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int c = 0; c < CT; ++c)
 #pragma unroll
                     for (int p = 0; p < PT; ++p)
-                        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[S][c][o][e], xr[S][p][o][e], acc[c][p], 0, 0, 0);
+                        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[S][c][hf][e], xf[S & 1][p][hf][e], acc[c][p], 0, 0, 0);
     };
-    auto for_slots = [&](auto fn) __attribute__((always_inline)) {
+    // one K-step whose operands are register set S and the fragments of LDS stage S & 1 (D is even): the positions of the
+    // next step go through the other stage into the other fragment registers FIRST (write and read of one wave execute in
+    // order; both complete under the MFMAs), then the multiply, then the set is refilled with step + D
+    auto kstep = [&](auto set_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_tag)::value, N = (S + 1) % D;
+        lstore((S + 1) & 1, std::integral_constant<int, N>{});
+        lread(std::integral_constant<int, (S + 1) & 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(set_tag);
+        gload(set_tag);
+    };
+    auto for_sets = [&](auto fn) __attribute__((always_inline)) {
         fn(std::integral_constant<int, 0>{});
-        if constexpr (D > 1) fn(std::integral_constant<int, 1>{});
-        if constexpr (D > 2) fn(std::integral_constant<int, 2>{});
-        if constexpr (D > 3) fn(std::integral_constant<int, 3>{});
+        fn(std::integral_constant<int, 1>{});
+        if constexpr (D > 2) { fn(std::integral_constant<int, 2>{}); fn(std::integral_constant<int, 3>{}); }
+        if constexpr (D > 4) {
+            fn(std::integral_constant<int, 4>{}); fn(std::integral_constant<int, 5>{});
+            fn(std::integral_constant<int, 6>{}); fn(std::integral_constant<int, 7>{});
+        }
     };
-    for_slots([&](auto s) __attribute__((always_inline)) { load(s); });
+    for_sets([&](auto s) __attribute__((always_inline)) { gload(s); });
+    lstore(0, std::integral_constant<int, 0>{});
+    lread(std::integral_constant<int, 0>{});
     int ks = 0;
-    for (; ks + D <= KS; ks += D)
-        for_slots([&](auto s) __attribute__((always_inline)) { compute(s); load(s); });
+    for (; ks + D <= KS; ks += D) for_sets([&](auto s) __attribute__((always_inline)) { kstep(s); });
     {
-        const int rem = KS - ks;                              // 0 .. D-1 steps left, already loaded
-        for_slots([&](auto s) __attribute__((always_inline)) { if (decltype(s)::value < rem) compute(s); });
+        const int rem = KS - ks;     // 0 .. D-1 steps left: their operands are loaded (set d = step's index in the group)
+        for_sets([&](auto s) __attribute__((always_inline)) { if (decltype(s)::value < rem) kstep(s); });
     }
 
     epilogue_16x16<PT, CT>(a, L, acc, m0, n0, lane);
@@ -192,10 +246,10 @@ bool igemm_lat_supports(const IgemmArgs &a)
 
 hipError_t launch_igemm_lat(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 {
-    if (!igemm_lat_supports(a) || (a.taps != 1 && a.taps != 9)) return hipErrorInvalidValue;
-    if ((long long)a.taps * a.CoutPad * a.Cin * 4 + 4 >= (1LL << 31)) return hipErrorInvalidValue;
+    if (!igemm_lat_supports(a) || !a.wt_lat || (a.taps != 1 && a.taps != 9)) return hipErrorInvalidValue;
+    if ((long long)a.taps * a.CoutPad * a.Cin * 4 >= (1LL << 31)) return hipErrorInvalidValue;
     for (int l = 0; l < a.nlevels; ++l) {
-        if ((long long)a.B * a.lv[l].H * a.lv[l].W * a.Cin * 4 + 4 >= (1LL << 31)) return hipErrorInvalidValue;
+        if ((long long)a.B * a.lv[l].H * a.lv[l].W * a.Cin * 4 >= (1LL << 31)) return hipErrorInvalidValue;
         if ((long long)a.B * a.lv[l].out_bstride * 4 >= (1LL << 31) || a.lv[l].out_bstride < 0) return hipErrorInvalidValue;
     }
     if ((a.mean != nullptr) != (a.sf != nullptr) || (a.mean != nullptr) != (a.beta != nullptr)) return hipErrorInvalidValue;
@@ -205,8 +259,8 @@ hipError_t launch_igemm_lat(int tile, const IgemmArgs &a, int total_tiles_m, hip
     if (a.n_tiles_n * igemm_lat_bn(tile) != a.CoutPad || a.nlevels < 1 || a.nlevels > SSD_MAX_LEVELS) return hipErrorInvalidValue;
     switch (tile) {
     case IGEMM_LAT_1x1: return launch_l<1, 1, 4>(a, total_tiles_m, s);
-    case IGEMM_LAT_1x2: return launch_l<1, 2, 3>(a, total_tiles_m, s);
-    case IGEMM_LAT_2x1: return launch_l<2, 1, 3>(a, total_tiles_m, s);
+    case IGEMM_LAT_1x2: return launch_l<1, 2, 4>(a, total_tiles_m, s);
+    case IGEMM_LAT_2x1: return launch_l<2, 1, 4>(a, total_tiles_m, s);
     case IGEMM_LAT_2x2: return launch_l<2, 2, 2>(a, total_tiles_m, s);
     }
     return hipErrorInvalidValue;

@@ -1,4 +1,4 @@
-// Shared by the two kernels built on v_mfma_f32_16x16x4_f32 (igemm_lat.hip, igemm_s.hip): the epilogue of the TRANSPOSED
+// The epilogue of the kernel built on v_mfma_f32_16x16x4_f32 (igemm_lat.hip): the TRANSPOSED
 // product -- weights as the MFMA's A operand, activations as its B operand, so that D's rows are channels and its columns
 // positions: lane l = (column i = l & 15, row group kk = l >> 4) holds channels 4*kk .. 4*kk+3 of position i of every 16x16
 // accumulator -- four CONSECUTIVE physical channels of one position: batch norm with vector parameter loads and 16-byte

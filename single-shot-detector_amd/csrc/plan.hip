@@ -15,6 +15,7 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in; a.wt = in_fmt ? cw.wt16 : cw.wt; a.out = out; a.out2 = out2;
+    a.wt_lat = in_fmt ? nullptr : cw.wlat;
     a.in_fmt = in_fmt; a.out_fmt = out_fmt; a.res_fmt = res ? res_fmt : 0;
     a.acc_scale = in_fmt ? cw.scale16 : 1.0f;
     a.flags = flags;
@@ -105,28 +106,19 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
     // its own operands in fragment shape, ~70 cycles per 1-KB load instruction, and only a launch of at most one or two
     // waves per CU keeps that under its MFMA chain.  Option igemm_lat = 0 switches the form off, igemm_tile = 20 .. 23
     // pins a wave tile wherever the form applies (tests run every shape on all four).
-    if (igemm_is_lat(tile) || igemm_is_s(tile)) {            // (diagnostics: ssd_bench_conv asked for this tile)
-        if (!igemm_lat_supports(a) || cw.CoutPad % (igemm_is_s(tile) ? igemm_s_bn(tile) : igemm_lat_bn(tile))) tile = IGEMM_128x128;
+    if (igemm_is_lat(tile)) {            // (diagnostics: ssd_bench_conv asked for this wave tile)
+        if (!igemm_lat_supports(a) || cw.CoutPad % igemm_lat_bn(tile) || !a.wt_lat) tile = IGEMM_128x128;
     } else if (tile != IGEMM16_TILE && g_force_tile < 0 && igemm_lat_supports(a)) {
         const int pin = ssd_opt(h, OPT_IGEMM_TILE, 0);
-        if ((igemm_is_lat(pin) && cw.CoutPad % igemm_lat_bn(pin) == 0) || (igemm_is_s(pin) && cw.CoutPad % igemm_s_bn(pin) == 0)) tile = pin;
+        if (igemm_is_lat(pin) && a.wt_lat && cw.CoutPad % igemm_lat_bn(pin) == 0) tile = pin;
         else if (pin == 0 && ssd_opt(h, OPT_IGEMM_LAT, 1)) {
-            long long waves = 0;
-            for (size_t i = 0; i < lv.size(); ++i) waves += (((long long)a.lv[i].M + 15) / 16) * (cw.CoutPad / 16);
-            if (waves <= 320) tile = IGEMM_LAT_1x1;
+            long long waves = 0, b64 = 0;
+            for (size_t i = 0; i < lv.size(); ++i) {
+                waves += (((long long)a.lv[i].M + 15) / 16) * (cw.CoutPad / 16);
+                b64 += (((long long)a.lv[i].M + 63) / 64) * ((cw.CoutPad + 63) / 64);
+            }
+            if ((waves <= 320 || b64 <= 40) && a.wt_lat) tile = IGEMM_LAT_1x1;
         }
-    }
-    // 1x1 convolutions of at most ~1.2 64x64 tiles per CU, and 3x3 ones of a few dozen (batch 1: Conv2d_6 .. 11 pointwise,
-    // lateral5; fpn p5 at batch 2): 32x32 tiles on v_mfma_f32_16x16x4_f32 (igemm_s.hip).  A 64x64 tile's K loop cannot be
-    // shorter than 1 024 cycles per K-step and 280 tiles leave 24 CUs with two of them; the same work in 1 120 tiles of a
-    // quarter of the chain splits evenly.  Alone on the chip (profiles/r03_conv_small_tiles.log): 512 -> 512 at 40x56
-    // 22 -> 19 us, 256 -> 512 14 -> 12, lateral5 20 -> 12, p5 39 -> 23 us; equal for the 144-tile and the 560-tile layers, slower
-    // for p4 (42 -> 46): those stay.  Same bits.
-    if (tile == IGEMM_64x64 && !in_fmt && g_force_tile < 0 && igemm_lat_supports(a) && ssd_opt(h, OPT_IGEMM_TILE, 0) == 0 &&
-        ssd_opt(h, OPT_IGEMM_SMALL, 1) && cw.CoutPad % 32 == 0) {
-        long long b64 = 0;
-        for (size_t i = 0; i < lv.size(); ++i) b64 += (((long long)a.lv[i].M + 63) / 64) * (cw.CoutPad / 64);
-        if ((cw.taps == 1 && (b64 <= 40 || (b64 >= 200 && b64 <= 300))) || (cw.taps == 9 && b64 <= 40)) tile = IGEMM_S_32x32;
     }
     // 64x64 tiles of a launch that leaves the chip mostly empty (at most ~2.5 blocks per CU: the FPN and pointwise layers of
     // a batch-1 forward): the instance with two register sets, loads three K-steps ahead.  In the network these launches'
@@ -140,11 +132,11 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
         if (pin >= 0) deep = pin != 0;
         if (deep) tile = IGEMM_64x64D;
     }
-    const bool lat = igemm_is_lat(tile), sml = igemm_is_s(tile);
-    a.n_tiles_n = a.CoutPad / (tile == IGEMM16_TILE ? 256 : (lat ? igemm_lat_bn(tile) : (sml ? igemm_s_bn(tile) : igemm_tile_bn(tile))));
+    const bool lat = igemm_is_lat(tile);
+    a.n_tiles_n = a.CoutPad / (tile == IGEMM16_TILE ? 256 : (lat ? igemm_lat_bn(tile) : igemm_tile_bn(tile)));
     a.dN = ssd_udiv_make((unsigned)a.n_tiles_n);
     int tiles = 0;
-    const int BM = tile == IGEMM16_TILE ? 256 : (lat ? igemm_lat_bm(tile) : (sml ? igemm_s_bm(tile) : igemm_tile_bm(tile)));
+    const int BM = tile == IGEMM16_TILE ? 256 : (lat ? igemm_lat_bm(tile) : igemm_tile_bm(tile));
     for (size_t i = 0; i < lv.size(); ++i) {
         a.lv[i].tile_begin = tiles;
         tiles += (a.lv[i].M + BM - 1) / BM;
@@ -155,7 +147,6 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
     op.bytes = inb + rows * cw.Cout_l * 4.0 + (double)cw.taps * cw.Cin_l * cw.Cout_l * 4.0;
     op.run = [a, tile, tiles](hipStream_t s) {
         if (tile == IGEMM16_TILE) return launch_igemm16(a, tiles, s);
-        if (igemm_is_s(tile)) return launch_igemm_s(tile, a, tiles, s);
         return igemm_is_lat(tile) ? launch_igemm_lat(tile, a, tiles, s) : launch_igemm(tile, a, tiles, s);
     };
     return op;
@@ -853,12 +844,13 @@ int make_plans(ssd_handle *h, int B, int H, int W)
         h->plans.push_back(pl);
         if (k > 0) HIPCHK(hipStreamCreateWithFlags(&pl->s_main, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&pl->s_aux, hipStreamNonBlocking));
-        {   // option side_priority = 1: the third / fourth stream (fpn p6 -> p7 at batch 1) at the lowest dispatch priority, so
-            // that its waves yield to the lateral chain they run beside (measurement: DESIGN section 8)
+        {   // option side_priority: the third / fourth stream (fpn p6 -> p7 at batch 1) at the lowest (1) / highest (2) dispatch
+            // priority (measurements: DESIGN section 8)
             int least = 0, greatest = 0;
-            const bool low = ssd_opt(h, OPT_SIDE_PRIORITY, 0) == 1 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+            const int want = ssd_opt(h, OPT_SIDE_PRIORITY, 0);          // 1: lowest, 2: highest
+            const bool have = (want == 1 || want == 2) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
             for (int i = 0; i < 2; ++i) {
-                if (low) HIPCHK(hipStreamCreateWithPriority(&pl->s_bb[i], hipStreamNonBlocking, least));
+                if (have) HIPCHK(hipStreamCreateWithPriority(&pl->s_bb[i], hipStreamNonBlocking, want == 1 ? least : greatest));
                 else HIPCHK(hipStreamCreateWithFlags(&pl->s_bb[i], hipStreamNonBlocking));
             }
         }

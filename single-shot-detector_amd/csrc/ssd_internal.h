@@ -67,6 +67,7 @@ struct IgemmLevel {
 struct IgemmArgs {
     const float *in;
     const float *wt;       // [taps][CoutPad][Cin] physical-k order (transposed weights)
+    const float *wt_lat;   // nullable: the same kernel in igemm_lat.hip's lane-order pieces ([tap][CoutPad/16][Cin/32][2][64 lanes][4])
     float *out;
     float *out2;           // optional second output = relu(raw accumulator) (fpn p6 -> p7 input)
     const float *mean, *sf, *beta;  // batch norm (nullable as a group)
@@ -109,12 +110,6 @@ int igemm_lat_bm(int tile);
 int igemm_lat_bn(int tile);
 bool igemm_lat_supports(const IgemmArgs &a);
 hipError_t launch_igemm_lat(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s);
-// igemm_s.hip: small LDS-staged tiles on v_mfma_f32_16x16x4_f32 (BM positions x BN channels); tile_begin counts BM-row tiles
-enum IgemmSTile { IGEMM_S_32x32 = 30, IGEMM_S_32x64 = 31, IGEMM_S_64x32 = 32, IGEMM_S_64x64 = 33 };
-static inline bool igemm_is_s(int tile) { return tile >= IGEMM_S_32x32 && tile <= IGEMM_S_64x64; }
-int igemm_s_bm(int tile);
-int igemm_s_bn(int tile);
-hipError_t launch_igemm_s(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s);
 // igemm16.hip: 256 x 256 tiles, one block per CU, S16 in / S16 out with batch norm (towers, FPN outputs);
 // tile_begin of the levels counts 256-row tiles, n_tiles_n = CoutPad / 256
 #define IGEMM16_TILE 100

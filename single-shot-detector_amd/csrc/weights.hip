@@ -68,6 +68,23 @@ int pack_conv(const ssd_handle *h, DevPool &pool, const float *w, int k, int Cin
                 if (inmap[p] >= 0) dst[p] = w[((size_t)tap * Cin_l + inmap[p]) * Cout_l + outmap[n]];
         }
     SSDCHK(pool.upload(&cw.wt, t));
+    {   // igemm_lat.hip: per (tap, 16-channel tile, K-step of 32 channels) two 1-KB pieces in MFMA lane order -- lane
+        // (i = l & 15, kk = l >> 4) holds the weights of channel row i for k = 4 t + kk, t = 4 hf .. 4 hf + 3
+        const int KC = cw.CinP / 32, NT = cw.CoutPad / 16;
+        std::vector<float> wl(t.size());
+        for (int tap = 0; tap < cw.taps; ++tap)
+            for (int ct = 0; ct < NT; ++ct)
+                for (int kc = 0; kc < KC; ++kc)
+                    for (int hf = 0; hf < 2; ++hf)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 4; ++e) {
+                                const int i = l & 15, kk = l >> 4, cl = 4 * (4 * hf + e) + kk;      // logical channel within the K-step
+                                const int phys = kc * 32 + ssd_phys_of_logical(cl);
+                                wl[((((size_t)(tap * NT + ct) * KC + kc) * 2 + hf) * 64 + l) * 4 + e] =
+                                    t[((size_t)tap * cw.CoutPad + ct * 16 + i) * cw.CinP + phys];
+                            }
+        SSDCHK(pool.upload(&cw.wlat, wl));
+    }
     // split-fp16 rows of w * 2^s (igemm.hip "S16"): per octet of 8 input channels 8 halves h, then 8 halves
     // l = f16(w*2^s - h).  s puts the largest magnitude into [2^8, 2^9): every l of a weight within 2^-10 of
     // the largest is a normal half, and the scale is undone exactly in the epilogue (acc * 2^-s).
@@ -332,7 +349,7 @@ static int finalize_fpn_heads(ssd_handle *h)
         // convolutions run as ONE launch whose levels carry their own kernel offset (plan.hip, IgemmLevel::wt_off)
         ConvW &g = h->pgroup;
         g = h->pconv[0];
-        g.wt16 = g.wt16w = nullptr;         // (exact fp32 only: the split-fp16 packs carry a per-convolution scale)
+        g.wt16 = g.wt16w = g.wlat = nullptr;   // (exact fp32, 64x64 tiles only: the split-fp16 packs carry a per-convolution scale)
         const size_t wn = (size_t)g.taps * g.CoutPad * g.CinP, pn = (size_t)g.CoutP;
         if (h->pconv[1].CoutPad != g.CoutPad || h->pconv[2].CoutPad != g.CoutPad || h->pconv[1].CinP != g.CinP || h->pconv[2].CinP != g.CinP)
             return ssd_fail(SSD_ERR_WEIGHT, "fpn p3 / p4 / p5 kernels differ in shape");

@@ -138,8 +138,8 @@ def test_sub_batch_plans(cuda, ssd, oracle_graph, libopt):
 @pytest.mark.parametrize("H,W,B", [(256, 384, 1), (640, 896, 1), (256, 256, 2)])
 def test_small_batch_plan_variants_are_bit_identical(cuda, ssd, oracle_graph, H, W, B):
     """The batch-1 / batch-2 plan (round 3) picks other kernels and another launch structure than the serving plan: the
-    latency form of the implicit GEMM for fpn p6 / p7 (igemm_lat.hip), 32x32 tiles on v_mfma_f32_16x16x4_f32 for mid-size 1x1
-    layers (igemm_s.hip), fpn p3 + p4 + p5 as one grouped launch, 64x64 tiles with deep prefetch.  Every one of them is
+    latency form of the implicit GEMM on v_mfma_f32_16x16x4_f32 for tiny launches (fpn p6 / p7, lateral5: igemm_lat.hip), fpn
+    p3 + p4 + p5 as one grouped launch, 64x64 tiles with deep prefetch.  Every one of them is
     bit-identical to what it replaces by construction (the same k-ordered fmaf chain per output): switching each off, all of
     them off, or everything onto one stream changes no bit of any retained tensor or output -- and the default equals the
     oracle."""
@@ -163,8 +163,8 @@ def test_small_batch_plan_variants_are_bit_identical(cuda, ssd, oracle_graph, H,
         assert all(np.array_equal(a, ref[k]) for a, k in zip(base_out, ("boxes", "labels", "scores", "num_boxes")))
         for n in names:
             assert np.array_equal(base_t[n], keep[n].reshape(base_t[n].shape)), n
-    variants = [{"igemm_lat": 0}, {"igemm_small": 0}, {"fpn_group": 0}, {"igemm_deep64": 0}, {"streams": 1}, {"head_serial": 1},
-                {"side_priority": 1}, {"igemm_lat": 0, "igemm_small": 0, "fpn_group": 0, "igemm_deep64": 0}]
+    variants = [{"igemm_lat": 0}, {"fpn_group": 0}, {"igemm_deep64": 0}, {"streams": 1}, {"head_serial": 1}, {"side_priority": 1},
+                {"side_priority": 2}, {"igemm_tile": 20}, {"igemm_lat": 0, "fpn_group": 0, "igemm_deep64": 0}]
     for v in variants:
         for k, val in v.items():
             eng.set_option(k, val)
