@@ -11,7 +11,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 ssd_amd._lib.use_diag()        # libssd_hip_diag.so: the -DSSD_DIAG build (include/ssd_hip_diag.h)
 L = ssd_amd.lib()
 TILES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "128x256", 4: "256x128", 5: "64x64", 6: "128x96",
-         20: "lat 1x1", 21: "lat 1x2", 22: "lat 2x1", 23: "lat 2x2", 7: "64x64 deep", -1: "auto"}
+         20: "lat 1x1", 21: "lat 1x2", 22: "lat 2x1", 23: "lat 2x2", 24: "lat w2 1x1", 25: "lat w4 1x1", 26: "lat w4 2x1",
+         27: "lat w4 1x2", 7: "64x64 deep", -1: "auto"}
 
 
 def run(name, H, W, Cin, Cout, k, stride, tiles, pyramid=0, reps=10):
@@ -39,7 +40,8 @@ run("pw 1024->1024 20x28", 20, 28, 1024, 1024, 1, 1, [0, 1, 5])
 
 # the latency form (igemm_lat.hip: 16x16x4 MFMA, one wave per block) against the 64x64-tile kernel on the small launches of a batch-1 / batch-2 forward
 if B <= 4:
-    LAT = [5, 7, 20, 21, 22, 23, -1]
+    LAT = [5, 7, 20, 21, 22, 23, 24, 25, 26, 27, -1]
+    run("boxes 3x3 256->24 5 levels", 80, 112, 256, 24, 3, 1, [2, 20, 21, 22, 23], pyramid=1)
     run("fpn p6 3x3 s2 1024->256 20x28", 20, 28, 1024, 256, 3, 2, LAT)
     run("fpn p7 3x3 s2 256->256 10x14", 10, 14, 256, 256, 3, 2, LAT)
     run("fpn p5 3x3 256->256 20x28", 20, 28, 256, 256, 3, 1, LAT)
@@ -53,5 +55,5 @@ if B <= 4:
     run("pw 512->1024 20x28", 20, 28, 512, 1024, 1, 1, LAT)
     run("pw 1024->1024 20x28", 20, 28, 1024, 1024, 1, 1, LAT)
     run("pw 256->256 80x112", 80, 112, 256, 256, 1, 1, LAT)
-    run("tower 3x3 256->256 5 levels", 80, 112, 256, 256, 3, 1, [5, 23, 21], pyramid=1)
+    run("tower 3x3 256->256 5 levels", 80, 112, 256, 256, 3, 1, [5, 7, 23, 21, 25, 26, 27], pyramid=1)
     run("logits 3x3 256->480 5 levels", 80, 112, 256, 480, 3, 1, [6, 23], pyramid=1)

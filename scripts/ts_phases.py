@@ -1,5 +1,5 @@
 """Per-block phase timestamps of the 128x128 implicit-GEMM kernel (diagnostic tile id 17).
-usage: python scripts/ts_phases.py H W Cin Cout k [B] [pyramid]
+usage: python scripts/ts_phases.py H W Cin Cout k [B] [pyramid] [tile id: 17 = 128x128 (default), 18 = 64x64]
 Phases (100 MHz wall clock, thread 0 of each block): start -> first stage in LDS -> K loop done ->
 accumulators transposed in LDS -> last store issued."""
 import ctypes, os, sys
@@ -12,17 +12,18 @@ from ssd_amd._lib import check
 H, W, Cin, Cout, k = [int(v) for v in sys.argv[1:6]]
 B = int(sys.argv[6]) if len(sys.argv) > 6 else 32
 pyr = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+TILE = int(sys.argv[8]) if len(sys.argv) > 8 else 17
 path = "/tmp/ts_dump.bin"
 os.environ["SSD_TS_DUMP"] = path
 ssd_amd._lib.use_diag()        # libssd_hip_diag.so: the -DSSD_DIAG build (include/ssd_hip_diag.h)
 L = ssd_amd.lib()
 ms, gf = ctypes.c_double(), ctypes.c_double()
-check(L.ssd_bench_conv(B, H, W, Cin, Cout, k, 1, 17, 3, pyr, ctypes.byref(ms), ctypes.byref(gf)))
+check(L.ssd_bench_conv(B, H, W, Cin, Cout, k, 1, TILE, 3, pyr, ctypes.byref(ms), ctypes.byref(gf)))
 t = np.fromfile(path, dtype=np.int64).reshape(-1, 9)
 st = t[:, :5].astype(np.float64) * 0.01          # us
 span = st[:, 4].max() - st[:, 0].min()
-print("%dx%d %d->%d k%d B=%d: %.3f ms/launch (events), %d blocks, span of last launch %.1f us" %
-      (H, W, Cin, Cout, k, B, ms.value, len(t), span))
+print("%dx%d %d->%d k%d B=%d%s tile %s: %.3f ms/launch (events), %d blocks, span of last launch %.1f us" %
+      (H, W, Cin, Cout, k, B, " pyramid" if pyr else "", "128x128" if TILE == 17 else "64x64", ms.value, len(t), span))
 names = ["prologue (offsets, 2 gloads, first stage in LDS)", "K loop", "acc -> LDS transpose", "BN/act + stores issued"]
 ep = t[:, 5:8].astype(np.float64) * 0.01
 print("   inside the last phase: parameters arrived +%.2f us, first row stored +%.2f us, half the rows +%.2f us (means, from the transpose mark)" %

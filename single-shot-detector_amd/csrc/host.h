@@ -50,6 +50,7 @@ enum SsdOpt {
     OPT_FPN_GROUP,          // -1 auto | 0 | 1: fpn p3 + p4 + p5 as one grouped launch (exact fp32)
     OPT_HEAD_SERIAL,        // -1 auto | 0 | 1: the box head behind the class logits on one stream instead of beside them
     OPT_SIDE_PRIORITY,      // 0 (default) | 1: the plan's third / fourth stream at the lowest dispatch priority
+    OPT_FPN_P6_FIRST,       // 0 | 1: the grouped p3+p4+p5 launch waits for fpn p6 (batch 1: p6 is not starved beside it)
     OPT_COUNT
 };
 #define SSD_OPT_UNSET INT_MIN

@@ -358,6 +358,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     };
     {
         int ks = 0;                                   // K-steps 0 .. KS-2 stage their successor; step ks reads stage ks & 1
+        // (Measured and not kept, batch 1: the waves that share a SIMD -- one per co-resident block, all started together -- do
+        //  not advance alike (K-loop times of the blocks of a tower launch 75 .. 115 us, profiles/r03_tower_phases_b1.log) and the
+        //  last ones finish alone on their SIMDs.  s_setprio 3 -> 0 as a wave's K loop advances, so that the arbiter favours
+        //  whichever wave is behind: 1.745 -> 1.770 ms per forward, one stream 1.782 -> 1.786.)
         for (; ks + 2 <= KS - 1; ks += 2) {
             kstep(std::integral_constant<int, 0>{});
             kstep(std::integral_constant<int, 1>{});
@@ -729,13 +733,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     }
 }
 
-int igemm_tile_bm(int tile) { return tile == IGEMM_256x128 ? 256 : ((tile == IGEMM_64x64 || tile == IGEMM_64x64D) ? 64 : 128); }
+int igemm_tile_bm(int tile) { return tile == IGEMM_256x128 ? 256 : ((tile == IGEMM_64x64 || tile == IGEMM_64x64D || tile == 18) ? 64 : 128); }
 int igemm_tile_bn(int tile)
 {
     switch (tile) {
     case IGEMM_128x256: return 256;
     case IGEMM_128x128: case IGEMM_256x128: return 128;
-    case IGEMM_128x64: case IGEMM_64x64: case IGEMM_64x64D: return 64;
+    case IGEMM_128x64: case IGEMM_64x64: case IGEMM_64x64D: case 18: return 64;
     case IGEMM_128x96: return 96;
     case IGEMM_128x32: return 32;
     default: return 128;   // diagnostic variants of 128x128
@@ -781,7 +785,7 @@ hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStre
     // host-side shape checks: the kernel assumes them
     // widths that are not a multiple of 4 take per-element stores; the vector forms need aligned rows
     if (a.Cout % 4 != 0 && (a.mean || a.res || a.out2)) return hipErrorInvalidValue;
-    if (a.Cin % 32 != 0 || a.CoutPad % igemm_tile_bn(tile >= 10 ? 0 : tile) != 0 || (a.taps != 1 && a.taps != 9)) return hipErrorInvalidValue;
+    if (a.Cin % 32 != 0 || a.CoutPad % igemm_tile_bn(tile) != 0 || (a.taps != 1 && a.taps != 9)) return hipErrorInvalidValue;
     // 32-bit byte offsets inside buffer resources: every tensor of a launch stays < 2 GiB
     if ((long long)a.taps * a.CoutPad * a.Cin * 4 >= (1LL << 31)) return hipErrorInvalidValue;
     for (int i = 0; i < a.nlevels; ++i)
@@ -797,7 +801,7 @@ hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStre
     if (a.in_fmt && tile >= 10) return hipErrorInvalidValue;
     for (int i = 0; i < a.nlevels; ++i)     // 32-bit byte offsets in the epilogue's buffer stores, relative to the level's base
         if ((long long)a.B * a.lv[i].out_bstride * 4 >= (1LL << 31) || a.lv[i].out_bstride < 0) return hipErrorInvalidValue;
-    if (a.n_tiles_n * igemm_tile_bn(tile >= 10 ? 0 : tile) != a.CoutPad || a.nlevels < 1 || a.nlevels > SSD_MAX_LEVELS) return hipErrorInvalidValue;
+    if (a.n_tiles_n * igemm_tile_bn(tile) != a.CoutPad || a.nlevels < 1 || a.nlevels > SSD_MAX_LEVELS) return hipErrorInvalidValue;
     switch (tile) {
     case IGEMM_128x128: return launch_t<2, 2, 2, 2>(a, total_tiles_m, s);
     case IGEMM_128x64: return launch_t<4, 1, 1, 2>(a, total_tiles_m, s);
@@ -810,6 +814,7 @@ hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStre
     case 11: return launch_t<2, 2, 2, 2, 2>(a, total_tiles_m, s);
     case 12: return launch_t<2, 2, 2, 2, 3>(a, total_tiles_m, s);
     case 17: return launch_t<2, 2, 2, 2, 7>(a, total_tiles_m, s);
+    case 18: return launch_t<2, 2, 1, 1, 7>(a, total_tiles_m, s);      // phase stamps of the 64x64 tile
 #endif
     }
     return hipErrorInvalidValue;

@@ -37,17 +37,24 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int PT, int CT, int TAPS, int D>
-__global__ __launch_bounds__(64) void igemm_lat_kernel(const IgemmArgs a)
+template <int PT, int CT, int TAPS, int D, int WB>
+__global__ __launch_bounds__(64 * WB) void igemm_lat_kernel(const IgemmArgs a)
 {
     static_assert(D == 2 || D == 4 || D == 8, "the loop is unrolled over D register sets and two LDS stages");
+    static_assert(WB == 1 || WB == 2 || WB == 4, "waves per block");
     // (Beside a launch that saturates the matrix pipe -- fpn p6 beside the grouped p3+p4+p5 launch -- this kernel's dependent
     //  32-cycle MFMAs queue behind the other waves' 64-cycle ones: p6 59 us alone, 172 us there, with or without s_setprio 3,
     //  4 or 8 K-steps of loads in flight, a high-priority stream: DESIGN section 8.)
-    constexpr int BM = PT * 16, BN = CT * 16;
-    constexpr int NX = 2 * PT;                    // position loads per K-step: 8 rows x 128 B each
+    // WB > 1 (the form for launches of a few blocks per CU): WB waves share the block's PT x 16 positions -- each loads its
+    // share of the rows, the LDS image is the block's, one barrier per K-step between its write and its reads -- and each
+    // wave owns CT x 16 of the block's WB x CT x 16 channels (weights stay per wave, straight into registers).  Per MFMA a
+    // quarter to a half of the one-wave form's operand traffic, the same 16x16 granularity.
+    constexpr int BM = PT * 16, BNW = CT * 16, BN = WB * BNW;
+    constexpr int NXB = 2 * PT;                   // position loads per K-step and block: 8 rows x 128 B each
+    constexpr int NX = (NXB + WB - 1) / WB;       // ... per wave: load j of wave w is the block's load w + WB * j
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PT * 2048];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = WB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 
     // blocks b, b+8, ... share an XCD: consecutive tiles (the channel tiles of one position tile first) per XCD
     int swz;
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(64) void igemm_lat_kernel(const IgemmArgs a)
         if (l < a.nlevels && tile_m >= a.lv[l].tile_begin) lvl = l;
     const IgemmLevel L = a.lv[lvl];
     const int H = L.H, W = L.W, OW = L.OW, M = L.M, P = L.OH * L.OW, Cin = a.Cin;
-    const int m0 = (tile_m - L.tile_begin) * BM, n0 = tile_n * BN;
+    const int m0 = (tile_m - L.tile_begin) * BM, n0 = tile_n * BN + wave * BNW;
     const int KC = Cin >> 5, KS = TAPS * KC;
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -73,14 +80,17 @@ __global__ __launch_bounds__(64) void igemm_lat_kernel(const IgemmArgs a)
         (void *)(a.wt_lat + L.wt_off), 0, (int)((long long)TAPS * a.CoutPad * Cin * 4), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
-    // ---- positions: load u covers rows 8 u + (lane >> 3), chunk lane & 7
+    // ---- positions: the block's load ub covers rows 8 ub + (lane >> 3), chunk lane & 7
     int xbase[NX];
     unsigned xmask[NX];
     int woff_lo[NX], woff_hi[NX];
+    bool xact[NX];                                // (wave-uniform) this wave has a j-th load
     const bool dense1x1 = TAPS == 1 && a.stride == 1 && a.pad == 0 && L.OH == H && OW == W;
 #pragma unroll
     for (int u = 0; u < NX; ++u) {
-        const int r = 8 * u + (lane >> 3), c = lane & 7;
+        const int ub = wave + WB * u;
+        xact[u] = WB == 1 || ub < NXB;
+        const int r = (8 * ub + (lane >> 3)) & (BM - 1), c = lane & 7;
         const int m = m0 + r;
         const bool rowok = m < M;
         const int mm = rowok ? m : 0;
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(64) void igemm_lat_kernel(const IgemmArgs a)
                 wr[S][c][hf] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wbase[c] + hf * 1024, wso, 0));
 #pragma unroll
         for (int u = 0; u < NX; ++u)
-            xr[S][u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)offc[u], so, 0));
+            if (xact[u]) xr[S][u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)offc[u], so, 0));
         if (++kload < KS) {          // advance the load stream (past the end the counters stay put: valid memory is re-read)
             if (++lkc == KC) {
                 lkc = 0;
@@ -156,10 +166,11 @@ __global__ __launch_bounds__(64) void igemm_lat_kernel(const IgemmArgs a)
         constexpr int S = decltype(set_tag)::value;
         unsigned char *base = lds + stage * (PT * 2048);
 #pragma unroll
-        for (int u = 0; u < NX; ++u) {
-            *(v2f *)(base + woff_lo[u]) = v2f{xr[S][u][0], xr[S][u][2]};
-            *(v2f *)(base + woff_hi[u]) = v2f{xr[S][u][1], xr[S][u][3]};
-        }
+        for (int u = 0; u < NX; ++u)
+            if (xact[u]) {
+                *(v2f *)(base + woff_lo[u]) = v2f{xr[S][u][0], xr[S][u][2]};
+                *(v2f *)(base + woff_hi[u]) = v2f{xr[S][u][1], xr[S][u][3]};
+            }
     };
     v4f xf[2][PT][2];                // fragments by LDS stage
     auto lread = [&](auto stage_tag) __attribute__((always_inline)) {
@@ -193,6 +204,8 @@ __global__ __launch_bounds__(64) void igemm_lat_kernel(const IgemmArgs a)
     auto kstep = [&](auto set_tag) __attribute__((always_inline)) {
         constexpr int S = decltype(set_tag)::value, N = (S + 1) % D;
         lstore((S + 1) & 1, std::integral_constant<int, N>{});
+        if constexpr (WB > 1) __syncthreads();    // every wave's rows of the stage are written; its previous readers passed the
+                                                  // barrier of the step before with their reads complete
         lread(std::integral_constant<int, (S + 1) & 1>{});
         __builtin_amdgcn_sched_barrier(0);
         mfmas(set_tag);
@@ -209,6 +222,7 @@ __global__ __launch_bounds__(64) void igemm_lat_kernel(const IgemmArgs a)
     };
     for_sets([&](auto s) __attribute__((always_inline)) { gload(s); });
     lstore(0, std::integral_constant<int, 0>{});
+    if constexpr (WB > 1) __syncthreads();
     lread(std::integral_constant<int, 0>{});
     int ks = 0;
     for (; ks + D <= KS; ks += D) for_sets([&](auto s) __attribute__((always_inline)) { kstep(s); });
@@ -220,16 +234,24 @@ __global__ __launch_bounds__(64) void igemm_lat_kernel(const IgemmArgs a)
     epilogue_16x16<PT, CT>(a, L, acc, m0, n0, lane);
 }
 
-int igemm_lat_bm(int tile) { return (tile == IGEMM_LAT_2x1 || tile == IGEMM_LAT_2x2) ? 32 : 16; }
-int igemm_lat_bn(int tile) { return (tile == IGEMM_LAT_1x2 || tile == IGEMM_LAT_2x2) ? 32 : 16; }
+int igemm_lat_bm(int tile) { return (tile == IGEMM_LAT_2x1 || tile == IGEMM_LAT_2x2 || tile == IGEMM_LAT_W4_2x1) ? 32 : 16; }
+int igemm_lat_bn(int tile)
+{
+    switch (tile) {
+    case IGEMM_LAT_1x2: case IGEMM_LAT_2x2: case IGEMM_LAT_W2_1x1: return 32;
+    case IGEMM_LAT_W4_1x1: case IGEMM_LAT_W4_2x1: return 64;
+    case IGEMM_LAT_W4_1x2: return 128;
+    default: return 16;
+    }
+}
 
-template <int PT, int CT, int D>
+template <int PT, int CT, int D, int WB = 1>
 static hipError_t launch_l(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 {
     const long long nblk = (long long)total_tiles_m * a.n_tiles_n;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (a.taps == 9) hipLaunchKernelGGL((igemm_lat_kernel<PT, CT, 9, D>), dim3((unsigned)nblk), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((igemm_lat_kernel<PT, CT, 1, D>), dim3((unsigned)nblk), dim3(64), 0, s, a);
+    if (a.taps == 9) hipLaunchKernelGGL((igemm_lat_kernel<PT, CT, 9, D, WB>), dim3((unsigned)nblk), dim3(64 * WB), 0, s, a);
+    else hipLaunchKernelGGL((igemm_lat_kernel<PT, CT, 1, D, WB>), dim3((unsigned)nblk), dim3(64 * WB), 0, s, a);
     return hipGetLastError();
 }
 
@@ -262,6 +284,10 @@ hipError_t launch_igemm_lat(int tile, const IgemmArgs &a, int total_tiles_m, hip
     case IGEMM_LAT_1x2: return launch_l<1, 2, 4>(a, total_tiles_m, s);
     case IGEMM_LAT_2x1: return launch_l<2, 1, 4>(a, total_tiles_m, s);
     case IGEMM_LAT_2x2: return launch_l<2, 2, 2>(a, total_tiles_m, s);
+    case IGEMM_LAT_W2_1x1: return launch_l<1, 1, 4, 2>(a, total_tiles_m, s);
+    case IGEMM_LAT_W4_1x1: return launch_l<1, 1, 4, 4>(a, total_tiles_m, s);
+    case IGEMM_LAT_W4_2x1: return launch_l<2, 1, 4, 4>(a, total_tiles_m, s);
+    case IGEMM_LAT_W4_1x2: return launch_l<1, 2, 4, 4>(a, total_tiles_m, s);
     }
     return hipErrorInvalidValue;
 }

@@ -98,14 +98,13 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
         rows += L.M;
         inb += (double)B * L.H * L.W * cw.Cin_l * 4.0;
     }
-    // Tiny launches in exact fp32 (batch 1-2: fpn p6 and p7 -- 140 and 35 positions per image): the latency form of
-    // igemm_lat.hip -- v_mfma_f32_16x16x4_f32 (a quarter of the 32x32x2 accumulator's chain latency, 16x16 tiles: sixteen
-    // times the independent chains of a 64x64 tile), one wave per block, no LDS.  Same bits.  Measured at batch 1
-    // (profiles/r03_conv_latency_form.log, alone on the chip): p6 141 -> 66 us, p7 38 -> 19 us; every LARGER launch is
-    // slower on it (p5 39 -> 42 .. 53, p4 42 -> 102, pointwise 512 -> 512 22 -> 46, p3 117 -> 385 us): each wave fetches
-    // its own operands in fragment shape, ~70 cycles per 1-KB load instruction, and only a launch of at most one or two
-    // waves per CU keeps that under its MFMA chain.  Option igemm_lat = 0 switches the form off, igemm_tile = 20 .. 23
-    // pins a wave tile wherever the form applies (tests run every shape on all four).
+    // Small launches in exact fp32 (batch 1-2): the latency form of igemm_lat.hip -- v_mfma_f32_16x16x4_f32 (a quarter of the
+    // 32x32x2 accumulator's chain latency, 16x16 tiles: sixteen times the independent chains of a 64x64 tile).  Same bits.
+    //   one wave per block   fpn p6 / p7 / lateral5 (140, 35, 560 positions per image): alone p6 141 -> 57 us, p7 38 -> 17,
+    //                        lateral5 20 -> 10 (profiles/r03_conv_latency_form.log)
+    //   four waves per block 1x1 launches of one or two 64x64 tiles per CU, below
+    // Option igemm_lat = 0 switches the form off, igemm_tile = 20 .. 27 pins a tile wherever the form applies (tests run
+    // every shape on all of them).
     if (igemm_is_lat(tile)) {            // (diagnostics: ssd_bench_conv asked for this wave tile)
         if (!igemm_lat_supports(a) || cw.CoutPad % igemm_lat_bn(tile) || !a.wt_lat) tile = IGEMM_128x128;
     } else if (tile != IGEMM16_TILE && g_force_tile < 0 && igemm_lat_supports(a)) {
@@ -118,16 +117,26 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
                 b64 += (((long long)a.lv[i].M + 63) / 64) * ((cw.CoutPad + 63) / 64);
             }
             if ((waves <= 320 || b64 <= 40) && a.wt_lat) tile = IGEMM_LAT_1x1;
+            // 1x1 launches of one or two 64x64 tiles per CU (batch 1-2: MobileNet pointwise Conv2d_5 .. 13, laterals 3 and 4): the
+            // tiles do not divide over the 256 CUs -- 280 of a 512 -> 512 layer at 40x56: 24 CUs run two, the launch takes two
+            // tile times -- and a CU's one block per SIMD covers none of its own waits (0.75 of the matrix pipe in its K loop,
+            // profiles/r03_tower_phases_b1.log).  The four-wave block form of igemm_lat.hip, 16 x 64 per block: 16x16 granularity,
+            // 4.4 waves per SIMD.  Alone 22 -> 18 us per launch (profiles/r03_conv_latency_form.log); batch-1 forward
+            // 1.735 -> 1.690 ms, batch 2 3.10 -> 3.06 ms (profiles/r03_batch1_option_ab.log).
+            else if (a.wt_lat && cw.CoutPad % 64 == 0 && cw.taps == 1 && cw.CinP >= 256 && b64 <= (ssd_opt(h, OPT_IGEMM_LAT, 1) >= 2 ? 1280 : 640))
+                tile = IGEMM_LAT_W4_1x1;
+            // (The box head -- 3x3, 24 of 32 columns, 96 tiles of 128x32 at batch 1 -- is NOT such a launch: 1 492 / 746 waves of
+            //  16x16 / 16x32 took 73 / 66 us against the 128x32 tiles' 41 us, profiles/r03_conv_latency_form.log.)
         }
     }
-    // 64x64 tiles of a launch that leaves the chip mostly empty (at most ~2.5 blocks per CU: the FPN and pointwise layers of
-    // a batch-1 forward): the instance with two register sets, loads three K-steps ahead.  In the network these launches'
+    // 64x64 tiles of a launch of a few blocks per CU (the FPN, pointwise and tower layers of a batch-1 / batch-2 forward):
+    // the instance with two register sets, loads three K-steps ahead.  In the network these launches'
     // operands come from HBM / the Infinity Cache (57 MB of weights pass between two uses of a layer's), and a K-step of
     // 0.43 us of MFMA work with loads issued 3/4 of a step ahead waits for them.  Option igemm_deep64 = 0 / 1 pins it.
     if (tile == IGEMM_64x64 && !in_fmt && g_force_tile < 0) {
         long long b64 = 0;
         for (size_t i = 0; i < lv.size(); ++i) b64 += (((long long)a.lv[i].M + 63) / 64) * (cw.CoutPad / 64);
-        bool deep = b64 <= 640;
+        bool deep = b64 <= 2048;     // (up to the tower launches of a batch-2 forward: those of batch 1 gain 1 %)
         const int pin = ssd_opt(h, OPT_IGEMM_DEEP64, -1);
         if (pin >= 0) deep = pin != 0;
         if (deep) tile = IGEMM_64x64D;
@@ -587,11 +596,11 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     const int s6 = ssd_opt(h, OPT_GRAPH, 0) ? 1 : 2;
     std::vector<int> p6_deps = {id_c5};             // c5 of every backbone chain that is not on p6's own stream
     for (int c = 1; c < 4; ++c) if (c != s6 && id_bb_last[c] >= 0) p6_deps.push_back(id_bb_last[c]);
-    int id_p7;
+    int id_p6, id_p7;
     {   // p6 = conv s2 (c5): BN+ReLU -> P6, ReLU(raw) -> T6 (input of p7, :60)
         LevelDesc d = dense_level(py.h[2], py.w[2], py.h[3], py.w[3], 256);
         d.out_off = py.off[3];
-        push(make_conv_op(h, h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), s6, p6_deps);
+        id_p6 = push(make_conv_op(h, h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), s6, p6_deps);
         LevelDesc d7 = dense_level(py.h[3], py.w[3], py.h[4], py.w[4], 256);
         d7.out_off = py.off[4];
         id_p7 = push(make_conv_op(h, h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true, X16, X16, 0, FL), s6);
@@ -645,7 +654,12 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             d.wt_off = (long long)l * g.taps * g.CoutPad * g.CinP;
             lv3.push_back(d);
         }
-        id_p3 = id_p4 = push(make_conv_op(h, g, X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv3, true), 0);
+        // option fpn_p6_first = 1: the launch waits for p6 (third stream).  p6 is a chain of 2 304 dependent 32-cycle MFMAs; beside
+        // this launch's 64-cycle ones it gets one issue slot in ~7 (59 us alone, ~175 us here) and p7 -> the towers wait for it
+        std::vector<int> gdeps;
+        if (s6 == 2 && ssd_opt(h, OPT_FPN_P6_FIRST, 0) == 1) gdeps.push_back(id_p6);
+        else if (s6 == 2 && ssd_opt(h, OPT_FPN_P6_FIRST, 0) == 2) gdeps.push_back(id_p7);
+        id_p3 = id_p4 = push(make_conv_op(h, g, X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv3, true), 0, gdeps);
         pl.ops[id_p3].fpn_end = true;
     }
     for (int l = 0; l < 5; ++l) {

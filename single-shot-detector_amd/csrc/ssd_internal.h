@@ -104,8 +104,10 @@ int igemm_tile_bn(int tile);
 hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s);
 // igemm_lat.hip: the latency form for small launches (v_mfma_f32_16x16x4_f32, one wave per block, no LDS): wave tile
 // PT x 16 positions by CT x 16 channels; tile_begin of the levels counts PT*16-row tiles, n_tiles_n = CoutPad / (CT*16)
-enum IgemmLatTile { IGEMM_LAT_1x1 = 20, IGEMM_LAT_1x2 = 21, IGEMM_LAT_2x1 = 22, IGEMM_LAT_2x2 = 23 };
-static inline bool igemm_is_lat(int tile) { return tile >= IGEMM_LAT_1x1 && tile <= IGEMM_LAT_2x2; }
+// ..._Wn_: n waves per block share the positions through the block's LDS image; block tile PT x 16 positions by n x CT x 16 channels
+enum IgemmLatTile { IGEMM_LAT_1x1 = 20, IGEMM_LAT_1x2 = 21, IGEMM_LAT_2x1 = 22, IGEMM_LAT_2x2 = 23,
+                    IGEMM_LAT_W2_1x1 = 24, IGEMM_LAT_W4_1x1 = 25, IGEMM_LAT_W4_2x1 = 26, IGEMM_LAT_W4_1x2 = 27 };
+static inline bool igemm_is_lat(int tile) { return tile >= IGEMM_LAT_1x1 && tile <= IGEMM_LAT_W4_1x2; }
 int igemm_lat_bm(int tile);
 int igemm_lat_bn(int tile);
 bool igemm_lat_supports(const IgemmArgs &a);

@@ -423,9 +423,10 @@ extern "C" int ssd_bench_conv(int32_t B, int32_t H, int32_t W, int32_t Cin, int3
         }
         long long *ts = nullptr;
         long long nblk = 0;
-        if (tile == 17) {   // per-block phase timestamps of the last launch -> $SSD_TS_DUMP (int64[nblk][9])
-            for (size_t l = 0; l < lv.size(); ++l) nblk += ((long long)B * lv[l].OH * lv[l].OW + 127) / 128;
-            nblk *= cw.CoutPad / 128;
+        if (tile == 17 || tile == 18) {   // per-block phase timestamps of the last launch -> $SSD_TS_DUMP (int64[nblk][9])
+            const int tb = tile == 17 ? 128 : 64;
+            for (size_t l = 0; l < lv.size(); ++l) nblk += ((long long)B * lv[l].OH * lv[l].OW + tb - 1) / tb;
+            nblk *= cw.CoutPad / tb;
             SSDCHK(pool.alloc((void **)&ts, (size_t)nblk * 9 * 8));
             HIPCHK(hipMemset(ts, 0, (size_t)nblk * 9 * 8));      // kernels with fewer blocks leave zero rows
             g_dbg_ts = ts;

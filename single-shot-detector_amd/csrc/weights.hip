@@ -349,7 +349,9 @@ static int finalize_fpn_heads(ssd_handle *h)
         // convolutions run as ONE launch whose levels carry their own kernel offset (plan.hip, IgemmLevel::wt_off)
         ConvW &g = h->pgroup;
         g = h->pconv[0];
-        g.wt16 = g.wt16w = g.wlat = nullptr;   // (exact fp32, 64x64 tiles only: the split-fp16 packs carry a per-convolution scale)
+        g.wt16 = g.wt16w = nullptr;            // (exact fp32 only: the split-fp16 packs carry a per-convolution scale)
+        const bool have_lat = h->pconv[0].wlat && h->pconv[1].wlat && h->pconv[2].wlat;
+        g.wlat = nullptr;
         const size_t wn = (size_t)g.taps * g.CoutPad * g.CinP, pn = (size_t)g.CoutP;
         if (h->pconv[1].CoutPad != g.CoutPad || h->pconv[2].CoutPad != g.CoutPad || h->pconv[1].CinP != g.CinP || h->pconv[2].CinP != g.CinP)
             return ssd_fail(SSD_ERR_WEIGHT, "fpn p3 / p4 / p5 kernels differ in shape");
@@ -357,7 +359,9 @@ static int finalize_fpn_heads(ssd_handle *h)
         SSDCHK(h->wpool.alloc((void **)&g.mean, 3 * pn * sizeof(float)));
         SSDCHK(h->wpool.alloc((void **)&g.sf, 3 * pn * sizeof(float)));
         SSDCHK(h->wpool.alloc((void **)&g.beta, 3 * pn * sizeof(float)));
+        if (have_lat) SSDCHK(h->wpool.alloc((void **)&g.wlat, 3 * wn * sizeof(float)));
         for (int i = 0; i < 3; ++i) {
+            if (have_lat) HIPCHK(hipMemcpy(g.wlat + i * wn, h->pconv[i].wlat, wn * sizeof(float), hipMemcpyDeviceToDevice));
             HIPCHK(hipMemcpy(g.wt + i * wn, h->pconv[i].wt, wn * sizeof(float), hipMemcpyDeviceToDevice));
             HIPCHK(hipMemcpy(g.mean + i * pn, h->pconv[i].mean, pn * sizeof(float), hipMemcpyDeviceToDevice));
             HIPCHK(hipMemcpy(g.sf + i * pn, h->pconv[i].sf, pn * sizeof(float), hipMemcpyDeviceToDevice));

@@ -59,13 +59,15 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", ["128", "64", "20", "21", "22", "23"])
+@pytest.mark.parametrize("tile", ["128", "64", "20", "21", "22", "23", "24", "25", "26", "27"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
 def test_conv2d(cuda, ssd, oracle_ops, case, tile, libopt):
     # the library picks 64x64 tiles for small problems and 128x128 for large ones: pin each
     # in turn so both kernels see every shape (narrow outputs keep their 128x64 / 128x32 tiles);
     # 20 .. 23: the four wave tiles of the latency form (igemm_lat.hip, v_mfma_f32_16x16x4_f32), which
-    # takes every case whose output rows are 16-byte aligned -- the same bits from all of them
+    # takes every case whose output rows are 16-byte aligned; 24 .. 27: its blocks of two / four waves that share the
+    # positions through LDS (where the padded output width is a multiple of the block's 32 / 64 / 128 channels) -- the
+    # same bits from all of them
     libopt(igemm_tile=int(tile, 0))
     B, H, W, Cin, Cout, k, stride, mode, use_bn, use_bias, act, use_up = case
     rng = np.random.default_rng(100 + CONV_CASES.index(case))
@@ -113,7 +115,7 @@ def test_conv2d_nan_inf(cuda, ssd, oracle_ops, shape, act, libopt):
     with np.errstate(all="ignore"):
         ref = oracle_ops.bn_act(oracle_ops.conv2d(x, w, 1, "SAME"), g, b, m, v, act)
     assert not np.isnan(ref).any() and (ref == 0).any()      # (ReLU keeps +inf; ReLU6 turns it into 6)
-    for tile in (128, 64, 20, 23):
+    for tile in (128, 64, 20, 23, 25):
         libopt(igemm_tile=tile)
         got = ssd.ssd.conv2d(dev(cuda, x), w, 1, "SAME", bn=(m, oracle_ops.bn_scale(g, v), b), act=act).cpu().numpy()
         assert np.array_equal(got, ref), "tile %d: %d of %d values differ" % (tile, int((got != ref).sum()), ref.size)
