@@ -300,6 +300,24 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
     else:
         torch.cuda.set_device(local)
         dev, sync = torch.device("cuda", local), torch.cuda.synchronize
+    for kv in args.option:
+        k, v = kv.split("=", 1)
+        ssd_amd.set_option(k, int(v, 0))
+    B = args.batch
+    total = args.global_batch or B * world
+    Wt = ssd_amd.synthetic_weights(params, seed=0, logits_bias=LOGITS_BIAS[net])
+    detector = None
+    if stub:
+        engine = engine_factory(params, Wt, local)
+    else:       # the boundary class (inference/detector.py:5-60) owns the engine; the throughput legs drive its engine directly
+        detector = ssd_amd.Detector(Wt, visible_device_list=str(local), config=params, precision=args.precision)
+        engine = detector.engine
+        # The engine creates its internal streams with its first forward; HIP maps a new stream onto the least-loaded of a few
+        # hardware queues.  One small forward BEFORE the process group exists gives the engine queues of its own; RCCL's
+        # streams, created later, share whichever (they only run between forwards).  The other order measured 788 instead of
+        # 822 img/s: the class tower's stream on the caller's queue (csrc/plan.hip ssd_side_stream).
+        engine.forward(torch.zeros((1, Hh, Ww, 3), dtype=torch.uint8, device=dev))
+        sync()
     ranks_seen = [0]
     # inside a torch.distributed.run launch (WORLD_SIZE set, also = 1) or with --force-dist the collective path runs
     use_dist = world > 1 or args.force_dist or "WORLD_SIZE" in os.environ
@@ -315,18 +333,6 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
         dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int32, device=dev))
         ranks_seen = [int(v) for v in ids.cpu()]
 
-    for kv in args.option:
-        k, v = kv.split("=", 1)
-        ssd_amd.set_option(k, int(v, 0))
-    B = args.batch
-    total = args.global_batch or B * world
-    Wt = ssd_amd.synthetic_weights(params, seed=0, logits_bias=LOGITS_BIAS[net])
-    detector = None
-    if stub:
-        engine = engine_factory(params, Wt, local)
-    else:       # the boundary class (inference/detector.py:5-60) owns the engine; the throughput legs drive its engine directly
-        detector = ssd_amd.Detector(Wt, visible_device_list=str(local), config=params, precision=args.precision)
-        engine = detector.engine
     # this rank's shard of the global batch, resident in HBM before the timed region
     lo, hi = ssd_amd.shard_range(total, rank, world)
     g = torch.Generator().manual_seed(1234 + rank)

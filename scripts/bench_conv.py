@@ -41,7 +41,7 @@ run("pw 1024->1024 20x28", 20, 28, 1024, 1024, 1, 1, [0, 1, 5])
 # the latency form (igemm_lat.hip: 16x16x4 MFMA, one wave per block) against the 64x64-tile kernel on the small launches of a batch-1 / batch-2 forward
 if B <= 4:
     LAT = [5, 7, 20, 21, 22, 23, 24, 25, 26, 27, -1]
-    run("boxes 3x3 256->24 5 levels", 80, 112, 256, 24, 3, 1, [2, 20, 21, 22, 23], pyramid=1)
+    run("boxes 3x3 256->24 5 levels", 80, 112, 256, 24, 3, 1, [2, 20, 21, 22, 23, 24], pyramid=1)
     run("fpn p6 3x3 s2 1024->256 20x28", 20, 28, 1024, 256, 3, 2, LAT)
     run("fpn p7 3x3 s2 256->256 10x14", 10, 14, 256, 256, 3, 2, LAT)
     run("fpn p5 3x3 256->256 20x28", 20, 28, 256, 256, 3, 1, LAT)

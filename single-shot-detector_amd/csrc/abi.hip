@@ -77,7 +77,6 @@ extern "C" int ssd_create(const ssd_config *cfg, ssd_handle **out)
     ssd_handle *h = new ssd_handle();
     h->cfg = *cfg;
     if (hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_gin, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_gout, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming) != hipSuccess) {
@@ -138,6 +137,7 @@ extern "C" void ssd_destroy(ssd_handle *h)
     for (auto r : h->ref_evs) (void)hipEventDestroy(r);
     for (auto r : h->ev_pool) (void)hipEventDestroy(r);
     free_plans(h);
+    for (hipStream_t st : h->side_streams) if (st) (void)hipStreamDestroy(st);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_gin) (void)hipEventDestroy(h->ev_gin);
     if (h->ev_gout) (void)hipEventDestroy(h->ev_gout);
@@ -198,6 +198,7 @@ static int forward_locked(ssd_handle *h, const uint8_t *images_dev, int32_t B, i
     const bool use_graph = ssd_opt(h, OPT_GRAPH, 0) != 0 && !h->capture_broken;
     if (!use_graph || h->profiling || h->plans.size() != 1)
         return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, s);
+    if (!h->gstream) HIPCHK(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));    // (only a handle that replays graphs has one)
     GraphKey key{images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, B, H, W};
     hipGraphExec_t exec = nullptr;
     for (auto &g : h->graphs)

@@ -170,9 +170,11 @@ void free_plans(ssd_handle *h)
         for (Op &op : pl->ops)
             if (op.done) (void)hipEventDestroy(op.done);
         pl->pool.free_all();
-        if (pl->s_main) (void)hipStreamDestroy(pl->s_main);
-        if (pl->s_aux) (void)hipStreamDestroy(pl->s_aux);
-        for (int i = 0; i < 2; ++i) if (pl->s_bb[i]) (void)hipStreamDestroy(pl->s_bb[i]);
+        if (pl->own_streams) {
+            if (pl->s_main) (void)hipStreamDestroy(pl->s_main);
+            if (pl->s_aux) (void)hipStreamDestroy(pl->s_aux);
+            for (int i = 0; i < 2; ++i) if (pl->s_bb[i]) (void)hipStreamDestroy(pl->s_bb[i]);
+        }
         if (pl->ev_fpn) (void)hipEventDestroy(pl->ev_fpn);
         if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
         if (pl->ev_done) (void)hipEventDestroy(pl->ev_done);
@@ -825,6 +827,29 @@ static hipError_t run_op(ssd_handle *h, const Op &op, hipStream_t s)
     return r;
 }
 
+// The plans' internal streams.  HIP streams share a small pool of hardware queues (4 per process and priority level by
+// default), each new stream joining the least-loaded one, so WHICH queue the class tower's stream gets depends on what the
+// process created before: on the caller's queue it runs behind the box tower instead of beside it (bench.py under
+// torch.distributed, RCCL's streams first: 788 instead of 822 img/s; a second engine in one process: batch-1 forward +30 us).
+// The handle creates its streams once, with its first plan; a process that wants the clean mapping creates its engine (and
+// runs one forward) before other stream-creating libraries -- bench.py does, INTEGRATION.md section 2.
+// Measured and not adopted (profiles/r03_batch1_option_ab.log): streams of the highest priority, whose queues come from a
+// pool of their own (option streams = 2): robust against what the framework created, 815 / 807 img/s plain / under
+// torch.distributed -- but with two engines in a process the second one's batch-1 forward took 2.4 ms instead of 1.64 (more
+// hardware queues than the command processor holds resident; GPU_MAX_HW_QUEUES=8 shows the same cliff at the third engine);
+// a CU-masked stream, which gets a queue of its own, is a BLOCKING stream (hipExtStreamCreateWithCUMask has no flags) and
+// would serialise with the legacy default stream.
+int ssd_side_stream(ssd_handle *h, hipStream_t *out)
+{
+    int least = 0, greatest = 0;
+    if (ssd_opt(h, OPT_STREAMS, 0) == 2 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
+        if (hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest) == hipSuccess) return SSD_OK;
+        (void)hipGetLastError();
+    }
+    HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return SSD_OK;
+}
+
 int make_plans(ssd_handle *h, int B, int H, int W)
 {
     free_plans(h);
@@ -856,16 +881,25 @@ int make_plans(ssd_handle *h, int B, int H, int W)
         const int bk = B / nsub + (k < B % nsub ? 1 : 0);
         Plan *pl = new Plan();
         h->plans.push_back(pl);
-        if (k > 0) HIPCHK(hipStreamCreateWithFlags(&pl->s_main, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&pl->s_aux, hipStreamNonBlocking));
         {   // option side_priority: the third / fourth stream (fpn p6 -> p7 at batch 1) at the lowest (1) / highest (2) dispatch
-            // priority (measurements: DESIGN section 8)
+            // priority (measurements: DESIGN section 8) -- streams of the plan's own; otherwise the handle's
             int least = 0, greatest = 0;
             const int want = ssd_opt(h, OPT_SIDE_PRIORITY, 0);          // 1: lowest, 2: highest
             const bool have = (want == 1 || want == 2) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
-            for (int i = 0; i < 2; ++i) {
-                if (have) HIPCHK(hipStreamCreateWithPriority(&pl->s_bb[i], hipStreamNonBlocking, want == 1 ? least : greatest));
-                else HIPCHK(hipStreamCreateWithFlags(&pl->s_bb[i], hipStreamNonBlocking));
+            if (have) {
+                pl->own_streams = true;
+                if (k > 0) HIPCHK(hipStreamCreateWithFlags(&pl->s_main, hipStreamNonBlocking));
+                HIPCHK(hipStreamCreateWithFlags(&pl->s_aux, hipStreamNonBlocking));
+                for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithPriority(&pl->s_bb[i], hipStreamNonBlocking, want == 1 ? least : greatest));
+            } else {
+                if (h->side_streams.size() < (size_t)4 * (k + 1)) h->side_streams.resize((size_t)4 * (k + 1), nullptr);
+                hipStream_t *ss = &h->side_streams[(size_t)4 * k];
+                for (int i = (k > 0 ? 0 : 1); i < 4; ++i)
+                    if (!ss[i]) SSDCHK(ssd_side_stream(h, &ss[i]));
+                pl->s_main = k > 0 ? ss[0] : nullptr;
+                pl->s_aux = ss[1];
+                pl->s_bb[0] = ss[2];
+                pl->s_bb[1] = ss[3];
             }
         }
         HIPCHK(hipEventCreateWithFlags(&pl->ev_fpn, hipEventDisableTiming));

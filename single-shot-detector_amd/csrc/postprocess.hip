@@ -669,31 +669,59 @@ __global__ __launch_bounds__(256) void post_pack_kernel(const PostArgs p)
 {
     extern __shared__ int pre[];            // C+1 exclusive prefix
     const int b = blockIdx.x, C = p.C, mp = p.max_per_class, T = C * mp;
-    if (threadIdx.x == 0) {
-        int s = 0;
-        for (int c = 0; c < C; ++c) { pre[c] = s; s += p.cls_counts[b * C + c]; }
-        pre[C] = s;
-        p.num[b] = s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // exclusive prefix of the per-class counts: every thread loads a count, waves scan theirs with shuffles, wave 0 adds the
+    // wave totals of each 256-class chunk (one thread walking the 80 counts was 80 dependent loads: 10 us of a batch-1 forward)
+    __shared__ int wtot[4];
+    int carry = 0;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int c = c0 + tid;
+        const int v = c < C ? p.cls_counts[b * C + c] : 0;
+        int inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(inc, off, 64);
+            inc += lane >= off ? o : 0;
+        }
+        if (lane == 63) wtot[tid >> 6] = inc;
+        __syncthreads();
+        int base = carry;
+        for (int w = 0; w < (tid >> 6); ++w) base += wtot[w];
+        if (c < C) pre[c] = base + inc - v;
+        carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
     }
+    if (tid == 0) { pre[C] = carry; p.num[b] = carry; }
     __syncthreads();
     const int total = pre[C];
     float *boxes = p.boxes + (long long)b * T * 4;
     float *scores = p.scores + (long long)b * T;
     int32_t *labels = p.labels + (long long)b * T;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    // rows as 16-byte stores when the box block is 16-byte aligned (always, for the packed output block of ssd.py): the block
+    // may live in pinned HOST memory (Engine.detect_host at small batches), where every partial write is a PCIe transaction
+    const bool vec = ((reinterpret_cast<uintptr_t>(boxes) | reinterpret_cast<uintptr_t>(p.cls_boxes)) & 15) == 0;
+    for (int t = tid; t < T; t += blockDim.x) {
         const int c = t / mp, j = t - c * mp;
         if (j < pre[c + 1] - pre[c]) {
             const int d = pre[c] + j;
             const long long src = (long long)(b * C + c) * mp + j;
+            if (vec) {
+                const v4f q = *(const v4f *)(p.cls_boxes + src * 4);
+                *(v4f *)(boxes + d * 4) = v4f{q[0] / p.box_scaler[0], q[1] / p.box_scaler[1], q[2] / p.box_scaler[2], q[3] / p.box_scaler[3]};
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) boxes[d * 4 + k] = p.cls_boxes[src * 4 + k] / p.box_scaler[k];
+                for (int k = 0; k < 4; ++k) boxes[d * 4 + k] = p.cls_boxes[src * 4 + k] / p.box_scaler[k];
+            }
             scores[d] = p.cls_scores[src];
             labels[d] = c;
         }
     }
-    for (int d = total + threadIdx.x; d < T; d += blockDim.x) {
+    for (int d = total + tid; d < T; d += blockDim.x) {
+        if (vec) *(v4f *)(boxes + d * 4) = v4f{0.f, 0.f, 0.f, 0.f};
+        else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) boxes[d * 4 + k] = 0.0f;
+            for (int k = 0; k < 4; ++k) boxes[d * 4 + k] = 0.0f;
+        }
         scores[d] = 0.0f;
         labels[d] = 0;
     }

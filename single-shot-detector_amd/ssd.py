@@ -256,6 +256,7 @@ class Engine:
         self.T = int(params["num_classes"]) * int(params["max_boxes_per_class"])
         self._static = {}
         self._copy_streams = None
+        self.zero_copy_max_batch = 4     # detect_host: up to this many images the outputs are written straight into pinned host memory
         self.h2d_chunks = 2              # detect_host: pieces of the staging copy + upload (measured: 1 / 2 / 3 / 4 pieces -> p50 1.769 / 1.752 / 1.755 / 1.769 ms)
         self.lock = threading.RLock()       # serialises the calls on this engine (tf.Session.run is thread-safe)
 
@@ -342,6 +343,11 @@ class Engine:
             pin_out = torch.empty(block.shape, dtype=torch.int32).pin_memory()
             slot = {"dev_in": torch.empty(key, dtype=torch.uint8, device=dev), "pin_in": pin_in, "pin_in_np": pin_in.numpy(),
                     "block": block, "views": views, "pin_out": pin_out, "host": self._split_host(pin_out.numpy(), B)}
+            # the same four views over the PINNED block: pinned host memory is device-accessible at its own address, so the
+            # last kernel of a small forward can write the packed outputs straight into it (detect_host)
+            T = self.T
+            slot["pin_views"] = (pin_out[:B * T * 4].view(torch.float32).view(B, T, 4), pin_out[B * T * 4:B * T * 5].view(B, T),
+                                 pin_out[B * T * 5:B * T * 6].view(torch.float32).view(B, T), pin_out[B * T * 6:])
             while len(self._static) >= 8:
                 self._static.pop(next(iter(self._static)))
             self._static[(key, index)] = slot
@@ -395,8 +401,13 @@ class Engine:
                     hi = min(lo + step, src.size)
                     np.copyto(pin_np[lo:hi], src[lo:hi])
                     dev_t[lo:hi].copy_(pin_t[lo:hi], non_blocking=True)
-            self.forward(slot["dev_in"], out=slot["views"])
-            slot["pin_out"].copy_(slot["block"], non_blocking=True)
+            if images.shape[0] <= self.zero_copy_max_batch:
+                # a few images: post_pack_kernel writes its 48 KB per image into the pinned block itself (16-byte rows over
+                # PCIe) -- no device-to-host copy behind the forward (11 us of a 1.7 ms call)
+                self.forward(slot["dev_in"], out=slot["pin_views"])
+            else:
+                self.forward(slot["dev_in"], out=slot["views"])
+                slot["pin_out"].copy_(slot["block"], non_blocking=True)
             torch.cuda.current_stream().synchronize()
             return slot["host"]
 

@@ -107,6 +107,25 @@ def test_detector_call_reads_pinned_views_safely(cuda, ssd):
     assert not np.array_equal(ra[2], rb[2])
 
 
+@pytest.mark.parametrize("B", [1, 3, 6])
+def test_detect_host_outputs_written_straight_into_pinned_memory(cuda, ssd, B):
+    """Up to Engine.zero_copy_max_batch images detect_host hands the PINNED result block to the forward as its output
+    pointers (the last kernel writes over PCIe, no device-to-host copy); beyond, a device block and one copy.  Both forms,
+    and the plain device-tensor forward, return the same bytes -- every row, the zero padding included."""
+    det = _detector(ssd)
+    eng = det.engine
+    rng = np.random.default_rng(17 + B)
+    imgs = rng.integers(0, 256, (B, 128, 160, 3), dtype=np.uint8)
+    ref = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(imgs).cuda())]
+    assert int(ref[3].sum()) > 5
+    for zc in (4, 0):
+        eng.zero_copy_max_batch = zc
+        for _ in range(2):           # (twice: the second call finds the previous results in the block)
+            got = [np.array(v) for v in eng.detect_host(imgs)]
+            for a, b in zip(got, ref):
+                assert np.array_equal(a, b), (zc, B)
+
+
 def _bench(args, env_extra=None):
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
