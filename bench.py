@@ -316,8 +316,9 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
         # hardware queues.  One small forward BEFORE the process group exists gives the engine queues of its own; RCCL's
         # streams, created later, share whichever (they only run between forwards).  The other order measured 788 instead of
         # 822 img/s: the class tower's stream on the caller's queue (csrc/plan.hip ssd_side_stream).
-        engine.forward(torch.zeros((1, Hh, Ww, 3), dtype=torch.uint8, device=dev))
-        sync()
+        if world > 1 or args.force_dist or "WORLD_SIZE" in os.environ:
+            engine.forward(torch.zeros((1, Hh, Ww, 3), dtype=torch.uint8, device=dev))
+            sync()
     ranks_seen = [0]
     # inside a torch.distributed.run launch (WORLD_SIZE set, also = 1) or with --force-dist the collective path runs
     use_dist = world > 1 or args.force_dist or "WORLD_SIZE" in os.environ

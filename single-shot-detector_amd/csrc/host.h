@@ -50,6 +50,7 @@ enum SsdOpt {
     OPT_FPN_GROUP,          // -1 auto | 0 | 1: fpn p3 + p4 + p5 as one grouped launch (exact fp32)
     OPT_HEAD_SERIAL,        // -1 auto | 0 | 1: the box head behind the class logits on one stream instead of beside them
     OPT_SIDE_PRIORITY,      // 0 (default) | 1: the plan's third / fourth stream at the lowest dispatch priority
+    OPT_TOWER_GROUP,        // 0 (default) | 1: layer i of the box and the class tower as ONE launch over 2 x 5 levels (exact fp32)
     OPT_FPN_P6_FIRST,       // 0 | 1: the grouped p3+p4+p5 launch waits for fpn p6 (batch 1: p6 is not starved beside it)
     OPT_COUNT
 };
@@ -222,6 +223,7 @@ struct ssd_handle {
     ConvW lat[3], pconv[5];             // fpn lateral3..5, p3..p7
     ConvW pgroup;                       // fpn p3 | p4 | p5 kernels and batch norms behind one pointer each: one grouped launch at batch 1
     ConvW tower[2][4], final_[2];       // [box, class]
+    ConvW tgroup[4];                    // tower layer i of BOTH nets behind one pointer each (kernel, 2 x 5 batch norms): one launch per layer
     std::vector<int *> tabs;            // shufflenet gather tables (device)
     int c_ch[3] = {0, 0, 0};            // logical channels of c3, c4, c5
     int precision = SSD_PRECISION_F32;  // ssd_set_precision

@@ -705,24 +705,58 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     //  ten more launches of 72-step chains beside the big ones cost more than the 0.07 ms earlier start.  option level_split = 1
     //  keeps the experiment reachable.)
     const bool split_levels = B <= 2 && s6 == 2 && ssd_opt(h, OPT_LEVEL_SPLIT, 0) != 0;
+    // Option tower_group = 1 (exact fp32): layer i of the box tower and of the class tower as ONE launch over 2 x 5 levels
+    // (h->tgroup: both kernels, the ten batch norms; a level's IgemmLevel carries its net's kernel offset, input and output).
+    // Its time does not depend on which hardware queues the plan's streams got (ssd_side_stream above), and a one-stream plan
+    // gains 1.9 % with it (784 -> 799 img/s) -- but two launches side by side on two well-placed streams are a little better
+    // still: they run out of phase, one's prologues and epilogues under the other's K loops, where the blocks of ONE launch
+    // start and finish together.  Measured (profiles/r03_hw_queue_mapping.log): 32 images 806 / 810 img/s grouped against 812 /
+    // 816 on two streams; batch-1 forward 1.680-1.689 ms in seven processes against 1.658-1.689 (mean 1.670).  Off.
+    bool tgrouped = false;
+    { const int pin = ssd_opt(h, OPT_TOWER_GROUP, -1); if (pin >= 0) tgrouped = !X16 && !split_levels && h->tgroup[0].wt != nullptr && pin != 0; }
     const int ngrp = split_levels ? 2 : 1;
     const int g_lo[2] = {0, 3}, g_hi[2] = {split_levels ? 3 : 5, 5};
     std::vector<Op> tower_ops[2][2];            // [tower][level group]
+    std::vector<Op> tg_ops;                     // grouped form: layer i of both towers
+    const float *tower_out[2] = {nullptr, nullptr};
+    float *TAB[2][2];
+    for (int t = 0; t < 2; ++t)
+        for (int k = 0; k < 2; ++k) SSDCHK(falloc(&TAB[t][k], py.total));
+    if (tgrouped) {
+        const float *in[2] = {P, P};
+        int cur = 0;
+        for (int i = 0; i < 4; ++i) {
+            const ConvW &g = h->tgroup[i];
+            std::vector<LevelDesc> lv;
+            for (int t = 0; t < 2; ++t)
+                for (int l = 0; l < 5; ++l) {
+                    LevelDesc d = dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, (in[t] - in[0]) + py.off[l],
+                                              (TAB[t][cur] - TAB[0][cur]) + py.off[l], (t * 5 + l) * g.CoutP);
+                    d.wt_off = (long long)t * g.taps * g.CoutPad * g.CinP;
+                    lv.push_back(d);
+                }
+            tg_ops.push_back(make_conv_op(h, g, in[0], TAB[0][cur], nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true));
+            for (int t = 0; t < 2; ++t) in[t] = TAB[t][cur];
+            cur ^= 1;
+        }
+        for (int t = 0; t < 2; ++t) tower_out[t] = in[t];
+    }
     bool all_marked = true;
     for (int t = 0; t < 2; ++t) {
-        float *TA, *TB;
-        SSDCHK(falloc(&TA, py.total));
-        SSDCHK(falloc(&TB, py.total));
         const float *in = P;
-        float *out = TA;
-        for (int i = 0; i < 4; ++i) {
-            for (int g = 0; g < ngrp; ++g) {
-                std::vector<LevelDesc> lv;
-                for (int l = g_lo[g]; l < g_hi[g]; ++l) lv.push_back(dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, py.off[l], py.off[l], l * 256));
-                tower_ops[t][g].push_back(make_conv_op(h, h->tower[t][i], in, out, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true, X16, X16, 0, FL));
+        int cur = 0;
+        if (!tgrouped) {
+            for (int i = 0; i < 4; ++i) {
+                for (int g = 0; g < ngrp; ++g) {
+                    std::vector<LevelDesc> lv;
+                    for (int l = g_lo[g]; l < g_hi[g]; ++l) lv.push_back(dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, py.off[l], py.off[l], l * 256));
+                    tower_ops[t][g].push_back(make_conv_op(h, h->tower[t][i], in, TAB[t][cur], nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true, X16, X16, 0, FL));
+                }
+                in = TAB[t][cur];
+                cur ^= 1;
             }
-            in = out;
-            out = (out == TA) ? TB : TA;
+        } else {
+            in = tower_out[t];
         }
         const int per = t == 0 ? 4 : C;     // values per anchor
         // class logits: the convolution's epilogue also marks the octets that hold a candidate (p.scan_bits) and
@@ -756,6 +790,19 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     // measured on one box, serial 1 823 us per forward, side by side 1 782 us (profiles/r03_batch1_timeline_*.txt).  Off.
     bool head_serial = false;
     { const int pin = ssd_opt(h, OPT_HEAD_SERIAL, -1); if (pin >= 0) head_serial = pin != 0 && !split_levels; }
+    if (tgrouped) {
+        // main stream: the four grouped tower layers, then the class logits; the box head beside the logits on the second stream
+        int id_last = -1;
+        for (size_t i = 0; i < tg_ops.size(); ++i) {
+            std::vector<int> deps;
+            if (i == 0) { deps.push_back(id_p3); deps.push_back(id_p4); deps.push_back(id_p7); }
+            id_last = push(tg_ops[i], 0, deps);
+        }
+        const int id_logits = push(tower_ops[1][0][0], 0);
+        if (head_serial) push(tower_ops[0][0][0], 0);
+        else push(tower_ops[0][0][0], 1, {id_last});
+        (void)id_logits;
+    } else {
     int id_box_last = -1;
     for (size_t i = 0; i < tower_ops[0][0].size(); ++i)
         for (int t = 1; t >= 0; --t) {
@@ -773,6 +820,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 push(tower_ops[t][1][i], t == 0 ? 2 : 3, d2);
             }
         }
+    }
     pl.tail_on[0] = pl.tail_on[1] = split_levels;
     // events for every op another stream waits on
     for (const Op &op : pl.ops)

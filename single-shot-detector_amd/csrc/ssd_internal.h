@@ -16,7 +16,7 @@
 static inline int ssd_phys_of_logical(int l) { int o = l & ~7, r = l & 7; return o + ((r & 1) ? 4 + (r >> 1) : (r >> 1)); }
 static inline int ssd_logical_of_phys(int p) { int o = p & ~7, r = p & 7; return o + (r < 4 ? 2 * r : 2 * (r - 4) + 1); }
 
-#define SSD_MAX_LEVELS 5
+#define SSD_MAX_LEVELS 10     // 5 pyramid levels; 10 = both head towers' levels in one launch (plan.hip)
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, DEVICE): the attribute belongs to the device's copy of
 // the function, so a second engine on another GPU of the same process needs its own call.  `done` is one word per

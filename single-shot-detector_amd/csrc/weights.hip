@@ -396,6 +396,27 @@ static int finalize_fpn_heads(ssd_handle *h)
         bpad.resize((size_t)round_up(Cout, 4), 0.0f);     // the epilogue reads parameters 4 at a time
         SSDCHK(h->wpool.upload(&cw.bias, bpad));
     }
+    // layer i of both towers behind one pointer each (same shapes: 3x3, 256 -> 256, five batch norms per net): one launch per
+    // layer over 2 x 5 levels (plan.hip), box net first
+    for (int i = 0; i < 4; ++i) {
+        ConvW &g = h->tgroup[i];
+        const ConvW &b0 = h->tower[0][i], &b1 = h->tower[1][i];
+        g = b0;
+        g.wt16 = g.wt16w = g.wlat = nullptr;       // (exact fp32, the 32x32x2 kernel only)
+        if (b0.CoutPad != b1.CoutPad || b0.CinP != b1.CinP || b0.CoutP != b1.CoutP) return ssd_fail(SSD_ERR_WEIGHT, "box / class tower kernels differ in shape");
+        const size_t wn = (size_t)g.taps * g.CoutPad * g.CinP, pn = (size_t)5 * g.CoutP;
+        SSDCHK(h->wpool.alloc((void **)&g.wt, 2 * wn * sizeof(float)));
+        SSDCHK(h->wpool.alloc((void **)&g.mean, 2 * pn * sizeof(float)));
+        SSDCHK(h->wpool.alloc((void **)&g.sf, 2 * pn * sizeof(float)));
+        SSDCHK(h->wpool.alloc((void **)&g.beta, 2 * pn * sizeof(float)));
+        for (int t = 0; t < 2; ++t) {
+            const ConvW &src = h->tower[t][i];
+            HIPCHK(hipMemcpy(g.wt + t * wn, src.wt, wn * sizeof(float), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(g.mean + t * pn, src.mean, pn * sizeof(float), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(g.sf + t * pn, src.sf, pn * sizeof(float), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(g.beta + t * pn, src.beta, pn * sizeof(float), hipMemcpyDeviceToDevice));
+        }
+    }
     return SSD_OK;
 }
 

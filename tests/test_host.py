@@ -165,7 +165,7 @@ def test_library_reads_one_environment_variable_and_options_go_through_the_abi(s
                  b"SSD_LEVEL_SPLIT", b"SSD_BACKBONE_SPLIT", b"SSD_LATERAL_SPLIT", b"SSD_IGEMM_96"):
         assert gone not in blob, gone
     unset = -2 ** 31
-    for key in ("igemm_tile", "igemm_lat", "igemm_deep64", "streams", "fpn_group", "head_serial", "side_priority", "fpn_p6_first", "igemm16", "igemm_96", "lateral_split", "backbone_split", "nsub", "level_split",
+    for key in ("igemm_tile", "igemm_lat", "igemm_deep64", "streams", "fpn_group", "head_serial", "side_priority", "tower_group", "fpn_p6_first", "igemm16", "igemm_96", "lateral_split", "backbone_split", "nsub", "level_split",
                 "nms_fast_max", "fuse_dw", "graph", "debug_sync"):
         assert ssd.get_option(key) == unset
         ssd.set_option(key, 3)
