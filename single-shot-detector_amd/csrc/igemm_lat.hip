@@ -22,8 +22,13 @@
 //               [kk = channel & 3][t = channel >> 2].  In the physical channel order a lane's 16-byte chunk (octet o, half h)
 //               holds logical 8o + {0,2,4,6} + h: elements (0,2) go to kk = h at t = 2o, 2o+1, elements (1,3) to kk = h + 2
 //               -- two 8-byte writes per load; lane (i, kk) reads its eight operands with two ds_read_b128.  The 16-byte
-//               slot (2 kk + half) of row r sits at slot ^ ((r >> 1) & 7) ^ (2 * ((r >> 2) & 1)): conflict-free for the four
-//               16-lane groups of ds_read_b128 (MI355X_MICROARCH.md LDS table).  No barrier: LDS operations of one wave
+//               slot (2 kk + half) of row r sits at slot ^ lat_swz(r), lat_swz(r) = P[(r >> 1) & 7] ^ 4 (r & 1) with
+//               P = 0 1 4 5 6 7 2 3, found by exhaustive search over the lane groups and bank rules of MI355X_MICROARCH.md's
+//               LDS table: ds_read_b128 is served in four NON-contiguous groups of 16 lanes over 64 banks, ds_write_b64 in
+//               four contiguous groups of 16 lanes over 32 banks -- rows r and r + 1, which one write group covers, must
+//               differ in the slot half they write.  SQ_LDS_BANK_CONFLICT 0 (the first swizzle, a function of r >> 1
+//               alone, was conflict-free for the reads and 2-way on every write group: 25-40 % of the kernel's LDS
+//               cycles, profiles/r03_batch1_pmc_summary.txt).  No barrier: LDS operations of one wave
 //               execute in order
 //   pipeline    D register sets: the loads of K-step s + D are issued behind the MFMAs of K-step s; the positions of step
 //               s + 1 go to the other LDS stage before the MFMAs of step s and are read back behind them; waits are the
@@ -36,6 +41,7 @@
 #include <type_traits>
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ int lat_swz(int r) { return (int)((0x32765410u >> (4 * ((r >> 1) & 7))) & 7u) ^ ((r & 1) << 2); }
 
 template <int PT, int CT, int TAPS, int D, int WB>
 __global__ __launch_bounds__(64 * WB) void igemm_lat_kernel(const IgemmArgs a)
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(64 * WB) void igemm_lat_kernel(const IgemmArgs a)
         }
         // LDS image: octet o, half h of the row -> elements (0,2) at role kk = h, (1,3) at kk = h + 2
         const int o = c >> 1, hh = c & 1;
-        const int f = ((r >> 1) & 7) ^ (2 * ((r >> 2) & 1));
+        const int f = lat_swz(r);
         woff_lo[u] = r * 128 + ((((hh) * 2 + (o >> 1)) ^ f) << 4) + (o & 1) * 8;
         woff_hi[u] = r * 128 + ((((hh + 2) * 2 + (o >> 1)) ^ f) << 4) + (o & 1) * 8;
     }
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(64 * WB) void igemm_lat_kernel(const IgemmArgs a)
     int roff[2];
     {
         const int i = lane & 15, kk = lane >> 4;
-        const int f = ((i >> 1) & 7) ^ (2 * ((i >> 2) & 1));
+        const int f = lat_swz(i);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) roff[hf] = i * 128 + (((2 * kk + hf) ^ f) << 4);
     }
