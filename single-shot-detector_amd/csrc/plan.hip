@@ -704,7 +704,12 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     //  third / fourth stream behind p7, so that the towers of levels 3..5 start when p3..p5 exist: 2.12 -> 2.29 ms per forward;
     //  ten more launches of 72-step chains beside the big ones cost more than the 0.07 ms earlier start.  option level_split = 1
     //  keeps the experiment reachable.)
-    const bool split_levels = B <= 2 && s6 == 2 && ssd_opt(h, OPT_LEVEL_SPLIT, 0) != 0;
+    const bool split_levels = B <= 2 && s6 == 2 && ssd_opt(h, OPT_LEVEL_SPLIT, 0) == 1;
+    // (Measured and not adopted either, round 3, level_split = 2: only the FIRST tower layer split -- its levels 3..5 start when
+    //  p3..p5 exist (p6, starved beside the grouped p3+p4+p5 launch, and p7 behind it hold the towers back ~50 us), its levels
+    //  6..7, 175 positions on the latency kernel, run behind p7 on p7's stream, and the second layer waits for both: batch-1
+    //  forward 1.674 -> 1.700 ms, batch 2 unchanged.  The earlier tower layer starves p6 for longer.)
+    const bool split0 = !split_levels && !X16 && B <= 2 && s6 == 2 && ssd_opt(h, OPT_LEVEL_SPLIT, 0) == 2;
     // Option tower_group = 1 (exact fp32): layer i of the box tower and of the class tower as ONE launch over 2 x 5 levels
     // (h->tgroup: both kernels, the ten batch norms; a level's IgemmLevel carries its net's kernel offset, input and output).
     // Its time does not depend on which hardware queues the plan's streams got (ssd_side_stream above), and a one-stream plan
@@ -718,6 +723,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     const int g_lo[2] = {0, 3}, g_hi[2] = {split_levels ? 3 : 5, 5};
     std::vector<Op> tower_ops[2][2];            // [tower][level group]
     std::vector<Op> tg_ops;                     // grouped form: layer i of both towers
+    Op coarse0[2];                              // split0: the first layer's levels 6..7
     const float *tower_out[2] = {nullptr, nullptr};
     float *TAB[2][2];
     for (int t = 0; t < 2; ++t)
@@ -749,8 +755,14 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             for (int i = 0; i < 4; ++i) {
                 for (int g = 0; g < ngrp; ++g) {
                     std::vector<LevelDesc> lv;
-                    for (int l = g_lo[g]; l < g_hi[g]; ++l) lv.push_back(dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, py.off[l], py.off[l], l * 256));
+                    const int hi = (split0 && i == 0) ? 3 : g_hi[g];
+                    for (int l = g_lo[g]; l < hi; ++l) lv.push_back(dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, py.off[l], py.off[l], l * 256));
                     tower_ops[t][g].push_back(make_conv_op(h, h->tower[t][i], in, TAB[t][cur], nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true, X16, X16, 0, FL));
+                }
+                if (split0 && i == 0) {
+                    std::vector<LevelDesc> lv;
+                    for (int l = 3; l < 5; ++l) lv.push_back(dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, py.off[l], py.off[l], l * 256));
+                    coarse0[t] = make_conv_op(h, h->tower[t][i], in, TAB[t][cur], nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true, X16, X16, 0, FL);
                 }
                 in = TAB[t][cur];
                 cur ^= 1;
@@ -804,10 +816,14 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         (void)id_logits;
     } else {
     int id_box_last = -1;
+    int id_coarse0[2] = {-1, -1};
+    if (split0)
+        for (int t = 0; t < 2; ++t) id_coarse0[t] = push(coarse0[t], s6);     // behind p7 on its stream
     for (size_t i = 0; i < tower_ops[0][0].size(); ++i)
         for (int t = 1; t >= 0; --t) {
             std::vector<int> deps;
-            if (i == 0) { deps.push_back(t == 0 ? id_p4 : id_p3); if (!split_levels) deps.push_back(id_p7); }
+            if (i == 0) { deps.push_back(t == 0 ? id_p4 : id_p3); if (!split_levels && !split0) deps.push_back(id_p7); }
+            if (i == 1 && split0) deps.push_back(id_coarse0[t]);
             if (head_serial && t == 0 && i + 1 == tower_ops[0][0].size()) {
                 push(tower_ops[0][0][i], 1, {id_box_last});          // behind the logits (pushed just before), after the box tower
                 continue;
