@@ -103,20 +103,24 @@ int ssd_get_precision(ssd_handle *h);
  * the only one it reads).  `h` == NULL sets the process-wide value, which the handle-less stage entry points below use and
  * which a handle falls back to for an option it has not been given itself; with a handle the call synchronises and drops
  * the cached layer plan.  Keys (value; default):
- *   "igemm_tile"      0 auto | 128 | 64 pin the tile of the 128x128-class launches | 20..23 pin a wave tile of the latency
- *                     form (1x1, 1x2, 2x1, 2x2 sixteen-wide units) wherever that form applies           (0)
- *   "igemm_lat"       1 | 0: tiny exact-fp32 launches on the latency form (v_mfma_f32_16x16x4_f32)      (1)
+ *   "igemm_tile"      0 auto | 128 | 64 pin the tile of the 128x128-class launches | 20..27 pin a tile of the latency form
+ *                     wherever that form applies: 20..23 one wave per block (1x1, 1x2, 2x1, 2x2 sixteen-wide units), 24..27
+ *                     two / four waves per block sharing the positions through LDS                       (0)
+ *   "igemm_lat"       1 | 0: small exact-fp32 launches on the latency form (v_mfma_f32_16x16x4_f32)      (1)
  *   "igemm_deep64"    -1 auto | 0 | 1: 64x64 tiles with operand loads three K-steps ahead                (-1)
- *   "streams"         0 auto | 1: every kernel of a forward on one stream, in plan order                 (0)
+ *   "streams"         0 auto | 1: every kernel of a forward on one stream, in plan order | 2: the internal streams at the
+ *                     highest priority (a hardware-queue pool of their own)                  (0)
  *   "fpn_group"       -1 auto | 0 | 1: fpn p3 + p4 + p5 as one grouped launch (batch 1, F32)             (-1)
+ *   "tower_group"     0 | 1: layer i of the box and the class tower as one launch over 2 x 5 levels      (0)
  *   "head_serial"     -1 auto | 0 | 1: the box head behind the class logits instead of beside them       (-1)
- *   "side_priority"   0 | 1: the streams of fpn p6 / p7 at the lowest dispatch priority                  (0)
+ *   "side_priority"   0 | 1 | 2: the streams of fpn p6 / p7 at the lowest / highest dispatch priority    (0)
+ *   "fpn_p6_first"    0 | 1 | 2: the grouped fpn launch waits for p6 / for p7                            (0)
  *   "igemm16"         -1 auto | 0 | 1: F16X3 launches on the 256x256-tile kernel                         (-1)
  *   "igemm_96"        1 | 0: 128x96 tiles for widths 96 divides and 128 does not (read by ssd_finalize)  (1)
  *   "lateral_split"   1 | 0: F16X3 laterals split fp32 rows while staging them                           (1)
  *   "backbone_split"  0 auto | 1..4: MobileNet backbone chains                                           (0)
  *   "nsub"            0 auto | 1..8: staggered sub-batch plans                                            (0)
- *   "level_split"     0 | 1: head towers of levels 6-7 as launches of their own (batch <= 2)             (0)
+ *   "level_split"     0 | 1 | 2: head towers of levels 6-7 as launches of their own (batch <= 2): every layer / the first (0)
  *   "nms_fast_max"    -1 default | n >= 0: candidate lists up to n stay in one wave's registers          (-1)
  *   "fuse_dw"         -1 default | bit mask of depthwise+pointwise pairs that run as one launch          (-1)
  *   "graph"           0 | 1: hipGraph replay of a repeating forward                                      (0)
