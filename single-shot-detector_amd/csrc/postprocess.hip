@@ -438,22 +438,22 @@ __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
     // (Bench frames: ONE class holds 4 085 of a frame's 6 503 candidates; on the 1 024-thread in-register kernel its 25 rounds
     //  took 98 us -- 8 IoU tests x 16 waves on one CU per round -- and decided the post-processing's time.)
     {
-        constexpr int TCAP = 64 * NMS_R, NBIN = 2048;
+        constexpr int TCAP = 64 * NMS_R, TCAP_S = 64 * 2, NBIN = 2048;
         __shared__ unsigned hist[NBIN];
         __shared__ u64 chunk[TCAP];
-        __shared__ int chunk_n, cut_bin, trial_kept;
+        __shared__ int chunk_n, cut_bin[2], trial_kept;
         const unsigned lo_bits = __float_as_uint(p.score_thr > 0.0f ? p.score_thr : 0.0f);
         int shift = 0;
         while (((0x3F800000u - lo_bits) >> shift) >= (unsigned)NBIN) ++shift;
         for (int i = tid; i < NBIN; i += NMS_MID) hist[i] = 0;
-        if (tid == 0) { chunk_n = 0; trial_kept = -1; }
+        if (tid == 0) trial_kept = -1;
         __syncthreads();
         for (int i = tid; i < n; i += NMS_MID) atomicAdd(&hist[((unsigned)(keys[i] >> 32) - lo_bits) >> shift], 1u);
         __syncthreads();
-        // cut_bin = the smallest bin whose suffix count (candidates in bins >= it) is still <= TCAP.  Wave 0, lane l owns
-        // bins 32 l .. 32 l + 31: lane totals, a suffix scan over the lanes, and the one lane whose range holds the cut walks
-        // its 32 bins.  (One thread walking the histogram down from the top took 85 us: scores crowd just above the
-        // threshold, so the walk covered nearly all 2 048 bins, a dependent LDS read each.)
+        // cut_bin[k] = the smallest bin whose suffix count (candidates in bins >= it) is still <= cap_k, for the two caps
+        // 128 and 512.  Wave 0, lane l owns bins 32 l .. 32 l + 31: lane totals, a suffix scan over the lanes, and the one lane
+        // whose range holds a cut walks its 32 bins.  (One thread walking the histogram down from the top took 85 us: scores
+        // crowd just above the threshold, so the walk covered nearly all 2 048 bins, a dependent LDS read each.)
         if (wave == 0) {
             static_assert(NBIN == 64 * 32, "one lane per 32 bins");
             unsigned mine = 0;
@@ -465,32 +465,45 @@ __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
                 above += (lane + off < 64) ? o : 0u;
             }
             const unsigned higher = above - mine;               // count in bins >= 32 * (lane + 1)
-            if (lane == 0) cut_bin = above <= (unsigned)TCAP ? 0 : NBIN;
-            if (higher <= (unsigned)TCAP && above > (unsigned)TCAP) {      // exactly one lane, unless every bin fits (cut 0, set above)
-                unsigned cum = higher;
-                int bin = lane * 32 + 32;
-                while (bin > lane * 32 && cum + hist[bin - 1] <= (unsigned)TCAP) { cum += hist[bin - 1]; --bin; }
-                cut_bin = bin;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const unsigned cap = k == 0 ? (unsigned)TCAP_S : (unsigned)TCAP;
+                if (lane == 0) cut_bin[k] = above <= cap ? 0 : NBIN;
+                if (higher <= cap && above > cap) {             // exactly one lane, unless every bin fits (cut 0, set above)
+                    unsigned cum = higher;
+                    int bin = lane * 32 + 32;
+                    while (bin > lane * 32 && cum + hist[bin - 1] <= cap) { cum += hist[bin - 1]; --bin; }
+                    cut_bin[k] = bin;
+                }
             }
         }
         __syncthreads();
-        const int cb = cut_bin;
-        for (int i = tid; i < n; i += NMS_MID) {
-            const u64 k = keys[i];
-            if ((int)(((unsigned)(k >> 32) - lo_bits) >> shift) >= cb) chunk[atomicAdd(&chunk_n, 1)] = k;
-        }
-        __syncthreads();
-        const int nn = chunk_n;
-        if (nn >= p.max_per_class && cb > 0) {          // (fewer than the cap can never fill it; cb == 0: the cut kept everything)
-            if (wave == 0) {
-                const int kept = nms_one_wave<NMS_R>(p, chunk, dec, nn, lane, ob, os);
-                if (lane == 0) trial_kept = kept;
+        // two trials: the top <= 128 candidates with 2 per lane (a round costs a quarter of an 8-per-lane round: on the bench
+        // frames the class that holds two thirds of a frame's candidates fills its 25 boxes from them), then the top <= 512
+#pragma unroll 1
+        for (int k = 0; k < 2; ++k) {
+            const int cb = cut_bin[k];
+            if (k == 1 && cb == cut_bin[0]) break;          // the same candidates again
+            if (tid == 0) chunk_n = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += NMS_MID) {
+                const u64 kk = keys[i];
+                if ((int)(((unsigned)(kk >> 32) - lo_bits) >> shift) >= cb) chunk[atomicAdd(&chunk_n, 1)] = kk;
             }
             __syncthreads();
-            if (trial_kept >= p.max_per_class) {        // block-uniform
-                if (tid == 0) p.cls_counts[bc] = trial_kept;
-                return;
+            const int nn = chunk_n;
+            if (nn >= p.max_per_class && cb > 0) {      // (fewer than the cap can never fill it; cb == 0: the cut kept everything)
+                if (wave == 0) {
+                    const int kept = k == 0 ? nms_one_wave<2>(p, chunk, dec, nn, lane, ob, os) : nms_one_wave<NMS_R>(p, chunk, dec, nn, lane, ob, os);
+                    if (lane == 0) trial_kept = kept;
+                }
+                __syncthreads();
+                if (trial_kept >= p.max_per_class) {    // block-uniform
+                    if (tid == 0) p.cls_counts[bc] = trial_kept;
+                    return;
+                }
             }
+            __syncthreads();
         }
     }
     if (n > p.mid_max) {                    // too long for this block's registers: post_nms_regs_kernel / post_nms_big_kernel
