@@ -124,7 +124,7 @@ int ssd_get_precision(ssd_handle *h);
  *   "nms_fast_max"    -1 default | n >= 0: candidate lists up to n stay in one wave's registers          (-1)
  *   "fuse_dw"         -1 default | bit mask of depthwise+pointwise pairs that run as one launch          (-1)
  *   "graph"           0 | 1: hipGraph replay of a repeating forward                                      (0)
- *   "debug_sync"      0 | 1: announce every op on stderr, run it alone and wait for it                   (0)
+ *   "debug_sync"      0 | 1: announce every op on stderr, run it alone, wait for it, print its time      (0)
  * ssd_get_option returns the value in effect (handle, else process), INT32_MIN when neither was set. */
 int ssd_set_option(ssd_handle *h, const char *key, int32_t value);
 int ssd_get_option(ssd_handle *h, const char *key, int32_t *value);

@@ -2,6 +2,7 @@
 // launches on a few streams with explicit dependencies, no host synchronisation.  Built once per shape by
 // ssd_forward (abi.hip), enqueued per call.
 #include "host.h"
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -868,9 +869,12 @@ static hipError_t run_op(ssd_handle *h, const Op &op, hipStream_t s)
         fprintf(stderr, "[ssd] op class %d stream %d flops %.3g bytes %.3g ...", op.cls, op.stream, op.flops, op.bytes);
         fflush(stderr);
         (void)hipDeviceSynchronize();
+        const auto t0 = std::chrono::steady_clock::now();
         hipError_t r = op.run(s);
         hipError_t r2 = hipDeviceSynchronize();
-        fprintf(stderr, " %s\n", r == hipSuccess && r2 == hipSuccess ? "ok" : "FAILED");
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, " %s  %.1f us alone (launch + wait included): %.1f TFLOP/s, %.2f TB/s\n", r == hipSuccess && r2 == hipSuccess ? "ok" : "FAILED",
+                us, op.flops / us * 1e-6, op.bytes / us * 1e-6);
         return r != hipSuccess ? r : r2;
     }
     if (!h->profiling) return op.run(s);
