@@ -422,6 +422,34 @@ def test_postprocess_long_lists(cuda, ssd, oracle_ops, libopt):
     run_post(cuda, ssd, oracle_ops, codes, logits, anc)
 
 
+def test_postprocess_many_classes_and_failing_trials(cuda, ssd, oracle_ops):
+    """(a) More classes than the pack kernel has threads (its prefix of the per-class counts runs in chunks of 256).
+    (b) Long lists built so that the top-score trials of post_nms_kernel FAIL at either level: heavy overlap among the
+    best-scoring candidates (the top 128 / top 512 keep fewer than max_boxes_per_class boxes) sends the list on to the
+    next trial and then to the full-list path -- the detections must be the oracle's in every case."""
+    rng = np.random.default_rng(99)
+    anc = oracle_ops.anchors(128, 128)
+    N = anc.shape[0]
+    C = 300
+    codes = (rng.standard_normal((2, N, 4)) * 0.3).astype(np.float32)
+    logits = (rng.standard_normal((2, N, C)) * 1.5 - 5.0).astype(np.float32)
+    run_post(cuda, ssd, oracle_ops, codes, logits, anc, m=7)
+    anc = oracle_ops.anchors(640, 896)
+    N = anc.shape[0]
+    codes, logits = synth_heads(rng, 1, N, 80, frac=0.0005)
+    codes[:] = 0.0                                    # decoded box = its anchor: neighbours of one cell overlap heavily
+    # class 5: 3 000 candidates; the 600 best are the six anchors of 100 neighbouring cells of level 3 (one cluster: NMS keeps few)
+    logits[0, :, 5] = -9.0
+    logits[0, 1000:4000, 5] = rng.uniform(-1.0, 1.0, 3000).astype(np.float32)
+    logits[0, 1200:1800, 5] = rng.uniform(3.0, 4.0, 600).astype(np.float32)
+    # class 6: the 100 best in one cluster (first trial fails), the next 300 spread out (second trial succeeds)
+    logits[0, :, 6] = -9.0
+    logits[0, 20000:23000, 6] = rng.uniform(-1.0, 0.5, 3000).astype(np.float32)
+    logits[0, 20000:20100, 6] = rng.uniform(3.0, 4.0, 100).astype(np.float32)
+    logits[0, 21000:22800:6, 6] = rng.uniform(1.0, 2.0, 300).astype(np.float32)
+    run_post(cuda, ssd, oracle_ops, codes, logits, anc)
+
+
 def test_postprocess_batch_properties(cuda, ssd, oracle_ops):
     """Full BASELINE size (config 3: B=32, N=71610): images are independent, so a
     permutation of the batch permutes the outputs and every image equals its B=1 run."""
