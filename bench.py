@@ -112,6 +112,25 @@ def latency_batch1(detector):
             "detections_over_0.5": int(len(scores))}
 
 
+def latency_segments(detector):
+    """Where a batch-1 Detector call spends its time (attribution: every segment followed by a synchronisation, so the
+    sum exceeds the pipelined call): staging memcpy, upload, forward (results into pinned host memory), score filter."""
+    e = detector.engine
+    img = np.random.default_rng(0).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    for _ in range(5):
+        detector(img, score_threshold=0.5)
+    slot = e._slot((1, H, W, 3))
+    seg = {k: [] for k in ("copyto_pinned", "h2d", "forward_zero_copy_out", "filter")}
+    for _ in range(50):
+        t0 = time.perf_counter(); np.copyto(slot["pin_in_np"], img[None]); t1 = time.perf_counter()
+        slot["dev_in"].copy_(slot["pin_in"], non_blocking=True); torch.cuda.synchronize(); t2 = time.perf_counter()
+        e.forward(slot["dev_in"], out=slot["pin_views"]); torch.cuda.synchronize(); t3 = time.perf_counter()
+        b, l, s, n = slot["host"]; k = s[0][:n[0]] > 0.5; _ = b[0][:n[0]][k], l[0][:n[0]][k], s[0][:n[0]][k]; t4 = time.perf_counter()
+        for name, a, c in zip(seg, (t0, t1, t2, t3), (t1, t2, t3, t4)):
+            seg[name].append((c - a) * 1e6)
+    return {k: float(np.percentile(v, 50)) for k, v in seg.items()}
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -242,6 +261,7 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
     launcher and step loop with a stand-in engine on CPU); the product run uses none of them."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--no-numa-bind", action="store_true", help="do not restrict the process to the CPUs of the GPU's NUMA node")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 = BASELINE config 5: 256/8; 64 with --config shufflenet)")
@@ -295,11 +315,15 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
     if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     import torch.distributed as dist
+    numa_node = None
     if stub:
         dev, sync = torch.device("cpu"), (lambda: None)
     else:
         torch.cuda.set_device(local)
         dev, sync = torch.device("cuda", local), torch.cuda.synchronize
+        # one process per GPU, on the GPU's NUMA node (the host side of a batch-1 call is 1-3 % faster there and no longer
+        # depends on where the scheduler put the thread: scripts/numa_probe.py)
+        numa_node = None if args.no_numa_bind else ssd_amd.bind_to_gpu_numa_node(local)
     for kv in args.option:
         k, v = kv.split("=", 1)
         ssd_amd.set_option(k, int(v, 0))
@@ -408,7 +432,7 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
             "dtype": "f32" if args.precision == "f32" else "f32 carried as split f16 pairs (3 x f16 MFMA, f32 accumulate)",
             "precision": args.precision, "status_word": status_value,
             "data": "synthetic" if not stub else "STAND-IN ENGINE (launcher test, no GPU work)",
-            "ranks_seen": ranks_seen, "collective_path": bool(use_dist),
+            "ranks_seen": ranks_seen, "collective_path": bool(use_dist), "numa_node_bound": numa_node,
             "config": {"workload": ("MobileNet-v1 + FPN + RetinaNet heads + decode + per-class NMS, 640x896 (HxW) "
                                     "uint8 frames, %d per GPU (BASELINE config 5 shard; config 2 = same graph at batch 1, "
                                     "see latency_batch1; config 4 = the shufflenet_config4 object)" % B) if net == "mobilenet" else
@@ -442,7 +466,8 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
                     lat[mode] = latency_batch1(detector)
                 engine.set_precision(args.precision)
                 res["latency_batch1"] = dict(lat[args.precision], precision=args.precision,
-                                             roofline_ms=ROOFLINE_MS["mobilenet"], by_precision=lat)
+                                             roofline_ms=ROOFLINE_MS["mobilenet"], by_precision=lat,
+                                             segments_p50_us=latency_segments(detector))
             if world == 1 and not args.no_shufflenet:
                 engine.close()
                 res["shufflenet_config4"] = shufflenet_leg(local, timed, max(3, args.steps // 2), 2, 64)

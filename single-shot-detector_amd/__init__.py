@@ -16,4 +16,4 @@ from .ssd import (SSD, AnchorGenerator, RetinaNetFeatureExtractor, RetinaNetBoxP
                   batch_multiclass_non_max_suppression, network_input_size, Engine)
 from .detector import Detector                                         # noqa: F401
 from . import coco_eval                                                # noqa: F401
-from .distributed import shard_range, all_gather_detections, detect_sharded  # noqa: F401
+from .distributed import shard_range, all_gather_detections, detect_sharded, bind_to_gpu_numa_node  # noqa: F401

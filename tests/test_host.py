@@ -231,3 +231,18 @@ def test_voc_ap_self_check_known_answers(ssd):
     ev.add_image([[1, 1, 2, 2]], [0], [[1, 1, 2, 2]], [0], [0.7])
     out = ev.evaluate()
     assert out[0]["AP"] == 1.0 and out[2]["AP"] == 1.0 and out[1]["AP"] == 0.0 and abs(out["mAP"] - 2 / 3) < 1e-12
+
+
+def test_numa_binding_helper_is_harmless_without_a_gpu():
+    """bind_to_gpu_numa_node: one process per GPU on the GPU's NUMA node (bench.py calls it).  Where the device or the
+    topology cannot be read it must change nothing and say so."""
+    import os
+    import ssd_amd
+    before = os.sched_getaffinity(0)
+    node = ssd_amd.bind_to_gpu_numa_node(0)
+    after = os.sched_getaffinity(0)
+    if node is None:
+        assert after == before
+    else:
+        assert isinstance(node, int) and node >= 0 and after and after <= before
+        os.sched_setaffinity(0, before)
