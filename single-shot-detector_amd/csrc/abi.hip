@@ -137,7 +137,6 @@ extern "C" void ssd_destroy(ssd_handle *h)
     for (auto r : h->ref_evs) (void)hipEventDestroy(r);
     for (auto r : h->ev_pool) (void)hipEventDestroy(r);
     free_plans(h);
-    for (hipStream_t st : h->side_streams) if (st) (void)hipStreamDestroy(st);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_gin) (void)hipEventDestroy(h->ev_gin);
     if (h->ev_gout) (void)hipEventDestroy(h->ev_gout);

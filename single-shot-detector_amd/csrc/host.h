@@ -193,7 +193,7 @@ struct Plan {
     hipStream_t s_main = nullptr;       // null: the caller's stream (sub-batch 0)
     hipStream_t s_aux = nullptr;        // class tower beside the box tower (box_predictor.py:47-59)
     hipStream_t s_bb[2] = {nullptr, nullptr};   // further chains (Op::stream 2, 3)
-    bool own_streams = false;           // false: the streams are the handle's (ssd_handle::side_streams), not destroyed with the plan
+    bool own_streams = false;           // false: the streams are the process-wide ones (plan.hip make_plans), not destroyed with the plan
     hipEvent_t ev_fpn = nullptr, ev_join = nullptr, ev_done = nullptr, ev_begin = nullptr;
     hipEvent_t ev_join_bb[2] = {nullptr, nullptr};
     bool tail_on[2] = {false, false};   // the plan's last ops on stream 2 / 3 are not awaited by any later op: join them before the post-processing
@@ -231,11 +231,6 @@ struct ssd_handle {
     // plans
     int pB = 0, pH = 0, pW = 0;
     std::vector<Plan *> plans;
-    // the plans' internal streams, created once per handle and handed to every plan built later ([4 k + i]: sub-batch k's
-    // main (k > 0), second, third, fourth stream).  A rebuilt plan (another batch size, another precision mode) then runs on the
-    // hardware queues the first one had: streams created late in a process share queues with earlier ones (4 hardware queues
-    // per process by default), which costs a batch-1 forward ~30 us (profiles/r03_batch1_option_ab.log, first vs later engines)
-    std::vector<hipStream_t> side_streams;
     hipEvent_t ev_start = nullptr;
     const uint8_t *cur_images = nullptr;
     // the arena is one per handle: a forward enqueued on another stream than the previous one waits for it

@@ -895,12 +895,12 @@ static hipError_t run_op(ssd_handle *h, const Op &op, hipStream_t s)
     return r;
 }
 
-// The plans' internal streams.  HIP streams share a small pool of hardware queues (4 per process and priority level by
+// The plans' internal streams (one set per device and process, make_plans below).  HIP streams share a small pool of hardware queues (4 per process and priority level by
 // default), each new stream joining the least-loaded one, so WHICH queue the class tower's stream gets depends on what the
 // process created before: on the caller's queue it runs behind the box tower instead of beside it (bench.py under
 // torch.distributed, RCCL's streams first: 788 instead of 822 img/s; a second engine in one process: batch-1 forward +30 us).
-// The handle creates its streams once, with its first plan; a process that wants the clean mapping creates its engine (and
-// runs one forward) before other stream-creating libraries -- bench.py does, INTEGRATION.md section 2.
+// The streams are created once per process, with the first plan; a process that wants the clean mapping creates its first
+// engine (and runs one forward) before other stream-creating libraries -- bench.py does, INTEGRATION.md section 2.
 // Measured and not adopted (profiles/r03_batch1_option_ab.log): streams of the highest priority, whose queues come from a
 // pool of their own (option streams = 2): robust against what the framework created, 815 / 807 img/s plain / under
 // torch.distributed -- but with two engines in a process the second one's batch-1 forward took 2.4 ms instead of 1.64 (more
@@ -960,8 +960,17 @@ int make_plans(ssd_handle *h, int B, int H, int W)
                 HIPCHK(hipStreamCreateWithFlags(&pl->s_aux, hipStreamNonBlocking));
                 for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithPriority(&pl->s_bb[i], hipStreamNonBlocking, want == 1 ? least : greatest));
             } else {
-                if (h->side_streams.size() < (size_t)4 * (k + 1)) h->side_streams.resize((size_t)4 * (k + 1), nullptr);
-                hipStream_t *ss = &h->side_streams[(size_t)4 * k];
+                // ONE set of internal streams per device and process, created by the first plan that needs them and shared by every
+                // handle after it (a handle's ops stay ordered per stream and across streams by their events; two handles that
+                // run at the same time merely take turns on them): a second engine -- bench.py's ShuffleNet leg behind the
+                // MobileNet one -- runs on the hardware queues the first one got, instead of on whatever is least loaded by then
+                // (measured: 1 113 instead of 1 200 img/s when its class-tower stream landed on the caller's queue).
+                static std::mutex pool_mu;
+                static std::map<int, std::vector<hipStream_t>> pool;       // device -> [4 k + i]
+                std::lock_guard<std::mutex> lk(pool_mu);
+                std::vector<hipStream_t> &pv = pool[h->cfg.device];
+                if (pv.size() < (size_t)4 * (k + 1)) pv.resize((size_t)4 * (k + 1), nullptr);
+                hipStream_t *ss = &pv[(size_t)4 * k];
                 for (int i = (k > 0 ? 0 : 1); i < 4; ++i)
                     if (!ss[i]) SSDCHK(ssd_side_stream(h, &ss[i]));
                 pl->s_main = k > 0 ? ss[0] : nullptr;
