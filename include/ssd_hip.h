@@ -114,7 +114,8 @@ int ssd_get_precision(ssd_handle *h);
  *   "tower_group"     0 | 1: layer i of the box and the class tower as one launch over 2 x 5 levels      (0)
  *   "head_serial"     -1 auto | 0 | 1: the box head behind the class logits instead of beside them       (-1)
  *   "side_priority"   0 | 1 | 2: the streams of fpn p6 / p7 at the lowest / highest dispatch priority    (0)
- *   "fpn_p6_first"    0 | 1 | 2: the grouped fpn launch waits for p6 / for p7                            (0)
+ *   "fpn_p6_first"    3: fpn p6 -> p7 on the caller's stream, the lateral chain beside them (batch <= 2) | 0: p6 -> p7 on the
+ *                     third stream | 1 | 2: ... and the grouped fpn launch waits for p6 / for p7         (3)
  *   "igemm16"         -1 auto | 0 | 1: F16X3 launches on the 256x256-tile kernel                         (-1)
  *   "igemm_96"        1 | 0: 128x96 tiles for widths 96 divides and 128 does not (read by ssd_finalize)  (1)
  *   "lateral_split"   1 | 0: F16X3 laterals split fp32 rows while staging them                           (1)

@@ -51,7 +51,7 @@ enum SsdOpt {
     OPT_HEAD_SERIAL,        // -1 auto | 0 | 1: the box head behind the class logits on one stream instead of beside them
     OPT_SIDE_PRIORITY,      // 0 (default) | 1: the plan's third / fourth stream at the lowest dispatch priority
     OPT_TOWER_GROUP,        // 0 (default) | 1: layer i of the box and the class tower as ONE launch over 2 x 5 levels (exact fp32)
-    OPT_FPN_P6_FIRST,       // 0 | 1: the grouped p3+p4+p5 launch waits for fpn p6 (batch 1: p6 is not starved beside it)
+    OPT_FPN_P6_FIRST,       // 3 (default): fpn p6 -> p7 on the main stream, the laterals beside them | 0: p6 -> p7 on the third stream | 1 / 2: ... and the grouped launch waits for p6 / p7
     OPT_COUNT
 };
 #define SSD_OPT_UNSET INT_MIN

@@ -590,9 +590,25 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     // last backbone op on the main stream (produces c5, or its first half); the second half, if any, ends on the
     // second stream: the main stream's first FPN op waits for it
     const int id_c5 = id_bb_last[0] >= 0 ? id_bb_last[0] : (int)pl.ops.size() - 1;
+    bool grouped = false;
+    if (!X16 && h->pgroup.wt) {
+        const long long b64 = (((long long)B * py.h[0] * py.w[0] + 63) / 64) * (256 / 64);
+        grouped = b64 <= 640;
+        const int pin = ssd_opt(h, OPT_FPN_GROUP, -1);
+        if (pin >= 0) grouped = pin != 0;
+    }
+    // Batch <= 2 with the grouped launch: p6 -> p7 on the MAIN stream right behind c5 and the lateral chain on the third stream
+    // beside them; the grouped launch waits for lateral3 (done long before p7) and nothing waits for p7 across streams.  With
+    // p6 -> p7 on the third stream (option fpn_p6_first = 0) p6 is starved beside the grouped launch -- a chain of 32-cycle MFMAs
+    // among 64-cycle ones: 57 us alone, ~170 there -- and the towers wait ~50 us for p7 behind it; the grouped launch waiting
+    // for p6 or p7 there (= 1 / 2) moved nothing.  Batch-1 forward 1.661 -> 1.653 ms (profiles/r03_batch1_option_ab.log).
+    const int p6opt = ssd_opt(h, OPT_FPN_P6_FIRST, 3);
+    const bool swap67 = grouped && B <= 2 && !ssd_opt(h, OPT_GRAPH, 0) && p6opt == 3;
+    const int s_lat = swap67 ? 2 : 0;
     std::vector<int> l5_deps;
     for (int c = 1; c < 4; ++c) if (id_bb_last[c] >= 0) l5_deps.push_back(id_bb_last[c]);
-    const int id_l5 = push(make_conv_op(h, h->lat[2], C5, X5, nullptr, nullptr, B, 1, 0, SSD_ACT_NONE, {lvl(2, 256)}, true, X16, X16, 0, FL), 0, l5_deps);
+    if (swap67) l5_deps.push_back(id_c5);
+    const int id_l5 = push(make_conv_op(h, h->lat[2], C5, X5, nullptr, nullptr, B, 1, 0, SSD_ACT_NONE, {lvl(2, 256)}, true, X16, X16, 0, FL), s_lat, l5_deps);
     // (hipGraph capture of a forward with this third forked stream crashed inside the ROCm 7.2 runtime, and so did a captured
     //  wait on an event of the waiting stream itself: with option graph = 1 p6 -> p7 stay on the second stream, in front of p5
     //  and p4, as in round 1; enqueue_forward skips same-stream waits)
@@ -603,10 +619,10 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     {   // p6 = conv s2 (c5): BN+ReLU -> P6, ReLU(raw) -> T6 (input of p7, :60)
         LevelDesc d = dense_level(py.h[2], py.w[2], py.h[3], py.w[3], 256);
         d.out_off = py.off[3];
-        id_p6 = push(make_conv_op(h, h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), s6, p6_deps);
+        id_p6 = push(make_conv_op(h, h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), swap67 ? 0 : s6, p6_deps);
         LevelDesc d7 = dense_level(py.h[3], py.w[3], py.h[4], py.w[4], 256);
         d7.out_off = py.off[4];
-        id_p7 = push(make_conv_op(h, h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true, X16, X16, 0, FL), s6);
+        id_p7 = push(make_conv_op(h, h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true, X16, X16, 0, FL), swap67 ? 0 : s6);
     }
     // Batch 1 in exact fp32: p3, p4 and p5 (the same 3x3 256 -> 256 + batch norm + ReLU on x3, x4, x5) as ONE launch behind
     // lateral3, each level with its own kernel (IgemmLevel::wt_off into h->pgroup) and batch norm.  Measured, one stream
@@ -614,13 +630,6 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     // beside each other on three streams they stretched to 129 / 73 / 61 us and the towers started 266 us after c5.  The
     // grouped launch is 736 tiles -- a tower-sized launch, ~108 us -- and nothing else competes with the lateral chain.
     // Option fpn_group = 0 / 1 pins it.
-    bool grouped = false;
-    if (!X16 && h->pgroup.wt) {
-        const long long b64 = (((long long)B * py.h[0] * py.w[0] + 63) / 64) * (256 / 64);
-        grouped = b64 <= 640;
-        const int pin = ssd_opt(h, OPT_FPN_GROUP, -1);
-        if (pin >= 0) grouped = pin != 0;
-    }
     if (!grouped) {   // p5 = conv(x5)
         LevelDesc d = lvl(2, 256);
         d.out_off = py.off[2];
@@ -632,14 +641,14 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     // output follow the mode
     int LF = X16 && h->lat[1].tile == IGEMM_128x128 && h->lat[0].tile == IGEMM_128x128 ? 2 : 0;
     if (!ssd_opt(h, OPT_LATERAL_SPLIT, 1)) LF = 0;       // A/B runs: 0 keeps them on the exact MFMA
-    const int id_l4 = push(make_conv_op(h, h->lat[1], C4, X4, nullptr, X5, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true, LF, X16, X16, FL), 0);
+    const int id_l4 = push(make_conv_op(h, h->lat[1], C4, X4, nullptr, X5, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true, LF, X16, X16, FL), s_lat);
     int id_p4, id_p3;
     if (!grouped) {
         LevelDesc d = lvl(1, 256);
         d.out_off = py.off[1];
         id_p4 = push(make_conv_op(h, h->pconv[1], X4, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 1, {id_l4});
     }
-    push(make_conv_op(h, h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true, LF, X16, X16, FL), 0);
+    const int id_l3 = push(make_conv_op(h, h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true, LF, X16, X16, FL), s_lat);
     if (!grouped) {
         LevelDesc d = lvl(0, 256);
         d.out_off = py.off[0];
@@ -657,11 +666,10 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             d.wt_off = (long long)l * g.taps * g.CoutPad * g.CinP;
             lv3.push_back(d);
         }
-        // option fpn_p6_first = 1: the launch waits for p6 (third stream).  p6 is a chain of 2 304 dependent 32-cycle MFMAs; beside
-        // this launch's 64-cycle ones it gets one issue slot in ~7 (59 us alone, ~175 us here) and p7 -> the towers wait for it
         std::vector<int> gdeps;
-        if (s6 == 2 && ssd_opt(h, OPT_FPN_P6_FIRST, 0) == 1) gdeps.push_back(id_p6);
-        else if (s6 == 2 && ssd_opt(h, OPT_FPN_P6_FIRST, 0) == 2) gdeps.push_back(id_p7);
+        if (swap67) gdeps.push_back(id_l3);
+        else if (s6 == 2 && p6opt == 1) gdeps.push_back(id_p6);
+        else if (s6 == 2 && p6opt == 2) gdeps.push_back(id_p7);
         id_p3 = id_p4 = push(make_conv_op(h, g, X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv3, true), 0, gdeps);
         pl.ops[id_p3].fpn_end = true;
     }
@@ -819,7 +827,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     int id_box_last = -1;
     int id_coarse0[2] = {-1, -1};
     if (split0)
-        for (int t = 0; t < 2; ++t) id_coarse0[t] = push(coarse0[t], s6);     // behind p7 on its stream
+        for (int t = 0; t < 2; ++t) id_coarse0[t] = push(coarse0[t], s6, {id_p7});     // behind p7 (a same-stream wait is skipped)
     for (size_t i = 0; i < tower_ops[0][0].size(); ++i)
         for (int t = 1; t >= 0; --t) {
             std::vector<int> deps;

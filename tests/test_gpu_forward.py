@@ -164,7 +164,7 @@ def test_small_batch_plan_variants_are_bit_identical(cuda, ssd, oracle_graph, H,
         for n in names:
             assert np.array_equal(base_t[n], keep[n].reshape(base_t[n].shape)), n
     variants = [{"igemm_lat": 0}, {"fpn_group": 0}, {"igemm_deep64": 0}, {"streams": 1}, {"head_serial": 1}, {"side_priority": 1},
-                {"side_priority": 2}, {"fpn_p6_first": 1}, {"tower_group": 1}, {"tower_group": 1, "streams": 1}, {"level_split": 2}, {"level_split": 1}, {"streams": 2}, {"igemm_tile": 20}, {"igemm_tile": 25}, {"igemm_lat": 0, "fpn_group": 0, "igemm_deep64": 0}]
+                {"side_priority": 2}, {"fpn_p6_first": 0}, {"fpn_p6_first": 1}, {"fpn_p6_first": 2}, {"tower_group": 1}, {"tower_group": 1, "streams": 1}, {"level_split": 2}, {"level_split": 1}, {"streams": 2}, {"igemm_tile": 20}, {"igemm_tile": 25}, {"igemm_lat": 0, "fpn_group": 0, "igemm_deep64": 0}]
     for v in variants:
         for k, val in v.items():
             eng.set_option(k, val)
