@@ -506,7 +506,7 @@ __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
             __syncthreads();
         }
     }
-    if (n > p.mid_max) {                    // too long for this block's registers: post_nms_regs_kernel / post_nms_big_kernel
+    if (n > p.mid_max) {                    // too long for this block's registers: post_nms_long_kernel
         if (tid == 0) p.big_list[atomicAdd(p.big_n, 1)] = bc;
         return;
     }
@@ -518,18 +518,18 @@ __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
 // same in-register rounds (nms_block).  A kernel of its own: beside the global-memory path of post_nms_big_kernel the
 // 128-register budget of a 1 024-thread block spilled into the rounds (that kernel took 96 us for ONE list of 4 085
 // candidates at batch 1: 3.8 us per round).
-__global__ __launch_bounds__(NMS_BIG) void post_nms_regs_kernel(const PostArgs p)
+static __device__ __forceinline__ void nms_long_regs(const PostArgs &p, const int bid, const int nblocks)
 {
     __shared__ u64 rbest[2][NMS_BIG / 64];
     __shared__ v4f rbox[2][NMS_BIG / 64];
     const int tid = threadIdx.x;
     const int nbig = *p.big_n;
-    for (int item = blockIdx.x; item < nbig; item += gridDim.x) {
+    for (int item = bid; item < nbig; item += nblocks) {
         const int bc = p.big_list[item];
         const int b = bc / p.C;
         int n = p.counts[bc];
         if (n > p.N) n = p.N;
-        if (n > NMS_BIG * NMS_R) continue;   // post_nms_big_kernel's (block-uniform)
+        if (n > NMS_BIG * NMS_R) continue;   // nms_long_global's (block-uniform)
         const int kept = nms_block<NMS_BIG>(p, p.keys + (long long)bc * p.N, p.dec + (long long)b * p.N * 4, n, tid,
                                             p.cls_boxes + (long long)bc * p.max_per_class * 4, p.cls_scores + (long long)bc * p.max_per_class,
                                             rbest, rbox);
@@ -544,12 +544,12 @@ __global__ __launch_bounds__(NMS_BIG) void post_nms_regs_kernel(const PostArgs p
 // The blocks take their (image, class) pairs from the work list the small kernel filled: most lists are short
 // and never come here, and a block of 1024 threads with 80 KB of LDS that only looks at its count and leaves
 // still costs its launch -- one block per pair made this kernel 0.31 ms of a 32-image step for 64 long lists.
-__global__ __launch_bounds__(NMS_BIG) void post_nms_big_kernel(const PostArgs p)
+static __device__ __forceinline__ void nms_long_global(const PostArgs &p, const int bid, const int nblocks)
 {
     __shared__ u64 wbest[2][NMS_BIG / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbig = *p.big_n;
-    for (int item = blockIdx.x; item < nbig; item += gridDim.x) {
+    for (int item = bid; item < nbig; item += nblocks) {
     const int bc = p.big_list[item];
     const int b = bc / p.C;
     int n = p.counts[bc];
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(NMS_BIG) void post_nms_big_kernel(const PostArgs p)
     const float *dec = p.dec + (long long)b * p.N * 4;
     float *ob = p.cls_boxes + (long long)bc * p.max_per_class * 4;
     float *os = p.cls_scores + (long long)bc * p.max_per_class;
-    if (n <= NMS_BIG * NMS_R) continue;      // post_nms_regs_kernel's (block-uniform)
+    if (n <= NMS_BIG * NMS_R) continue;      // nms_long_regs's (block-uniform)
     // Lists longer than the register capacity: greedy NMS only consumes candidates in
     // descending score order until max_per_class boxes are kept, so first try the top
     // scores alone -- a score histogram picks the largest score cut that leaves at most
@@ -676,6 +676,16 @@ restart:
     if (tid == 0) p.cls_counts[bc] = kept;
     __syncthreads();                         // the shared arrays are reused by the next pair
     }
+}
+
+// K9c, both forms of the long lists in ONE launch (most forwards have no such list, and an empty launch of 1 024-thread
+// blocks costs its 5 us all the same): blocks [0, nregs) take the work list's pairs of at most NMS_BIG * NMS_R candidates,
+// the others the longer ones.  Two code paths without a common live register: the kernel needs the larger budget of the
+// two, not their sum (one loop over both forms spilled 67 registers into the rounds).
+__global__ __launch_bounds__(NMS_BIG) void post_nms_long_kernel(const PostArgs p, const int nregs)
+{
+    if ((int)blockIdx.x < nregs) nms_long_regs(p, (int)blockIdx.x, nregs);
+    else nms_long_global(p, (int)blockIdx.x - nregs, (int)gridDim.x - nregs);
 }
 
 __global__ __launch_bounds__(256) void post_pack_kernel(const PostArgs p)
@@ -810,8 +820,8 @@ hipError_t launch_postprocess(const PostArgs &pin, hipStream_t s)
     hipLaunchKernelGGL(post_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
     hipLaunchKernelGGL(post_nms_kernel, dim3((unsigned)(p.B * p.C)), dim3(NMS_MID), 0, s, p);
     const int big_blocks = p.B * p.C < 512 ? p.B * p.C : 512;     // two resident blocks per CU
-    hipLaunchKernelGGL(post_nms_regs_kernel, dim3((unsigned)big_blocks), dim3(NMS_BIG), 0, s, p);
-    hipLaunchKernelGGL(post_nms_big_kernel, dim3((unsigned)(big_blocks < 64 ? big_blocks : 64)), dim3(NMS_BIG), 0, s, p);
+    const int long_blocks = big_blocks < 64 ? big_blocks : 64;
+    hipLaunchKernelGGL(post_nms_long_kernel, dim3((unsigned)(big_blocks + long_blocks)), dim3(NMS_BIG), 0, s, p, big_blocks);
     hipLaunchKernelGGL(post_pack_kernel, dim3((unsigned)p.B), dim3(256), (p.C + 1) * sizeof(int), s, p);
     return hipGetLastError();
 }
