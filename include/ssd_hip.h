@@ -185,6 +185,13 @@ int ssd_profile_reset(ssd_handle *h);
 /* AnchorGenerator.__call__ (anchor_generator.py:40-120) with model.py:37-42 constants. */
 int32_t ssd_num_anchors(int32_t H, int32_t W);
 int ssd_anchors(int32_t H, int32_t W, float *anchors_host /* [N,4] */);
+/* AnchorGenerator(strides, scales, scale_multipliers, aspect_ratios).__call__ (anchor_generator.py:13-120) for any
+ * hyper-parameters: n_levels strides / scales, anchors per location = n_mult * n_ratios in itertools.product order.
+ * Returns the number of anchors N (>= 0) or a negative SSD_ERR_*; writes [N,4] when anchors_host != NULL and
+ * capacity_rows >= N (call once with NULL to size the buffer). */
+int64_t ssd_anchors_ex(int32_t H, int32_t W, int32_t n_levels, const int32_t *strides, const double *scales,
+                       int32_t n_mult, const double *multipliers, int32_t n_ratios, const double *ratios,
+                       float *anchors_host, int64_t capacity_rows);
 
 /* Dense k x k convolution (k = 1 or 3) on the MFMA implicit-GEMM kernel:
  * slim.conv2d / tf.layers.conv2d / conv2d_same (mobilenet_v1.py:49,66;

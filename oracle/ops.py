@@ -36,6 +36,7 @@ def lib():
         _lib.orc_sigmoid.restype = ctypes.c_float
         _lib.orc_sigmoid.argtypes = [ctypes.c_float]
         _lib.orc_num_anchors.restype = _i
+        _lib.orc_anchors_ex.restype = ctypes.c_longlong
     return _lib
 
 
@@ -190,6 +191,20 @@ def anchors(H, W):
     n = lib().orc_num_anchors(_i(H), _i(W))
     out = np.empty((n, 4), np.float32)
     lib().orc_anchors(_i(H), _i(W), _p(out))
+    return out
+
+
+def anchors_ex(H, W, strides, scales, scale_multipliers, aspect_ratios):
+    """AnchorGenerator(strides, scales, scale_multipliers, aspect_ratios)(H, W) (anchor_generator.py:13-120)."""
+    n = len(strides)
+    st = (ctypes.c_int * n)(*[int(s) for s in strides])
+    sc = (ctypes.c_double * n)(*[float(s) for s in scales])
+    mu = (ctypes.c_double * len(scale_multipliers))(*[float(m) for m in scale_multipliers])
+    ar = (ctypes.c_double * len(aspect_ratios))(*[float(a) for a in aspect_ratios])
+    args = (_i(H), _i(W), _i(n), st, sc, _i(len(mu)), mu, _i(len(ar)), ar)
+    cnt = lib().orc_anchors_ex(*args, None)
+    out = np.empty((cnt, 4), np.float32)
+    lib().orc_anchors_ex(*args, _p(out))
     return out
 
 

@@ -425,6 +425,53 @@ ORC_API void orc_anchors(int H, int W, float *out /* [N,4] */)
     }
 }
 
+/* AnchorGenerator with ANY hyper-parameters (anchor_generator.py:13-38): the same graph, written the way tile_anchors
+ * builds it (:123-170) -- the level's height / width vectors, the centre vectors of the grid, then
+ * concat([centres - 0.5 * sizes, centres + 0.5 * sizes]) and the division by [H, W, H, W] (:110-114).
+ * Returns the number of anchors; writes when out != NULL. */
+ORC_API long long orc_anchors_ex(int H, int W, int n_levels, const int *strides, const double *scales, int n_mult,
+                                 const double *multipliers, int n_ratios, const double *ratios, float *out)
+{
+    const int N = n_mult * n_ratios;
+    const float image_height = (float)H, image_width = (float)W;
+    long long idx = 0;
+    float *heights = (float *)malloc(sizeof(float) * N), *widths = (float *)malloc(sizeof(float) * N);
+    for (int l = 0; l < n_levels; ++l) {
+        const float stride = (float)strides[l];
+        const int h = (int)ceilf(image_height / stride), w = (int)ceilf(image_width / stride);
+        if (!out) { idx += (long long)h * w * N; continue; }
+        for (int m = 0, a = 0; m < n_mult; ++m)
+            for (int r = 0; r < n_ratios; ++r, ++a) {
+                const float scale = (float)(multipliers[m] * scales[l]);      /* tf.constant(m * scale, float32) (:75) */
+                const float ratio_sqrt = sqrtf((float)ratios[r]);             /* :145 */
+                heights[a] = scale / ratio_sqrt;
+                widths[a] = scale * ratio_sqrt;
+            }
+        float t = ((float)h - 1.0f) * stride;
+        const float offset_y = 0.5f * (image_height - t);                     /* :92 */
+        t = ((float)w - 1.0f) * stride;
+        const float offset_x = 0.5f * (image_width - t);
+        for (int i = 0; i < h; ++i) {
+            float yc = (float)i * stride;                                     /* :152 */
+            yc = yc + offset_y;
+            for (int j = 0; j < w; ++j) {
+                float xc = (float)j * stride;
+                xc = xc + offset_x;
+                for (int a = 0; a < N; ++a, ++idx) {
+                    const float sh = 0.5f * heights[a], sw = 0.5f * widths[a];   /* :167 */
+                    out[idx * 4 + 0] = (yc - sh) / image_height;
+                    out[idx * 4 + 1] = (xc - sw) / image_width;
+                    out[idx * 4 + 2] = (yc + sh) / image_height;
+                    out[idx * 4 + 3] = (xc + sw) / image_width;
+                }
+            }
+        }
+    }
+    free(heights);
+    free(widths);
+    return idx;
+}
+
 /* ------------------------------------------------------------------------- */
 /* ssd.py:60 tf.sigmoid; correctly rounded fp32 value of 1/(1+e^-x).         */
 ORC_API float orc_sigmoid(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }

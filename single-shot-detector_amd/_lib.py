@@ -35,7 +35,7 @@ def build(force=False, verbose=False, diag=False):
     srcs = [os.path.join(_CSRC, s) for s in _SOURCES]
     deps = srcs + [os.path.join(_CSRC, "ssd_internal.h"), os.path.join(_CSRC, "host.h"), os.path.join(_CSRC, "igemm_mfma16.h"),
                    os.path.join(_HERE, "..", "include", "ssd_hip.h"),
-                   os.path.join(_HERE, "..", "include", "ssd_hip_diag.h")]
+                   os.path.join(_HERE, "..", "include", "ssd_hip_diag.h"), os.path.join(_CSRC, "exports.map")]
     target = _DIAG_PATH if diag else _LIB_PATH
     # freshness by CONTENT (sha256 of sources + headers + flags, kept beside the library), not by mtime: the
     # snapshot that travels to a GPU box does not promise to preserve modification-time order
@@ -90,7 +90,8 @@ def build(force=False, verbose=False, diag=False):
                 with open(ostamp, "w") as f:
                     f.write(odig)
             objs = [os.path.join(objdir, os.path.basename(src) + ".o") for src in srcs]
-            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(_CSRC, "exports.map"),
+                   "-o", tmp] + objs
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
@@ -136,6 +137,8 @@ SIGNATURES = {
     "ssd_profile_reset": (ctypes.c_int, [_vp]),
     "ssd_num_anchors": (ctypes.c_int32, [_i, _i]),
     "ssd_anchors": (ctypes.c_int, [_i, _i, _f]),
+    "ssd_anchors_ex": (ctypes.c_int64, [_i, _i, _i, _i32p, ctypes.POINTER(ctypes.c_double), _i, ctypes.POINTER(ctypes.c_double),
+                                        _i, ctypes.POINTER(ctypes.c_double), _f, ctypes.c_int64]),
     "ssd_conv2d": (ctypes.c_int, [_vp, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f,
                                   _vp, _i, _vp, _vp]),
     "ssd_conv2d_f16x3": (ctypes.c_int, [_vp, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f,

@@ -25,23 +25,37 @@ extern "C" int32_t ssd_num_anchors(int32_t H, int32_t W)
     return n;
 }
 
-// anchor_generator.py:40-170 in the fp32 arithmetic of the TF graph (host side, once per
-// image size).  Constants: model.py:37-42.
-extern "C" int ssd_anchors(int32_t H, int32_t W, float *out)
+// anchor_generator.py:13-170 in the fp32 arithmetic of the TF graph (host side, once per image size), any
+// hyper-parameters: `scales = tf.constant([m * self.scales[i] ...], tf.float32)` is a Python (double) product rounded to
+// fp32, the aspect ratios are the doubles rounded to fp32 (:70-75); h, w = ceil of the fp32 quotient (:59-60).
+// Returns the number of anchors (written when `out` is non-null and `capacity` rows suffice) or a negative error code.
+extern "C" int64_t ssd_anchors_ex(int32_t H, int32_t W, int32_t n_levels, const int32_t *strides, const double *scales,
+                                  int32_t n_mult, const double *multipliers, int32_t n_ratios, const double *ratios,
+                                  float *out, int64_t capacity)
 {
-    if (H <= 0 || W <= 0 || !out) return ssd_fail(SSD_ERR_INVALID, "ssd_anchors: bad arguments");
-    static const double base[5] = {32, 64, 128, 256, 512}, mult[2] = {1.0, 1.4142}, ars[3] = {1.0, 2.0, 0.5};
+    if (H <= 0 || W <= 0 || n_levels < 1 || n_mult < 1 || n_ratios < 1 || !strides || !scales || !multipliers || !ratios)
+        return ssd_fail(SSD_ERR_INVALID, "ssd_anchors_ex: bad arguments");
+    for (int l = 0; l < n_levels; ++l)
+        if (strides[l] < 1) return ssd_fail(SSD_ERR_INVALID, "ssd_anchors_ex: strides must be positive");
+    const int A = n_mult * n_ratios;
     const float ih = (float)H, iw = (float)W;
+    long long total = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const float stride = (float)strides[l];
+        total += (long long)ceilf(ih / stride) * (long long)ceilf(iw / stride) * A;
+    }
+    if (!out) return total;
+    if (capacity < total) return ssd_fail(SSD_ERR_INVALID, "ssd_anchors_ex: output too small");
+    std::vector<float> hh(A), hw(A);
     long long idx = 0;
-    for (int l = 0; l < 5; ++l) {
-        const float stride = (float)A_STRIDES[l];
+    for (int l = 0; l < n_levels; ++l) {
+        const float stride = (float)strides[l];
         const int h = (int)ceilf(ih / stride), w = (int)ceilf(iw / stride);
-        float hh[6], hw[6];
         int a = 0;
-        for (int m = 0; m < 2; ++m)
-            for (int r = 0; r < 3; ++r, ++a) {
-                const float scale = (float)(mult[m] * base[l]);
-                const float rs = sqrtf((float)ars[r]);
+        for (int m = 0; m < n_mult; ++m)              // itertools.product(scale_multipliers, aspect_ratios)
+            for (int r = 0; r < n_ratios; ++r, ++a) {
+                const float scale = (float)(multipliers[m] * scales[l]);
+                const float rs = sqrtf((float)ratios[r]);
                 const float height = scale / rs, width = scale * rs;
                 hh[a] = 0.5f * height;
                 hw[a] = 0.5f * width;
@@ -56,7 +70,7 @@ extern "C" int ssd_anchors(int32_t H, int32_t W, float *out)
             for (int j = 0; j < w; ++j) {
                 float cx = (float)j * stride;
                 cx = cx + offx;
-                for (a = 0; a < 6; ++a, ++idx) {
+                for (a = 0; a < A; ++a, ++idx) {
                     out[idx * 4 + 0] = (cy - hh[a]) / ih;
                     out[idx * 4 + 1] = (cx - hw[a]) / iw;
                     out[idx * 4 + 2] = (cy + hh[a]) / ih;
@@ -65,7 +79,16 @@ extern "C" int ssd_anchors(int32_t H, int32_t W, float *out)
             }
         }
     }
-    return SSD_OK;
+    return total;
+}
+
+// ... with the constants model.py:37-42 fixes for the exported graph (what every plan uses)
+extern "C" int ssd_anchors(int32_t H, int32_t W, float *out)
+{
+    if (H <= 0 || W <= 0 || !out) return ssd_fail(SSD_ERR_INVALID, "ssd_anchors: bad arguments");
+    static const double base[5] = {32, 64, 128, 256, 512}, mult[2] = {1.0, 1.4142}, ars[3] = {1.0, 2.0, 0.5};
+    const int64_t n = ssd_anchors_ex(H, W, 5, A_STRIDES, base, 2, mult, 3, ars, out, (int64_t)ssd_num_anchors(H, W));
+    return n < 0 ? (int)n : SSD_OK;
 }
 
 // resize_keeping_aspect_ratio (pipeline.py:138-194), the size arithmetic of the TF graph:

@@ -157,26 +157,35 @@ def concat_shuffle_split(x, y):
 
 
 class AnchorGenerator:
-    """detector/anchor_generator.py:12-120 with the hyper-parameters model.py:37-42 fixes
-    (the C ABI hard-codes exactly those; other values raise)."""
+    """detector/anchor_generator.py:12-120: any strides / scales / scale multipliers / aspect ratios (ssd_anchors_ex; the
+    defaults are the values model.py:37-42 fixes for the exported graph)."""
 
     def __init__(self, strides=[8, 16, 32, 64, 128], scales=[32, 64, 128, 256, 512],
                  scale_multipliers=[1.0, 1.4142], aspect_ratios=[1.0, 2.0, 0.5]):
-        if (list(strides), list(scales), list(scale_multipliers), list(aspect_ratios)) != \
-                ([8, 16, 32, 64, 128], [32, 64, 128, 256, 512], [1.0, 1.4142], [1.0, 2.0, 0.5]):
-            raise NotImplementedError("only the anchor hyper-parameters of model.py:37-42")
+        assert len(strides) == len(scales)                      # anchor_generator.py:33
         self.strides, self.scales = list(strides), list(scales)
         self.scale_multipliers, self.aspect_ratios = list(scale_multipliers), list(aspect_ratios)
         self.num_anchors_per_location = len(aspect_ratios) * len(scale_multipliers)
 
+    def _call(self, H, W, out, cap):
+        n = len(self.strides)
+        st = (ctypes.c_int32 * n)(*[int(s) for s in self.strides])
+        sc = (ctypes.c_double * n)(*[float(s) for s in self.scales])
+        mu = (ctypes.c_double * len(self.scale_multipliers))(*[float(m) for m in self.scale_multipliers])
+        ar = (ctypes.c_double * len(self.aspect_ratios))(*[float(a) for a in self.aspect_ratios])
+        r = lib().ssd_anchors_ex(int(H), int(W), n, st, sc, len(mu), mu, len(ar), ar, out, cap)
+        if r < 0:
+            check(int(r))
+        return int(r)
+
     def __call__(self, image_height, image_width):
         """-> float32 ndarray [num_anchors, 4], normalised ymin,xmin,ymax,xmax, not clipped."""
-        n = lib().ssd_num_anchors(int(image_height), int(image_width))
+        n = self._call(image_height, image_width, None, 0)
         out = np.empty((n, 4), np.float32)
-        check(lib().ssd_anchors(int(image_height), int(image_width),
-                                out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        self._call(image_height, image_width, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), n)
+        ih, iw = np.float32(image_height), np.float32(image_width)
         self.num_anchors_per_feature_map = [
-            -(-int(image_height) // s) * -(-int(image_width) // s) * self.num_anchors_per_location
+            int(np.ceil(ih / np.float32(s))) * int(np.ceil(iw / np.float32(s))) * self.num_anchors_per_location
             for s in self.strides]
         return out
 

@@ -144,6 +144,12 @@ def test_abi_exports_every_declared_symbol(ssd):
     assert diag == {"ssd_bench_conv", "ssd_bench_dwpw"} == set(import_module("ssd_amd._lib").DIAG_SIGNATURES)
     for name in diag:
         assert not hasattr(lib, name), name + " exported by the shipped library"
+    # ... and NOTHING else: the header is the boundary (csrc/exports.map); C++ internals stay local to the library
+    import subprocess
+    for path in (ssd.lib_path(),):
+        names = [l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", path], text=True).splitlines() if l.strip()]
+        assert names and all(n.startswith("ssd_") for n in names), [n for n in names if not n.startswith("ssd_")][:5]
+        assert set(names) == declared
     blob = open(ssd.lib_path(), "rb").read()
     for switch in (b"SSD_IGEMM16_DBG", b"SSD_BENCH_PRECISION", b"SSD_TS_DUMP"):
         assert switch not in blob, switch
@@ -181,8 +187,19 @@ def test_anchors_host_side(ssd, oracle_ops):
     for H, W in [(640, 896), (640, 640), (128, 128), (256, 384)]:
         a = ssd.AnchorGenerator()(H, W)
         assert np.array_equal(a, oracle_ops.anchors(H, W))
-    with pytest.raises(NotImplementedError):
-        ssd.AnchorGenerator(scales=[16, 32, 64, 128, 256])
+    # any hyper-parameters (anchor_generator.py:13-38): ssd_anchors_ex against the oracle's twin
+    other = dict(strides=[16, 32, 64], scales=[40, 96.5, 200], scale_multipliers=[1.0, 1.26, 1.5874],
+                 aspect_ratios=[1.0, 3.0, 1.0 / 3.0, 0.5])
+    for H, W in [(256, 384), (250, 330), (640, 896)]:
+        g = ssd.AnchorGenerator(**other)
+        a = g(H, W)
+        assert g.num_anchors_per_location == 12 and sum(g.num_anchors_per_feature_map) == len(a)
+        assert np.array_equal(a, oracle_ops.anchors_ex(H, W, other["strides"], other["scales"], other["scale_multipliers"],
+                                                       other["aspect_ratios"]))
+    with pytest.raises(AssertionError):
+        ssd.AnchorGenerator(strides=[8, 16], scales=[32])
+    with pytest.raises(ssd.SsdError):
+        ssd.AnchorGenerator(strides=[0], scales=[32])(128, 128)
 
 
 def test_no_cpu_fallback(ssd):

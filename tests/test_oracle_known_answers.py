@@ -60,6 +60,51 @@ def test_anchor_layout_offsets(oracle_ops):
             assert abs((a[i, 2] - a[i, 0]) - 32 * 2 ** lvl) < 1e-2     # pair (1.0, 1.0)
 
 
+def _tile_anchors_numpy(H, W, strides, scales, mults, ars):
+    """anchor_generator.py:40-170 written as the TF graph is -- whole-tensor fp32 operations, tile_anchors' meshgrid /
+    stack / tile / concat / reshape -- in numpy: a restatement that shares no loop with the oracle's."""
+    import itertools
+    f = np.float32
+    ih, iw = f(H), f(W)
+    pairs = list(itertools.product(mults, ars))
+    ratios = np.array([a for _, a in pairs], f)
+    out = []
+    for i, s in enumerate(strides):
+        st = f(s)
+        h, w = int(np.ceil(ih / st)), int(np.ceil(iw / st))
+        sc = np.array([m * scales[i] for m, _ in pairs], f)
+        oy = f(0.5) * (ih - (f(h) - f(1.0)) * st)
+        ox = f(0.5) * (iw - (f(w) - f(1.0)) * st)
+        rs = np.sqrt(ratios)
+        heights, widths = sc / rs, sc * rs
+        yc = np.arange(h).astype(f) * st + oy
+        xc = np.arange(w).astype(f) * st + ox
+        xg, yg = np.meshgrid(xc, yc)
+        centers = np.tile(np.stack([yg, xg], axis=2)[:, :, None, :], (1, 1, len(pairs), 1))
+        sizes = np.tile(np.stack([heights, widths], axis=1)[None, None], (h, w, 1, 1))
+        out.append(np.concatenate([centers - f(0.5) * sizes, centers + f(0.5) * sizes], axis=3).reshape(-1, 4))
+    return (np.concatenate(out, 0) / np.array([ih, iw, ih, iw], f)).astype(f)
+
+
+def test_anchor_generator_any_hyper_parameters(oracle_ops):
+    # AnchorGenerator.__init__ takes any strides / scales / multipliers / ratios (anchor_generator.py:13-38)
+    default = ([8, 16, 32, 64, 128], [32, 64, 128, 256, 512], [1.0, 1.4142], [1.0, 2.0, 0.5])
+    assert np.array_equal(oracle_ops.anchors_ex(640, 896, *default), oracle_ops.anchors(640, 896))
+    assert np.array_equal(oracle_ops.anchors_ex(256, 384, *default), _tile_anchors_numpy(256, 384, *default))
+    other = ([16, 32, 64], [40, 96.5, 200], [1.0, 1.26, 1.5874], [1.0, 3.0, 1.0 / 3.0, 0.5])
+    for H, W in [(256, 384), (250, 330)]:          # the second: sizes the strides do not divide (ceil, offsets < stride / 2)
+        a = oracle_ops.anchors_ex(H, W, *other)
+        assert a.shape == (sum(-(-H // s) * -(-W // s) for s in other[0]) * 12, 4)
+        assert np.array_equal(a, _tile_anchors_numpy(H, W, *other))
+    # known answers by hand, 256x384, level 0 (stride 16, scale 40), cell (0,0): centre (8, 8)
+    a = oracle_ops.anchors_ex(256, 384, *other) * np.array([256, 384, 256, 384], np.float32)
+    np.testing.assert_allclose(a[0], [8 - 20, 8 - 20, 8 + 20, 8 + 20], atol=1e-4)                     # (1.0, 1.0)
+    r3 = math.sqrt(3.0)
+    np.testing.assert_allclose(a[1], [8 - 20 / r3, 8 - 20 * r3, 8 + 20 / r3, 8 + 20 * r3], atol=1e-4)  # (1.0, 3.0): w/h = 3
+    np.testing.assert_allclose(a[4], [8 - 25.2, 8 - 25.2, 8 + 25.2, 8 + 25.2], atol=1e-4)              # (1.26, 1.0)
+    np.testing.assert_allclose(a[12], [8 - 20, 24 - 20, 8 + 20, 24 + 20], atol=1e-4)                   # cell (0,1)
+
+
 # --------------------------------------------------------------------------- decode
 def test_decode_known_answers(oracle_ops):
     anc = np.array([[0.2, 0.3, 0.4, 0.7]], np.float32)
