@@ -17,7 +17,7 @@ extern "C" const char *ssd_last_error(void) { return g_err.c_str(); }
 static Options g_opts;                 // process-wide values (ssd_set_option with a NULL handle)
 static std::mutex g_opts_mu;
 static const char *const OPT_NAMES[OPT_COUNT] = {"igemm_tile", "igemm16", "igemm_96", "lateral_split", "backbone_split", "nsub",
-                                                 "level_split", "nms_fast_max", "debug_sync", "fuse_dw", "graph", "igemm_lat", "igemm_deep64", "streams", "fpn_group", "head_serial", "side_priority", "tower_group", "fpn_p6_first"};
+                                                 "level_split", "nms_fast_max", "debug_sync", "fuse_dw", "graph", "igemm_lat", "igemm_deep64", "streams", "fpn_group", "head_serial", "side_priority", "tower_group", "fpn_p6_first", "fpn_p7_group", "event_fence", "lat_one"};
 int ssd_opt_index(const char *key)
 {
     for (int i = 0; i < OPT_COUNT; ++i)
@@ -29,6 +29,14 @@ int ssd_opt(const ssd_handle *h, int key, int dflt)
     if (h && h->opts.v[key] != SSD_OPT_UNSET) return h->opts.v[key];
     const int g = g_opts.v[key];
     return g != SSD_OPT_UNSET ? g : dflt;
+}
+// Events that order the library's streams against each other live on ONE device: no system-scope fence (the default flags
+// make every record write the caches back -- measured as 8-12 us between the kernels on either side of a record or a wait,
+// three of them on the critical path of a batch-1 forward).  Host visibility of the results is the caller's stream
+// synchronisation, as before.
+unsigned ssd_sync_event_flags(const ssd_handle *h)
+{
+    return hipEventDisableTiming | (ssd_opt(h, OPT_EVENT_FENCE, 0) ? 0u : (unsigned)hipEventDisableSystemFence);
 }
 int nms_fast_max(const ssd_handle *h)
 {
@@ -76,10 +84,11 @@ extern "C" int ssd_create(const ssd_config *cfg, ssd_handle **out)
     HIPCHK(hipSetDevice(cfg->device));
     ssd_handle *h = new ssd_handle();
     h->cfg = *cfg;
-    if (hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_gin, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_gout, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming) != hipSuccess) {
+    const unsigned evf = ssd_sync_event_flags(nullptr);
+    if (hipEventCreateWithFlags(&h->ev_start, evf) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_gin, evf) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_gout, evf) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_last, evf) != hipSuccess) {
         delete h;
         return ssd_fail(SSD_ERR_HIP, "ssd_create: cannot create events");
     }
@@ -188,7 +197,14 @@ static int forward_locked(ssd_handle *h, const uint8_t *images_dev, int32_t B, i
         int rc = make_plans(h, B, H, W);
         if (rc != SSD_OK) { free_plans(h); return rc; }
     }
-    if (h->have_last && h->last_stream != s) HIPCHK(hipStreamWaitEvent(s, h->ev_last, 0));
+    // one arena per handle: a forward on another stream than the previous one waits for it.  The event is recorded HERE, at the
+    // current tail of the previous stream (everything the previous forward enqueued there precedes it), not at the end of
+    // every forward: a record behind the last kernel is one more packet the caller's synchronisation waits for.
+    if (h->have_last && h->last_stream != s) {
+        if (hipEventRecord(h->ev_last, h->last_stream) == hipSuccess) HIPCHK(hipStreamWaitEvent(s, h->ev_last, 0));
+        else { (void)hipGetLastError(); HIPCHK(hipDeviceSynchronize()); }      // (the caller destroyed that stream)
+        h->have_last = false;
+    }
     // hipGraph replay (launch-bound regime: batch 1 is ~35 short kernels on a few streams).  A
     // forward whose pointers, shape and stream repeat is captured on the handle's own stream at
     // its second occurrence and replayed from then on; profiling or option graph = 0 keep it eager.
@@ -251,7 +267,6 @@ extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, 
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
         if (cs == hipStreamCaptureStatusNone) {
-            HIPCHK(hipEventRecord(h->ev_last, s));
             h->last_stream = s;
             h->have_last = true;
         }

@@ -52,12 +52,17 @@ enum SsdOpt {
     OPT_SIDE_PRIORITY,      // 0 (default) | 1: the plan's third / fourth stream at the lowest dispatch priority
     OPT_TOWER_GROUP,        // 0 (default) | 1: layer i of the box and the class tower as ONE launch over 2 x 5 levels (exact fp32)
     OPT_FPN_P6_FIRST,       // 3 (default): fpn p6 -> p7 on the main stream, the laterals beside them | 0: p6 -> p7 on the third stream | 1 / 2: ... and the grouped launch waits for p6 / p7
+    OPT_FPN_P7_GROUP,       // 1 (default) | 0: fpn p7 as a fourth level of the grouped p3 + p4 + p5 launch (batch <= 2, exact fp32)
+    OPT_EVENT_FENCE,        // 0 (default): the library's ordering events carry no system-scope fence (hipEventDisableSystemFence: they order
+                            // streams of ONE device) | 1: default event flags (a cache writeback per record: ~8-12 us per cross-stream edge)
+    OPT_LAT_ONE,            // 20 | 28 .. 32: the one-wave tile of igemm_lat.hip the plan gives its tiny launches (fpn p6 / p7 / lateral5 at batch 1-2)
     OPT_COUNT
 };
 #define SSD_OPT_UNSET INT_MIN
 struct Options { int v[OPT_COUNT]; Options() { for (int &x : v) x = SSD_OPT_UNSET; } };
 int ssd_opt(const struct ssd_handle *h, int key, int dflt);      // handle value, else process value, else dflt
 int ssd_opt_index(const char *key);                              // -1: unknown key
+unsigned ssd_sync_event_flags(const struct ssd_handle *h);       // flags of the events that order streams inside the library
 
 // ----------------------------------------------------------------------------- helpers
 struct Tensor {
@@ -153,6 +158,7 @@ struct LevelDesc {
     int out_rstride, param_off;
     long long res_off;
     long long wt_off = 0;           // float offset of this level's kernel inside the ConvW (grouped launches; 0 = shared)
+    int stride = 0, pad = -1;       // > 0 / >= 0: this level's own stride / pad_beg (else the launch's)
 };
 
 // in_fmt / out_fmt / res_fmt: 0 fp32 rows, 1 split-fp16 rows (ssd_internal.h); flags: the handle's status word
@@ -196,6 +202,7 @@ struct Plan {
     bool own_streams = false;           // false: the streams are the process-wide ones (plan.hip make_plans), not destroyed with the plan
     hipEvent_t ev_fpn = nullptr, ev_join = nullptr, ev_done = nullptr, ev_begin = nullptr;
     hipEvent_t ev_join_bb[2] = {nullptr, nullptr};
+    bool need_begin = false;            // some chain starts on an internal stream without a dependency: it waits for ev_begin
     bool tail_on[2] = {false, false};   // the plan's last ops on stream 2 / 3 are not awaited by any later op: join them before the post-processing
     int last_aux = -1;                  // index of the last op on the second stream
 };
@@ -221,7 +228,7 @@ struct ssd_handle {
     std::vector<DwW> dw;                // depthwise layers in execution order
     std::vector<ConvW> pw;              // backbone pointwise layers in execution order
     ConvW lat[3], pconv[5];             // fpn lateral3..5, p3..p7
-    ConvW pgroup;                       // fpn p3 | p4 | p5 kernels and batch norms behind one pointer each: one grouped launch at batch 1
+    ConvW pgroup;                       // fpn p3 | p4 | p5 | p7 kernels and batch norms behind one pointer each: one grouped launch at batch 1
     ConvW tower[2][4], final_[2];       // [box, class]
     ConvW tgroup[4];                    // tower layer i of BOTH nets behind one pointer each (kernel, 2 x 5 batch norms): one launch per layer
     std::vector<int *> tabs;            // shufflenet gather tables (device)

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     // issue slot from the matrix pipe, profiles/r02_pointwise_phases.log.)
     int abase0[NA];
     unsigned amask[NA];
-    const bool dense1x1 = TAPS == 1 && a.stride == 1 && a.pad == 0 && L.OH == H && OW == W;   // rows of A = rows of the input
+    const bool dense1x1 = TAPS == 1 && L.stride == 1 && L.pad == 0 && L.OH == H && OW == W;   // rows of A = rows of the input
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
         const int m = m0 + (tid >> 3) + RPP * u;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         } else {
             const int b = (int)udiv((unsigned)mm, L.dP), p = mm - b * P;
             const int oy = (int)udiv((unsigned)p, L.dOW), ox = p - oy * OW;
-            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            const int iy0 = oy * L.stride - L.pad, ix0 = ox * L.stride - L.pad;
             abase0[u] = (b * H * W * Cin + (tid & 7) * 4) * 4 + (iy0 * W + ix0) * Cin * 4;
             unsigned vx = 0, mk = 0;                              // bit 3*ky + kx
 #pragma unroll

@@ -43,10 +43,10 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ int lat_swz(int r) { return (int)((0x32765410u >> (4 * ((r >> 1) & 7))) & 7u) ^ ((r & 1) << 2); }
 
-template <int PT, int CT, int TAPS, int D, int WB>
+template <int PT, int CT, int TAPS, int D, int WB, int IL>
 __global__ __launch_bounds__(64 * WB) void igemm_lat_kernel(const IgemmArgs a)
 {
-    static_assert(D == 2 || D == 4 || D == 8, "the loop is unrolled over D register sets and two LDS stages");
+    static_assert(D == 2 || D == 4 || D == 8 || D == 16, "the loop is unrolled over D register sets and two LDS stages");
     static_assert(WB == 1 || WB == 2 || WB == 4, "waves per block");
     // (Beside a launch that saturates the matrix pipe -- fpn p6 beside the grouped p3+p4+p5 launch -- this kernel's dependent
     //  32-cycle MFMAs queue behind the other waves' 64-cycle ones: p6 59 us alone, 172 us there, with or without s_setprio 3,
@@ -69,8 +69,9 @@ __global__ __launch_bounds__(64 * WB) void igemm_lat_kernel(const IgemmArgs a)
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
         swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tile_m = (int)udivl((unsigned)swz, a.dN);
-    const int tile_n = swz - tile_m * a.n_tiles_n;
+    int tile_m, tile_n;
+    if (a.n_major) { tile_n = (int)udivl((unsigned)swz, a.dM); tile_m = swz - tile_n * a.tiles_m; }
+    else { tile_m = (int)udivl((unsigned)swz, a.dN); tile_n = swz - tile_m * a.n_tiles_n; }
     int lvl = 0;
 #pragma unroll
     for (int l = 1; l < SSD_MAX_LEVELS; ++l)
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(64 * WB) void igemm_lat_kernel(const IgemmArgs a)
     unsigned xmask[NX];
     int woff_lo[NX], woff_hi[NX];
     bool xact[NX];                                // (wave-uniform) this wave has a j-th load
-    const bool dense1x1 = TAPS == 1 && a.stride == 1 && a.pad == 0 && L.OH == H && OW == W;
+    const bool dense1x1 = TAPS == 1 && L.stride == 1 && L.pad == 0 && L.OH == H && OW == W;
 #pragma unroll
     for (int u = 0; u < NX; ++u) {
         const int ub = wave + WB * u;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(64 * WB) void igemm_lat_kernel(const IgemmArgs a)
         } else {
             const int b = (int)udivl((unsigned)mm, L.dP), pp = mm - b * P;
             const int oy = (int)udivl((unsigned)pp, L.dOW), ox = pp - oy * OW;
-            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            const int iy0 = oy * L.stride - L.pad, ix0 = ox * L.stride - L.pad;
             xbase[u] = ((b * H * W + iy0 * W + ix0) * Cin + c * 4) * 4;
             unsigned vx = 0, mk = 0;
 #pragma unroll
@@ -225,7 +226,82 @@ __global__ __launch_bounds__(64 * WB) void igemm_lat_kernel(const IgemmArgs a)
             fn(std::integral_constant<int, 4>{}); fn(std::integral_constant<int, 5>{});
             fn(std::integral_constant<int, 6>{}); fn(std::integral_constant<int, 7>{});
         }
+        if constexpr (D > 8) {
+            fn(std::integral_constant<int, 8>{}); fn(std::integral_constant<int, 9>{});
+            fn(std::integral_constant<int, 10>{}); fn(std::integral_constant<int, 11>{});
+            fn(std::integral_constant<int, 12>{}); fn(std::integral_constant<int, 13>{});
+            fn(std::integral_constant<int, 14>{}); fn(std::integral_constant<int, 15>{});
+        }
     };
+    if constexpr (IL) {
+        static_assert(WB == 1 && PT == 1 && CT == 1, "the interleaved K-step is written for the one-accumulator wave");
+        // ---- the ONE-accumulator wave (fpn p6 / p7 / lateral5 at batch 1-2): its 8 MFMAs per K-step are one dependent chain, a
+        // wave issues in order, and while MFMA i + 1 waits for MFMA i nothing behind it in the program can issue -- with the
+        // K-step written as [stage next step | 8 MFMAs | loads] only the LAST MFMA covered any of the ~35 other instructions:
+        // 488 cycles per K-step for 256 of matrix pipe, whatever the prefetch depth or the tile order (p6 59 us alone at every
+        // D and either order, profiles/r04_lat_one_wave.log).  Here every MFMA is followed by its share of the other work
+        // (sched_barrier fences pin the order): the 32 cycles of its execution carry them.
+        // Set k % D holds K-step k; step k multiplies set S, stages the positions of step k + 1 (set N) through LDS stage
+        // (k + 1) & 1, and refills the set step k - 1 freed (T) with step k + D - 1.
+        auto issue_w = [&](auto set_tag) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_tag)::value;
+            const int wso = ltap * w_tapstride + lkc * 2048;
+            wr[S][0][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wbase[0], wso, 0));
+            wr[S][0][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wbase[0] + 1024, wso, 0));
+        };
+        auto issue_x = [&](auto set_tag) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_tag)::value;
+            const int so = lkc * 128;
+#pragma unroll
+            for (int u = 0; u < NX; ++u) xr[S][u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)offc[u], so, 0));
+        };
+        auto advance = [&]() __attribute__((always_inline)) {
+            if (++kload < KS) {
+                if (++lkc == KC) {
+                    lkc = 0;
+                    ++ltap;
+#pragma unroll
+                    for (int u = 0; u < NX; ++u) offc[u] = offn[u];
+                    tap_offsets(ltap + 1, offn);
+                }
+            }
+        };
+#define SSD_SB __builtin_amdgcn_sched_barrier(0)
+        auto kstep_il = [&](auto set_tag) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_tag)::value, N = (S + 1) % D, T = (S + D - 1) % D, STN = (S + 1) & 1;
+            unsigned char *base = lds + STN * (PT * 2048);
+            auto M = [&](int hf, int e) __attribute__((always_inline)) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[S][0][hf][e], xf[S & 1][0][hf][e], acc[0][0], 0, 0, 0);
+            };
+            SSD_SB; M(0, 0); SSD_SB;
+            *(v2f *)(base + woff_lo[0]) = v2f{xr[N][0][0], xr[N][0][2]};
+            *(v2f *)(base + woff_hi[0]) = v2f{xr[N][0][1], xr[N][0][3]};
+            SSD_SB; M(0, 1); SSD_SB;
+            *(v2f *)(base + woff_lo[1]) = v2f{xr[N][1][0], xr[N][1][2]};
+            *(v2f *)(base + woff_hi[1]) = v2f{xr[N][1][1], xr[N][1][3]};
+            SSD_SB; M(0, 2); SSD_SB;
+            xf[STN][0][0] = *(const v4f *)(base + roff[0]);
+            xf[STN][0][1] = *(const v4f *)(base + roff[1]);
+            SSD_SB; M(0, 3); SSD_SB;
+            issue_w(std::integral_constant<int, T>{});
+            SSD_SB; M(1, 0); SSD_SB;
+            issue_x(std::integral_constant<int, T>{});
+            SSD_SB; M(1, 1); SSD_SB;
+            advance();
+            SSD_SB; M(1, 2); SSD_SB; M(1, 3); SSD_SB;
+        };
+#undef SSD_SB
+        static_assert(NX == 2, "one wave, 16 positions: two row loads per K-step");
+        for_sets([&](auto s) __attribute__((always_inline)) {
+            if constexpr (decltype(s)::value < D - 1) { issue_w(s); issue_x(s); advance(); }
+        });
+        lstore(0, std::integral_constant<int, 0>{});
+        lread(std::integral_constant<int, 0>{});
+        int ks = 0;
+        for (; ks + D <= KS; ks += D) for_sets([&](auto s) __attribute__((always_inline)) { kstep_il(s); });
+        const int rem = KS - ks;
+        for_sets([&](auto s) __attribute__((always_inline)) { if (decltype(s)::value < rem) kstep_il(s); });
+    } else {
     for_sets([&](auto s) __attribute__((always_inline)) { gload(s); });
     lstore(0, std::integral_constant<int, 0>{});
     if constexpr (WB > 1) __syncthreads();
@@ -236,11 +312,13 @@ __global__ __launch_bounds__(64 * WB) void igemm_lat_kernel(const IgemmArgs a)
         const int rem = KS - ks;     // 0 .. D-1 steps left: their operands are loaded (set d = step's index in the group)
         for_sets([&](auto s) __attribute__((always_inline)) { if (decltype(s)::value < rem) kstep(s); });
     }
+    }
 
     epilogue_16x16<PT, CT>(a, L, acc, m0, n0, lane);
 }
 
 int igemm_lat_bm(int tile) { return (tile == IGEMM_LAT_2x1 || tile == IGEMM_LAT_2x2 || tile == IGEMM_LAT_W4_2x1) ? 32 : 16; }
+bool igemm_lat_n_major(int tile) { return tile == IGEMM_LAT_1x1_NM || tile == IGEMM_LAT_1x1_D8_NM; }
 int igemm_lat_bn(int tile)
 {
     switch (tile) {
@@ -251,13 +329,13 @@ int igemm_lat_bn(int tile)
     }
 }
 
-template <int PT, int CT, int D, int WB = 1>
+template <int PT, int CT, int D, int WB = 1, int IL = 0>
 static hipError_t launch_l(const IgemmArgs &a, int total_tiles_m, hipStream_t s)
 {
     const long long nblk = (long long)total_tiles_m * a.n_tiles_n;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (a.taps == 9) hipLaunchKernelGGL((igemm_lat_kernel<PT, CT, 9, D, WB>), dim3((unsigned)nblk), dim3(64 * WB), 0, s, a);
-    else hipLaunchKernelGGL((igemm_lat_kernel<PT, CT, 1, D, WB>), dim3((unsigned)nblk), dim3(64 * WB), 0, s, a);
+    if (a.taps == 9) hipLaunchKernelGGL((igemm_lat_kernel<PT, CT, 9, D, WB, IL>), dim3((unsigned)nblk), dim3(64 * WB), 0, s, a);
+    else hipLaunchKernelGGL((igemm_lat_kernel<PT, CT, 1, D, WB, IL>), dim3((unsigned)nblk), dim3(64 * WB), 0, s, a);
     return hipGetLastError();
 }
 
@@ -285,8 +363,12 @@ hipError_t launch_igemm_lat(int tile, const IgemmArgs &a, int total_tiles_m, hip
     if (a.bias && a.res) return hipErrorInvalidValue;
     if (a.out2 && !a.mean) return hipErrorInvalidValue;
     if (a.n_tiles_n * igemm_lat_bn(tile) != a.CoutPad || a.nlevels < 1 || a.nlevels > SSD_MAX_LEVELS) return hipErrorInvalidValue;
+    if (a.n_major && (a.tiles_m != total_tiles_m || total_tiles_m < 1)) return hipErrorInvalidValue;
     switch (tile) {
     case IGEMM_LAT_1x1: return launch_l<1, 1, 4>(a, total_tiles_m, s);
+    case IGEMM_LAT_1x1_IL: case IGEMM_LAT_1x1_NM: return launch_l<1, 1, 4, 1, 1>(a, total_tiles_m, s);
+    case IGEMM_LAT_1x1_D8: case IGEMM_LAT_1x1_D8_NM: return launch_l<1, 1, 8, 1, 1>(a, total_tiles_m, s);
+    case IGEMM_LAT_1x1_D16: return launch_l<1, 1, 16, 1, 1>(a, total_tiles_m, s);
     case IGEMM_LAT_1x2: return launch_l<1, 2, 4>(a, total_tiles_m, s);
     case IGEMM_LAT_2x1: return launch_l<2, 1, 4>(a, total_tiles_m, s);
     case IGEMM_LAT_2x2: return launch_l<2, 2, 2>(a, total_tiles_m, s);

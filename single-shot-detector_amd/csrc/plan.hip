@@ -96,6 +96,8 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
         L.in_off = lv[i].in_off; L.out_off = lv[i].out_off; L.out_bstride = lv[i].out_bstride;
         L.res_off = lv[i].res_off;
         L.wt_off = lv[i].wt_off;
+        L.stride = lv[i].stride > 0 ? lv[i].stride : stride;
+        L.pad = lv[i].pad >= 0 ? lv[i].pad : pad;
         rows += L.M;
         inb += (double)B * L.H * L.W * cw.Cin_l * 4.0;
     }
@@ -117,7 +119,13 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
                 waves += (((long long)a.lv[i].M + 15) / 16) * (cw.CoutPad / 16);
                 b64 += (((long long)a.lv[i].M + 63) / 64) * ((cw.CoutPad + 63) / 64);
             }
-            if ((waves <= 320 || b64 <= 40) && a.wt_lat) tile = IGEMM_LAT_1x1;
+            if ((waves <= 320 || b64 <= 40) && a.wt_lat) {
+                // the one-accumulator wave with its K-step interleaved and 16 K-steps of operands in flight (igemm_lat.hip;
+                // batch-1 forward 1.652 -> 1.637 ms against the plain K-step, profiles/r04_batch1_option_ab.log); option
+                // lat_one = 20 | 28 .. 32 pins another form of the same tile
+                tile = ssd_opt(h, OPT_LAT_ONE, IGEMM_LAT_1x1_D16);
+                if (tile != IGEMM_LAT_1x1 && !(tile >= IGEMM_LAT_1x1_IL && tile <= IGEMM_LAT_1x1_D8_NM)) tile = IGEMM_LAT_1x1_D16;
+            }
             // 1x1 launches of one or two 64x64 tiles per CU (batch 1-2: MobileNet pointwise Conv2d_5 .. 13, laterals 3 and 4): the
             // tiles do not divide over the 256 CUs -- 280 of a 512 -> 512 layer at 40x56: 24 CUs run two, the launch takes two
             // tile times -- and a CU's one block per SIMD covers none of its own waits (0.75 of the matrix pipe in its K loop,
@@ -151,6 +159,9 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
         a.lv[i].tile_begin = tiles;
         tiles += (a.lv[i].M + BM - 1) / BM;
     }
+    a.tiles_m = tiles;
+    a.dM = ssd_udiv_make((unsigned)tiles);
+    a.n_major = lat && igemm_lat_n_major(tile) ? 1 : 0;
     Op op;
     op.cls = cw.taps == 9 ? (tile == IGEMM16_TILE ? 7 : 0) : 1;
     op.flops = 2.0 * rows * cw.taps * cw.Cin_l * cw.Cout_l;
@@ -603,7 +614,14 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     // among 64-cycle ones: 57 us alone, ~170 there -- and the towers wait ~50 us for p7 behind it; the grouped launch waiting
     // for p6 or p7 there (= 1 / 2) moved nothing.  Batch-1 forward 1.661 -> 1.653 ms (profiles/r03_batch1_option_ab.log).
     const int p6opt = ssd_opt(h, OPT_FPN_P6_FIRST, 3);
-    const bool swap67 = grouped && B <= 2 && !ssd_opt(h, OPT_GRAPH, 0) && p6opt == 3;
+    const bool swap67 = grouped && B <= 2 && !ssd_opt(h, OPT_GRAPH, 0) && (p6opt == 3 || p6opt == 4);
+    // = 4: p6 on the caller's stream, p7 (needs p6 only) on the third stream BEHIND the laterals and beside the grouped launch,
+    // which then follows p6 directly: p7's 17 us leave the critical path c5 -> p6 -> grouped -> towers (the towers wait for it)
+    const bool p7side = swap67 && p6opt == 4;
+    // fpn p7 (3x3 stride 2 on ReLU(p6 pre-BN), 35 positions per image: four more 64x64 tiles of the same 72 K-steps) as a fourth
+    // level of the grouped launch behind p6: its launch (17 us alone, a chain of 576 dependent 16x16x4 MFMAs on 48 waves) and
+    // one kernel boundary leave the critical path c5 -> p6 -> p7 -> grouped -> towers.  Same k-ordered chain, same bits.
+    const bool p7grouped = swap67 && !p7side && ssd_opt(h, OPT_FPN_P7_GROUP, 1) != 0;
     const int s_lat = swap67 ? 2 : 0;
     std::vector<int> l5_deps;
     for (int c = 1; c < 4; ++c) if (id_bb_last[c] >= 0) l5_deps.push_back(id_bb_last[c]);
@@ -622,7 +640,8 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         id_p6 = push(make_conv_op(h, h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), swap67 ? 0 : s6, p6_deps);
         LevelDesc d7 = dense_level(py.h[3], py.w[3], py.h[4], py.w[4], 256);
         d7.out_off = py.off[4];
-        id_p7 = push(make_conv_op(h, h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true, X16, X16, 0, FL), swap67 ? 0 : s6);
+        if (!p7side && !p7grouped) id_p7 = push(make_conv_op(h, h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true, X16, X16, 0, FL), swap67 ? 0 : s6);
+        else id_p7 = -1;
     }
     // Batch 1 in exact fp32: p3, p4 and p5 (the same 3x3 256 -> 256 + batch norm + ReLU on x3, x4, x5) as ONE launch behind
     // lateral3, each level with its own kernel (IgemmLevel::wt_off into h->pgroup) and batch norm.  Measured, one stream
@@ -649,6 +668,11 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         id_p4 = push(make_conv_op(h, h->pconv[1], X4, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 1, {id_l4});
     }
     const int id_l3 = push(make_conv_op(h, h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true, LF, X16, X16, FL), s_lat);
+    if (p7side) {
+        LevelDesc d7 = dense_level(py.h[3], py.w[3], py.h[4], py.w[4], 256);
+        d7.out_off = py.off[4];
+        id_p7 = push(make_conv_op(h, h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true, X16, X16, 0, FL), s_lat, {id_p6});
+    }
     if (!grouped) {
         LevelDesc d = lvl(0, 256);
         d.out_off = py.off[0];
@@ -666,11 +690,21 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             d.wt_off = (long long)l * g.taps * g.CoutPad * g.CinP;
             lv3.push_back(d);
         }
+        if (p7grouped) {
+            LevelDesc d = dense_level(py.h[3], py.w[3], py.h[4], py.w[4], 256);
+            d.in_off = T6 - X3;
+            d.out_off = py.off[4];
+            d.param_off = 3 * g.CoutP;
+            d.wt_off = (long long)3 * g.taps * g.CoutPad * g.CinP;
+            d.stride = 2; d.pad = 1;
+            lv3.push_back(d);
+        }
         std::vector<int> gdeps;
         if (swap67) gdeps.push_back(id_l3);
         else if (s6 == 2 && p6opt == 1) gdeps.push_back(id_p6);
         else if (s6 == 2 && p6opt == 2) gdeps.push_back(id_p7);
         id_p3 = id_p4 = push(make_conv_op(h, g, X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv3, true), 0, gdeps);
+        if (p7grouped) id_p7 = id_p3;
         pl.ops[id_p3].fpn_end = true;
     }
     for (int l = 0; l < 5; ++l) {
@@ -707,7 +741,6 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     post_carve(p, ws);
     HIPCHK(hipMemset(p.scan_bits, 0, post_scan_bitmap_bytes(B, (int)N, C)));
     HIPCHK(hipMemset(p.counts, 0, (size_t)B * C * sizeof(int)));      // the post-processing kernels leave these zeroed again
-    HIPCHK(hipMemset(p.big_n, 0, sizeof(int)));
     p.self_clean = 1;
     // (Measured and not adopted, batch 1: the two coarse levels -- 175 of 11 935 positions -- as launches of their own on a
     //  third / fourth stream behind p7, so that the towers of levels 3..5 start when p3..p5 exist: 2.12 -> 2.29 ms per forward;
@@ -847,10 +880,17 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         }
     }
     pl.tail_on[0] = pl.tail_on[1] = split_levels;
+    {   // does a chain start on an internal stream without a dependency (the second backbone chain from 4 images on)?
+        bool seen[4] = {true, false, false, false};
+        for (const Op &op : pl.ops) {
+            if (!seen[op.stream] && op.deps.empty()) pl.need_begin = true;
+            seen[op.stream] = true;
+        }
+    }
     // events for every op another stream waits on
     for (const Op &op : pl.ops)
         for (int d : op.deps)
-            if (!pl.ops[d].done) HIPCHK(hipEventCreateWithFlags(&pl.ops[d].done, hipEventDisableTiming));
+            if (!pl.ops[d].done) HIPCHK(hipEventCreateWithFlags(&pl.ops[d].done, ssd_sync_event_flags(h)));
     pl.retained["encoded_boxes"] = Retained{codes, B, 1, (int)N, 4, 4, false};
     pl.retained["class_predictions"] = Retained{logits, B, 1, (int)N, C, C, false};
 
@@ -987,11 +1027,11 @@ int make_plans(ssd_handle *h, int B, int H, int W)
                 pl->s_bb[1] = ss[3];
             }
         }
-        HIPCHK(hipEventCreateWithFlags(&pl->ev_fpn, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&pl->ev_done, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&pl->ev_begin, hipEventDisableTiming));
-        for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&pl->ev_join_bb[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&pl->ev_fpn, ssd_sync_event_flags(h)));
+        HIPCHK(hipEventCreateWithFlags(&pl->ev_join, ssd_sync_event_flags(h)));
+        HIPCHK(hipEventCreateWithFlags(&pl->ev_done, ssd_sync_event_flags(h)));
+        HIPCHK(hipEventCreateWithFlags(&pl->ev_begin, ssd_sync_event_flags(h)));
+        for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&pl->ev_join_bb[i], ssd_sync_event_flags(h)));
         SSDCHK(build_plan(h, *pl, bk, H, W, img0));
         img0 += bk;
     }
@@ -1012,7 +1052,7 @@ int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, 
         h->ref_evs.push_back(ref);
     }
     const int T = h->cfg.num_classes * h->cfg.max_boxes_per_class;
-    HIPCHK(hipEventRecord(h->ev_start, s));
+    if (h->plans.size() > 1) HIPCHK(hipEventRecord(h->ev_start, s));       // (sub-batch plans start behind the caller's prior work)
     for (size_t k = 0; k < h->plans.size(); ++k) {
         Plan &pl = *h->plans[k];
         hipStream_t sm = pl.s_main ? pl.s_main : s;
@@ -1022,7 +1062,7 @@ int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, 
             HIPCHK(hipStreamWaitEvent(sm, h->ev_start, 0));
             HIPCHK(hipStreamWaitEvent(sm, h->plans[k - 1]->ev_fpn, 0));
         }
-        HIPCHK(hipEventRecord(pl.ev_begin, sm));
+        if (pl.need_begin) HIPCHK(hipEventRecord(pl.ev_begin, sm));
         // option streams = 1: every op on the plan's main stream, in plan order (a valid order: an op's dependencies precede it) --
         // a measurement aid that shows what the kernels cost without each other beside them
         const bool single = ssd_opt(h, OPT_STREAMS, 0) == 1;
@@ -1037,7 +1077,7 @@ int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, 
                 if (!single && pl.ops[d].stream != op.stream) HIPCHK(hipStreamWaitEvent(st, pl.ops[d].done, 0));
             HIPCHK(run_op(h, op, st));
             if (op.done && !single) HIPCHK(hipEventRecord(op.done, st));
-            if (op.fpn_end) HIPCHK(hipEventRecord(pl.ev_fpn, sm));
+            if (op.fpn_end && h->plans.size() > 1) HIPCHK(hipEventRecord(pl.ev_fpn, sm));     // (only a following sub-batch plan waits for it)
             aux_used |= os == 1;
         }
         if (aux_used) {                             // join before the post-processing reads the logits

@@ -260,7 +260,6 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v)
 }
 
 #define NMS_R 8      // candidates per thread kept in registers
-#define NMS_BIG 1024 // threads of the large-list kernel
 #define NMS_MID 256  // threads of the per-pair kernel: lists up to 64 * NMS_R stay in wave 0, up to NMS_MID * NMS_R in the block
 
 // The box of the round's winner without a trip to memory: exactly one (lane, slot) of the wave holds `best` (keys are
@@ -400,10 +399,58 @@ __device__ __forceinline__ int nms_block(const PostArgs &p, const u64 *keys, con
     return kept;
 }
 
+// Greedy NMS of one list of ANY length by a block of NT threads with the keys in global memory: one pass per kept box that
+// kills the winner's victims (zeroing their keys: the list is this forward's scratch) and takes the arg-max of the survivors
+// for the next round on the way.  Exact for every n; the path of the lists neither the register forms nor the top-score
+// trials of post_nms_kernel settle (beyond NMS_MID * NMS_R candidates with massive ties or massive suppression: rare, and
+// then as many rounds as the class has objects).  Thread t revisits only the slots it wrote itself.
+template <int NT>
+__device__ __forceinline__ int nms_global(const PostArgs &p, u64 *keys, const float *dec, int n, int tid, float *ob, float *os,
+                                          u64 (*wbest)[NT / 64])
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    u64 best = 0;
+    for (int i = tid; i < n; i += NT) {
+        const u64 k = keys[i];
+        best = k > best ? k : best;
+    }
+    int kept = 0;
+    while (kept < p.max_per_class) {        // uniform trip count: `best` is block-uniform after the reduction
+        best = wave_max_u64(best);
+        const int buf = kept & 1;
+        if (lane == 0) wbest[buf][wave] = best;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) {
+            const u64 o = wbest[buf][w];
+            best = o > best ? o : best;
+        }
+        if (best == 0) break;
+        const v4f wb = *(const v4f *)(dec + (long long)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFu)) * 4);
+        if (tid == 0) {
+            *(v4f *)(ob + kept * 4) = wb;
+            os[kept] = __uint_as_float((unsigned)(best >> 32));
+        }
+        if (++kept >= p.max_per_class) break;
+        u64 next = 0;
+        for (int i = tid; i < n; i += NT) {
+            const u64 k = keys[i];
+            const unsigned anchor = k ? 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu) : 0u;   // dead: any mapped box
+            const v4f bx = *(const v4f *)(dec + (long long)anchor * 4);
+            const bool kill = (k == best) | iou_greater(bx, wb, p.iou_thr);
+            if (k != 0 && kill) keys[i] = 0;
+            const u64 live = kill ? 0ull : k;
+            next = live > next ? live : next;
+        }
+        best = next;
+    }
+    return kept;
+}
+
 // K9c, one block of NMS_MID threads per (image, class) pair.
 //   n <= fast_max (64 * NMS_R)      wave 0 alone, everything in registers, no barrier (the other waves leave at once)
 //   n <= mid_max (NMS_MID * NMS_R)  the block's four waves (nms_block)
-//   longer                          onto the work list of post_nms_big_kernel
+//   longer                          top-score trials first (below), then nms_global: the keys stay in global memory
 // (Measured and not adopted, round 2: ONE wave with 32 candidates per lane for lists of 513 .. 2 048 -- 0.22 -> 0.28 ms:
 //  32 IoU tests per lane and round.  Four waves keep 8 per lane.)
 __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
@@ -415,14 +462,15 @@ __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int n = p.counts[bc];
     if (n > p.N) n = p.N;
-    if (n > p.mid_max && p.fast_max < 64 * NMS_R) {    // a lowered hand-over point (tests): straight onto the work list of the
-        if (tid == 0) p.big_list[atomicAdd(p.big_n, 1)] = bc;    // 1 024-thread kernels, no trial here
-        return;
-    }
-    const u64 *keys = p.keys + (long long)bc * p.N;
+    u64 *keys = p.keys + (long long)bc * p.N;
     const float *dec = p.dec + (long long)b * p.N * 4;
     float *ob = p.cls_boxes + (long long)bc * p.max_per_class * 4;
     float *os = p.cls_scores + (long long)bc * p.max_per_class;
+    if (n > p.mid_max && p.fast_max < 64 * NMS_R) {    // a lowered hand-over point (tests): straight to the global-memory rounds,
+        const int kept = nms_global<NMS_MID>(p, keys, dec, n, tid, ob, os, wbest);      // no trial
+        if (tid == 0) p.cls_counts[bc] = kept;
+        return;
+    }
     if (n <= p.fast_max) {                  // block-uniform
         if (wave != 0) return;
         int kept = 0;
@@ -506,186 +554,11 @@ __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
             __syncthreads();
         }
     }
-    if (n > p.mid_max) {                    // too long for this block's registers: post_nms_long_kernel
-        if (tid == 0) p.big_list[atomicAdd(p.big_n, 1)] = bc;
-        return;
-    }
-    const int kept = nms_block<NMS_MID>(p, keys, dec, n, tid, ob, os, wbest, wbox);
+    // (the 1 024-thread kernels that took such lists from a work list are gone: most forwards have none, and their launch --
+    //  144 blocks that look at an empty list and leave -- cost its 5 us all the same)
+    const int kept = n > p.mid_max ? nms_global<NMS_MID>(p, keys, dec, n, tid, ob, os, wbest)
+                                   : nms_block<NMS_MID>(p, keys, dec, n, tid, ob, os, wbest, wbox);
     if (tid == 0) p.cls_counts[bc] = kept;
-}
-
-// K9c, lists of NMS_MID * NMS_R < n <= NMS_BIG * NMS_R candidates (the work list post_nms_kernel filled): 1 024 threads, the
-// same in-register rounds (nms_block).  A kernel of its own: beside the global-memory path of post_nms_big_kernel the
-// 128-register budget of a 1 024-thread block spilled into the rounds (that kernel took 96 us for ONE list of 4 085
-// candidates at batch 1: 3.8 us per round).
-static __device__ __forceinline__ void nms_long_regs(const PostArgs &p, const int bid, const int nblocks)
-{
-    __shared__ u64 rbest[2][NMS_BIG / 64];
-    __shared__ v4f rbox[2][NMS_BIG / 64];
-    const int tid = threadIdx.x;
-    const int nbig = *p.big_n;
-    for (int item = bid; item < nbig; item += nblocks) {
-        const int bc = p.big_list[item];
-        const int b = bc / p.C;
-        int n = p.counts[bc];
-        if (n > p.N) n = p.N;
-        if (n > NMS_BIG * NMS_R) continue;   // nms_long_global's (block-uniform)
-        const int kept = nms_block<NMS_BIG>(p, p.keys + (long long)bc * p.N, p.dec + (long long)b * p.N * 4, n, tid,
-                                            p.cls_boxes + (long long)bc * p.max_per_class * 4, p.cls_scores + (long long)bc * p.max_per_class,
-                                            rbest, rbox);
-        if (tid == 0) p.cls_counts[bc] = kept;
-        __syncthreads();                     // the shared arrays are reused by the next pair
-    }
-}
-
-// K9c, still longer lists (beyond the register capacity of 1 024 threads): 1024 threads per (image, class).  Up to 1024*NMS_R candidates live in
-// registers (same scheme, block-wide arg-max through LDS); beyond that the keys stay in
-// global memory and dead candidates are zeroed there.
-// The blocks take their (image, class) pairs from the work list the small kernel filled: most lists are short
-// and never come here, and a block of 1024 threads with 80 KB of LDS that only looks at its count and leaves
-// still costs its launch -- one block per pair made this kernel 0.31 ms of a 32-image step for 64 long lists.
-static __device__ __forceinline__ void nms_long_global(const PostArgs &p, const int bid, const int nblocks)
-{
-    __shared__ u64 wbest[2][NMS_BIG / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nbig = *p.big_n;
-    for (int item = bid; item < nbig; item += nblocks) {
-    const int bc = p.big_list[item];
-    const int b = bc / p.C;
-    int n = p.counts[bc];
-    if (n > p.N) n = p.N;
-    u64 *keys = p.keys + (long long)bc * p.N;
-    const float *dec = p.dec + (long long)b * p.N * 4;
-    float *ob = p.cls_boxes + (long long)bc * p.max_per_class * 4;
-    float *os = p.cls_scores + (long long)bc * p.max_per_class;
-    if (n <= NMS_BIG * NMS_R) continue;      // nms_long_regs's (block-uniform)
-    // Lists longer than the register capacity: greedy NMS only consumes candidates in
-    // descending score order until max_per_class boxes are kept, so first try the top
-    // scores alone -- a score histogram picks the largest score cut that leaves at most
-    // CAP candidates, those are compacted into LDS and processed in registers.  If that
-    // keeps max_per_class boxes the result is exact; otherwise (rare: massive ties or
-    // massive suppression) everything is redone by the global-memory path below.
-    constexpr int CAP = NMS_BIG * NMS_R;
-    constexpr int NBIN = 4096;
-    __shared__ unsigned hist[NBIN];
-    __shared__ u64 chunk[CAP];
-    __shared__ int chunk_n, cut_bin;
-    const unsigned lo_bits = __float_as_uint(p.score_thr > 0.0f ? p.score_thr : 0.0f);
-    int shift = 0;
-    while (((0x3F800000u - lo_bits) >> shift) >= (unsigned)NBIN) ++shift;
-    bool in_regs = n <= CAP, trial = false;
-    int nn = n;                              // candidates resident in registers
-    if (!in_regs) {
-        for (int i = tid; i < NBIN; i += NMS_BIG) hist[i] = 0;
-        if (tid == 0) chunk_n = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += NMS_BIG) {
-            const unsigned sb = (unsigned)(keys[i] >> 32);
-            atomicAdd(&hist[(sb - lo_bits) >> shift], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned cum = 0;
-            int bin = NBIN;                  // keep bins >= cut_bin
-            while (bin > 0 && cum + hist[bin - 1] <= (unsigned)CAP) { cum += hist[bin - 1]; --bin; }
-            cut_bin = bin;
-        }
-        __syncthreads();
-        const int cb = cut_bin;
-        for (int i = tid; i < n; i += NMS_BIG) {
-            const u64 k = keys[i];
-            if ((int)(((unsigned)(k >> 32) - lo_bits) >> shift) >= cb) chunk[atomicAdd(&chunk_n, 1)] = k;
-        }
-        __syncthreads();
-        nn = chunk_n;
-        trial = nn >= p.max_per_class;       // fewer than the cap can never fill it: skip the trial
-        in_regs = trial;
-    }
-    int kept = 0;
-    u64 key[NMS_R];
-    v4f box[NMS_R];
-    unsigned alive = 0;
-restart:
-    if (in_regs) {
-#pragma unroll
-        for (int r = 0; r < NMS_R; ++r) {
-            const int i = tid + NMS_BIG * r;
-            const bool ok = i < nn;
-            key[r] = ok ? (trial ? chunk[ok ? i : 0] : keys[ok ? i : 0]) : 0ull;
-            const unsigned anchor = 0xFFFFFFFFu - (unsigned)(key[r] & 0xFFFFFFFFu);
-            box[r] = *(const v4f *)(dec + (long long)(ok ? anchor : 0u) * 4);
-            alive |= ok ? (1u << r) : 0u;
-        }
-    }
-    while (kept < p.max_per_class) {        // uniform trip count: `best` is block-uniform
-        u64 best = 0;
-        if (in_regs) {
-#pragma unroll
-            for (int r = 0; r < NMS_R; ++r) {
-                const u64 k = ((alive >> r) & 1u) ? key[r] : 0ull;
-                best = k > best ? k : best;
-            }
-        } else {
-            for (int i = tid; i < n; i += NMS_BIG) {
-                const u64 k = keys[i];
-                best = k > best ? k : best;
-            }
-        }
-        best = wave_max_u64(best);
-        const int buf = kept & 1;
-        if (lane == 0) wbest[buf][wave] = best;
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < NMS_BIG / 64; ++w) {
-            const u64 o = wbest[buf][w];
-            best = o > best ? o : best;
-        }
-        if (best == 0) break;
-        const v4f wb = *(const v4f *)(dec + (long long)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFu)) * 4);
-        if (tid == 0) {
-            *(v4f *)(ob + kept * 4) = wb;
-            os[kept] = __uint_as_float((unsigned)(best >> 32));
-        }
-        ++kept;
-        if (in_regs) {
-            unsigned kill = 0;
-#pragma unroll
-            for (int r = 0; r < NMS_R; ++r) {
-                const bool k = (key[r] == best) | iou_greater(box[r], wb, p.iou_thr);
-                kill |= k ? (1u << r) : 0u;
-            }
-            alive &= ~kill;
-        } else {
-            for (int i = tid; i < n; i += NMS_BIG) {
-                const u64 k = keys[i];
-                const unsigned anchor = k ? 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu) : 0u;   // dead: any mapped box
-                const v4f bx = *(const v4f *)(dec + (long long)anchor * 4);
-                const bool kill = (k == best) | iou_greater(bx, wb, p.iou_thr);
-                if (k != 0 && kill) keys[i] = 0;
-            }
-        }
-    }
-    if (trial && kept < p.max_per_class) {   // block-uniform: the cut did not suffice -> exact redo
-        __syncthreads();
-        trial = false;
-        in_regs = false;
-        kept = 0;
-        alive = 0;
-        goto restart;
-    }
-    if (tid == 0) p.cls_counts[bc] = kept;
-    __syncthreads();                         // the shared arrays are reused by the next pair
-    }
-}
-
-// K9c, both forms of the long lists in ONE launch (most forwards have no such list, and an empty launch of 1 024-thread
-// blocks costs its 5 us all the same): blocks [0, nregs) take the work list's pairs of at most NMS_BIG * NMS_R candidates,
-// the others the longer ones.  Two code paths without a common live register: the kernel needs the larger budget of the
-// two, not their sum (one loop over both forms spilled 67 registers into the rounds).
-__global__ __launch_bounds__(NMS_BIG) void post_nms_long_kernel(const PostArgs p, const int nregs)
-{
-    if ((int)blockIdx.x < nregs) nms_long_regs(p, (int)blockIdx.x, nregs);
-    else nms_long_global(p, (int)blockIdx.x - nregs, (int)gridDim.x - nregs);
 }
 
 __global__ __launch_bounds__(256) void post_pack_kernel(const PostArgs p)
@@ -752,7 +625,6 @@ __global__ __launch_bounds__(256) void post_pack_kernel(const PostArgs p)
         // the last kernel of the post-processing leaves the counters as the next forward's scan expects them (the plan
         // zeroed them once when it was built): no memset launches in front of the scan
         for (int c = threadIdx.x; c < C; c += blockDim.x) p.counts[b * C + c] = 0;
-        if (b == 0 && threadIdx.x == 0) *p.big_n = 0;
     }
 }
 
@@ -768,7 +640,6 @@ size_t post_workspace_bytes(int B, int N, int C, int mp)
     s += align_up((size_t)B * C * mp * 4 * sizeof(float));
     s += align_up((size_t)B * C * mp * sizeof(float));
     s += align_up((size_t)B * C * sizeof(int));
-    s += align_up(((size_t)B * C + 1) * sizeof(int));      // work list of the long-list NMS kernel, its length first
     s += align_up(post_scan_bitmap_bytes(B, N, C));        // candidate-octet bitmap of the fused scan
     return s;
 }
@@ -783,8 +654,6 @@ void post_carve(PostArgs &p, void *ws)
     p.cls_boxes = (float *)q;   q += align_up(B * C * mp * 4 * sizeof(float));
     p.cls_scores = (float *)q;  q += align_up(B * C * mp * sizeof(float));
     p.cls_counts = (int *)q;    q += align_up(B * C * sizeof(int));
-    p.big_n = (int *)q;
-    p.big_list = (int *)q + 1;  q += align_up((B * C + 1) * sizeof(int));
     p.scan_bits = (unsigned *)q;
 }
 
@@ -792,7 +661,7 @@ hipError_t launch_postprocess(const PostArgs &pin, hipStream_t s)
 {
     PostArgs p = pin;
     // lists up to fast_max candidates stay in one wave's registers, up to mid_max in one 256-thread block; the caller may
-    // lower the hand-over point (tests route every list through the 1024-thread kernel): then longer lists go straight to
+    // lower the hand-over point (tests route every list through the global-memory rounds): then longer lists go straight to
     // that kernel as before.  0 / out of range = the defaults
     if (p.fast_max < 1 || p.fast_max > 64 * NMS_R) {
         p.fast_max = pin.fast_max == -1 ? 0 : 64 * NMS_R;
@@ -806,8 +675,6 @@ hipError_t launch_postprocess(const PostArgs &pin, hipStream_t s)
     if (!p.self_clean) {         // a caller's workspace (ssd_postprocess): nothing is known about its contents
         e = hipMemsetAsync(p.counts, 0, (size_t)p.B * p.C * sizeof(int), s);
         if (e != hipSuccess) return e;
-        e = hipMemsetAsync(p.big_n, 0, sizeof(int), s);
-        if (e != hipSuccess) return e;
     }
     const long long units = (long long)p.B * p.N * ((p.C & 3) ? p.C : p.C / 4);
     long long blocks = (units + 256 * SCAN_U - 1) / (256 * SCAN_U);
@@ -819,9 +686,6 @@ hipError_t launch_postprocess(const PostArgs &pin, hipStream_t s)
     }
     hipLaunchKernelGGL(post_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
     hipLaunchKernelGGL(post_nms_kernel, dim3((unsigned)(p.B * p.C)), dim3(NMS_MID), 0, s, p);
-    const int big_blocks = p.B * p.C < 512 ? p.B * p.C : 512;     // two resident blocks per CU
-    const int long_blocks = big_blocks < 64 ? big_blocks : 64;
-    hipLaunchKernelGGL(post_nms_long_kernel, dim3((unsigned)(big_blocks + long_blocks)), dim3(NMS_BIG), 0, s, p, big_blocks);
     hipLaunchKernelGGL(post_pack_kernel, dim3((unsigned)p.B), dim3(256), (p.C + 1) * sizeof(int), s, p);
     return hipGetLastError();
 }

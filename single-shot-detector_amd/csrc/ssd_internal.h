@@ -62,6 +62,8 @@ struct IgemmLevel {
     long long wt_off;      // float offset of THIS level's kernel inside `wt` (0: one kernel shared by all levels, the head towers;
                            // grouped launches -- fpn p3 + p4 + p5 at batch 1 -- give every level its own [taps][CoutPad][Cin])
     UDiv dP, dOW;          // division by OH*OW and by OW
+    int stride, pad;       // this level's convolution geometry (grouped launches mix them: fpn p7 -- stride 2, explicit pad -- rides
+                           // in the p3 + p4 + p5 launch); the launch-wide IgemmArgs::stride / pad where the plan gives none
 };
 
 struct IgemmArgs {
@@ -80,6 +82,9 @@ struct IgemmArgs {
     int nlevels;
     int n_tiles_n;
     UDiv dN;               // division by n_tiles_n
+    int n_major;           // igemm_lat.hip: 1 = tile index = tile_n * tiles_m + tile_m (the position tiles of one channel tile are
+    int tiles_m;           //   neighbours: an XCD streams few channel tiles' weights), else tile_m * n_tiles_n + tile_n
+    UDiv dM;               // division by tiles_m
     int dense_out;         // 1: out_bstride == OH*OW*out_rstride for every level
     // precision mode f16x3 (igemm.hip, "S16"): formats of the activations this launch touches
     int in_fmt;            // 1: `in` rows and `wt` rows are split-fp16 (h|l per octet), MFMA f16 x3;
@@ -106,10 +111,15 @@ hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStre
 // PT x 16 positions by CT x 16 channels; tile_begin of the levels counts PT*16-row tiles, n_tiles_n = CoutPad / (CT*16)
 // ..._Wn_: n waves per block share the positions through the block's LDS image; block tile PT x 16 positions by n x CT x 16 channels
 enum IgemmLatTile { IGEMM_LAT_1x1 = 20, IGEMM_LAT_1x2 = 21, IGEMM_LAT_2x1 = 22, IGEMM_LAT_2x2 = 23,
-                    IGEMM_LAT_W2_1x1 = 24, IGEMM_LAT_W4_1x1 = 25, IGEMM_LAT_W4_2x1 = 26, IGEMM_LAT_W4_1x2 = 27 };
-static inline bool igemm_is_lat(int tile) { return tile >= IGEMM_LAT_1x1 && tile <= IGEMM_LAT_W4_1x2; }
+                    IGEMM_LAT_W2_1x1 = 24, IGEMM_LAT_W4_1x1 = 25, IGEMM_LAT_W4_2x1 = 26, IGEMM_LAT_W4_1x2 = 27,
+                    // the one-wave 16x16 tile with its K-step interleaved (every MFMA of the one dependent chain followed by its
+                    // share of the staging work), 4 / 8 / 16 K-steps of operands in flight, and the tile order that keeps the
+                    // position tiles of ONE channel tile on one XCD (its weights then pass through that L2 once)
+                    IGEMM_LAT_1x1_IL = 28, IGEMM_LAT_1x1_D8 = 29, IGEMM_LAT_1x1_D16 = 30, IGEMM_LAT_1x1_NM = 31, IGEMM_LAT_1x1_D8_NM = 32 };
+static inline bool igemm_is_lat(int tile) { return tile >= IGEMM_LAT_1x1 && tile <= IGEMM_LAT_1x1_D8_NM; }
 int igemm_lat_bm(int tile);
 int igemm_lat_bn(int tile);
+bool igemm_lat_n_major(int tile);
 bool igemm_lat_supports(const IgemmArgs &a);
 hipError_t launch_igemm_lat(int tile, const IgemmArgs &a, int total_tiles_m, hipStream_t s);
 // igemm16.hip: 256 x 256 tiles, one block per CU, S16 in / S16 out with batch norm (towers, FPN outputs);
@@ -168,7 +178,7 @@ struct PostArgs {
     int max_per_class;
     int fast_max;          // candidate lists up to this length are processed in one wave's registers
     int mid_max;           // ... up to this length in one 256-thread block (set by launch_postprocess)
-    int self_clean;        // 1: the workspace belongs to a layer plan that zeroed counts / big_n / scan_bits once; the kernels leave
+    int self_clean;        // 1: the workspace belongs to a layer plan that zeroed counts / scan_bits once; the kernels leave
                            // them zeroed for the next forward (no memset launches).  0: a caller's workspace, cleared per call
     float box_scaler[4];
     float *boxes; int32_t *labels; float *scores; int32_t *num;
@@ -179,7 +189,6 @@ struct PostArgs {
     float *cls_boxes;           // [B][C][max][4]
     float *cls_scores;          // [B][C][max]
     int *cls_counts;            // [B][C]
-    int *big_n, *big_list;      // work list of (image, class) pairs whose candidate list is longer than fast_max
     // scan_fused: the logits convolution's epilogue (igemm16.hip) has marked in scan_bits (one bit per 8 consecutive
     // elements of [B][N][C]) every octet that holds a logit >= logit_lo; post_scan_kernel then reads the bitmap and
     // the marked octets instead of all logits.  The bitmap is cleared again at the end of the post-processing.

@@ -345,27 +345,31 @@ static int finalize_fpn_heads(ssd_handle *h)
         snprintf(b, sizeof b, "fpn/p%d_batch_norm", i + 3);
         SSDCHK(load_conv(h, n, b, 3, i == 3 ? h->c_ch[2] : 256, 256, h->pconv[i]));
     }
-    {   // p3 | p4 | p5 again behind one pointer each (same shapes: 3x3, 256 -> 256, batch norm + ReLU): at batch 1 the three
-        // convolutions run as ONE launch whose levels carry their own kernel offset (plan.hip, IgemmLevel::wt_off)
+    {   // p3 | p4 | p5 | p7 again behind one pointer each (same shapes: 3x3, 256 -> 256, batch norm + ReLU): at batch 1 the
+        // convolutions run as ONE launch whose levels carry their own kernel offset (plan.hip, IgemmLevel::wt_off) and
+        // geometry (p7: stride 2, explicit pad)
+        const int src_of[4] = {0, 1, 2, 4};
         ConvW &g = h->pgroup;
         g = h->pconv[0];
         g.wt16 = g.wt16w = nullptr;            // (exact fp32 only: the split-fp16 packs carry a per-convolution scale)
-        const bool have_lat = h->pconv[0].wlat && h->pconv[1].wlat && h->pconv[2].wlat;
+        const bool have_lat = h->pconv[0].wlat && h->pconv[1].wlat && h->pconv[2].wlat && h->pconv[4].wlat;
         g.wlat = nullptr;
         const size_t wn = (size_t)g.taps * g.CoutPad * g.CinP, pn = (size_t)g.CoutP;
-        if (h->pconv[1].CoutPad != g.CoutPad || h->pconv[2].CoutPad != g.CoutPad || h->pconv[1].CinP != g.CinP || h->pconv[2].CinP != g.CinP)
-            return ssd_fail(SSD_ERR_WEIGHT, "fpn p3 / p4 / p5 kernels differ in shape");
-        SSDCHK(h->wpool.alloc((void **)&g.wt, 3 * wn * sizeof(float)));
-        SSDCHK(h->wpool.alloc((void **)&g.mean, 3 * pn * sizeof(float)));
-        SSDCHK(h->wpool.alloc((void **)&g.sf, 3 * pn * sizeof(float)));
-        SSDCHK(h->wpool.alloc((void **)&g.beta, 3 * pn * sizeof(float)));
-        if (have_lat) SSDCHK(h->wpool.alloc((void **)&g.wlat, 3 * wn * sizeof(float)));
-        for (int i = 0; i < 3; ++i) {
-            if (have_lat) HIPCHK(hipMemcpy(g.wlat + i * wn, h->pconv[i].wlat, wn * sizeof(float), hipMemcpyDeviceToDevice));
-            HIPCHK(hipMemcpy(g.wt + i * wn, h->pconv[i].wt, wn * sizeof(float), hipMemcpyDeviceToDevice));
-            HIPCHK(hipMemcpy(g.mean + i * pn, h->pconv[i].mean, pn * sizeof(float), hipMemcpyDeviceToDevice));
-            HIPCHK(hipMemcpy(g.sf + i * pn, h->pconv[i].sf, pn * sizeof(float), hipMemcpyDeviceToDevice));
-            HIPCHK(hipMemcpy(g.beta + i * pn, h->pconv[i].beta, pn * sizeof(float), hipMemcpyDeviceToDevice));
+        for (int i = 1; i < 4; ++i)
+            if (h->pconv[src_of[i]].CoutPad != g.CoutPad || h->pconv[src_of[i]].CinP != g.CinP || h->pconv[src_of[i]].CoutP != g.CoutP)
+                return ssd_fail(SSD_ERR_WEIGHT, "fpn p3 / p4 / p5 / p7 kernels differ in shape");
+        SSDCHK(h->wpool.alloc((void **)&g.wt, 4 * wn * sizeof(float)));
+        SSDCHK(h->wpool.alloc((void **)&g.mean, 4 * pn * sizeof(float)));
+        SSDCHK(h->wpool.alloc((void **)&g.sf, 4 * pn * sizeof(float)));
+        SSDCHK(h->wpool.alloc((void **)&g.beta, 4 * pn * sizeof(float)));
+        if (have_lat) SSDCHK(h->wpool.alloc((void **)&g.wlat, 4 * wn * sizeof(float)));
+        for (int i = 0; i < 4; ++i) {
+            const ConvW &src = h->pconv[src_of[i]];
+            if (have_lat) HIPCHK(hipMemcpy(g.wlat + i * wn, src.wlat, wn * sizeof(float), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(g.wt + i * wn, src.wt, wn * sizeof(float), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(g.mean + i * pn, src.mean, pn * sizeof(float), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(g.sf + i * pn, src.sf, pn * sizeof(float), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(g.beta + i * pn, src.beta, pn * sizeof(float), hipMemcpyDeviceToDevice));
         }
     }
     // box_predictor.py:107-155: conv weights shared across levels, batch norm per level
