@@ -52,6 +52,8 @@ enum SsdOpt {
     OPT_SIDE_PRIORITY,      // 0 (default) | 1: the plan's third / fourth stream at the lowest dispatch priority
     OPT_TOWER_GROUP,        // 0 (default) | 1: layer i of the box and the class tower as ONE launch over 2 x 5 levels (exact fp32)
     OPT_FPN_P6_FIRST,       // 3 (default): fpn p6 -> p7 on the main stream, the laterals beside them | 0: p6 -> p7 on the third stream | 1 / 2: ... and the grouped launch waits for p6 / p7
+    OPT_DWPW_LAT,           // 0 (default) | 1 | 2 | 4: depthwise + pointwise pairs the streaming kernel leaves apart as ONE launch of
+                            // dwpw_lat.hip (measured slower than the pair, plan.hip); 1 = channel tiles per wave chosen per layer, 2 / 4 pin them
     OPT_FPN_P7_GROUP,       // 1 (default) | 0: fpn p7 as a fourth level of the grouped p3 + p4 + p5 launch (batch <= 2, exact fp32)
     OPT_EVENT_FENCE,        // 0 (default): the library's ordering events carry no system-scope fence (hipEventDisableSystemFence: they order
                             // streams of ONE device) | 1: default event flags (a cache writeback per record: ~8-12 us per cross-stream edge)
@@ -171,6 +173,8 @@ Op make_dw_op(const DwW &d, const float *in, int B, int H, int W, int stride, in
 bool dwpws_eligible(const DwW &d, const ConvW &cw, int B, int H, int W, int stride);
 Op make_dwpws_op(const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact, int act,
                  float *out, const int *omap = nullptr, long long out_bytes = 0, int rs0 = 0, int rs1 = 0);
+int dwpw_lat_ct(const struct ssd_handle *h, const DwW &d, const ConvW &cw, int B, int H, int W, int stride);   // 0: not this kernel's
+Op make_dwpw_lat_op(int ct, const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact, int act, float *out);
 LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long in_off = 0, long long out_off = 0,
                       int param_off = 0, long long res_off = 0);
 float conservative_logit_bound(float thr);

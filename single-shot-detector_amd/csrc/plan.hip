@@ -270,6 +270,73 @@ Op make_dwpws_op(const DwW &d, const ConvW &cw, const float *in, int B, int H, i
     return op;
 }
 
+// depthwise + pointwise on the latency-form kernel (dwpw_lat.hip): the pairs of a batch-1 / batch-2 forward that the streaming
+// kernel leaves apart (MobileNet Conv2d_5 .. 13).  Returns the channel tiles per wave (0: not this kernel's launch).
+//   ct   block = 16 positions x 64 ct channels; the block recomputes its positions' depthwise values once per channel tile of
+//        the layer, so wide blocks for wide layers -- as long as the launch keeps >= ~2 waves per SIMD
+static DwPwLArgs dwpw_lat_args(int ct, const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact, int act, float *out)
+{
+    DwPwLArgs q;
+    memset(&q, 0, sizeof(q));
+    IgemmArgs &a = q.g;
+    const int OH = H / stride, OW = W / stride;
+    a.in = in; a.wt = cw.wt; a.wt_lat = cw.wlat; a.out = out;
+    a.mean = cw.mean; a.sf = cw.sf; a.beta = cw.beta;
+    a.B = B; a.Cin = cw.CinP; a.Cout = cw.CoutP; a.CoutPad = cw.CoutPad; a.taps = 1; a.stride = 1; a.pad = 0; a.act = act;
+    a.nlevels = 1;
+    a.n_tiles_n = cw.CoutPad / (64 * (ct > 0 ? ct : 1));
+    a.dN = ssd_udiv_make((unsigned)a.n_tiles_n);
+    a.dense_out = 1;
+    a.acc_scale = 1.0f;
+    IgemmLevel &L = a.lv[0];
+    L.H = OH; L.W = OW; L.OH = OH; L.OW = OW; L.M = B * OH * OW;
+    L.out_rstride = cw.CoutP; L.out_bstride = (long long)OH * OW * cw.CoutP;
+    L.dP = ssd_udiv_make((unsigned)(OH * OW)); L.dOW = ssd_udiv_make((unsigned)OW);
+    L.stride = 1; L.pad = 0;
+    q.dw_w = d.w; q.dw_mean = d.mean; q.dw_sf = d.sf; q.dw_beta = d.beta;
+    q.H = H; q.W = W; q.dstride = stride; q.dpad = stride == 1 ? 1 : 0; q.dact = dact;
+    return q;
+}
+
+int dwpw_lat_ct(const ssd_handle *h, const DwW &d, const ConvW &cw, int B, int H, int W, int stride)
+{
+    // Measured (profiles/r04_batch1_option_ab.log, r04_batch1_timeline_dwpw_lat.txt): bit-identical and SLOWER than the pair
+    // it replaces -- a 512 -> 512 layer at 40x56 takes 35 us as one launch against 7.5 + 19 as two (batch-1 forward 1.589 ->
+    // 1.664 ms).  Every thread issues 21 sixteen-byte loads per 64-channel slice (9 taps, 9 depthwise weights, 3 batch-norm
+    // vectors: 84 wave instructions per block and slice on the CU's one texture-address path, against 1 024 cycles of MFMA per
+    // wave), they are consumed one slice later, and at 204 VGPRs two blocks per CU leave 48 of 560 blocks for a second round.
+    // What the design would need is dwpw_stream.hip's: 2-D position tiles with the input patch and the depthwise weights
+    // staged once per block in LDS (LDS-DMA), i.e. a 9x smaller load count.  OFF unless asked for (option dwpw_lat >= 1).
+    const int opt = ssd_opt(h, OPT_DWPW_LAT, 0);
+    if (opt <= 0 || cw.taps != 1 || d.Cp != cw.CinP || !cw.mean || cw.bias || !cw.wlat || !d.w || !d.mean) return 0;
+    if ((stride != 1 && stride != 2) || (stride == 2 && ((H | W) & 1))) return 0;
+    const long long M = (long long)B * (H / stride) * (W / stride);
+    int ct = 0;
+    if (opt == 2 || opt == 4) ct = opt;
+    else {
+        // auto: the launches of one or two 64x64 tiles per CU that make_conv_op gives the four-wave latency form (batch 1-2)
+        const long long b64 = ((M + 63) / 64) * ((cw.CoutPad + 63) / 64);
+        ct = cw.CoutPad % 128 == 0 ? 2 : 1;
+        const long long waves2 = ((M + 15) / 16) * (cw.CoutPad / 32);
+        if (ct == 2 && waves2 < 2048) ct = cw.CoutPad % 128 == 0 && waves2 >= 1024 ? 2 : 1;
+    }
+    while (ct > 1 && cw.CoutPad % (64 * ct)) ct >>= 1;
+    const DwPwLArgs q = dwpw_lat_args(ct, d, cw, nullptr, B, H, W, stride, 0, 0, nullptr);
+    return dwpw_lat_supports(q, ct) ? ct : 0;
+}
+
+Op make_dwpw_lat_op(int ct, const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact, int act, float *out)
+{
+    const DwPwLArgs q = dwpw_lat_args(ct, d, cw, in, B, H, W, stride, dact, act, out);
+    Op op;
+    op.cls = 6;
+    const double M = (double)B * (H / stride) * (W / stride);
+    op.flops = (2.0 * 9 * cw.Cin_l + 2.0 * cw.Cin_l * cw.Cout_l) * M;
+    op.bytes = ((double)B * H * W * cw.Cin_l + M * cw.Cout_l) * 4.0 + (double)cw.Cin_l * cw.Cout_l * 4.0;
+    op.run = [q, ct](hipStream_t s) { return launch_dwpw_lat(ct, q, s); };
+    return op;
+}
+
 LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long in_off, long long out_off, int param_off, long long res_off)
 {
     LevelDesc d;
@@ -385,7 +452,9 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 // f16x3: an unfused pair hands the depthwise result (exact fp32, in [0, 6]) to its pointwise
                 // convolution in split-fp16 rows, and the pointwise product runs as 3 x f16 MFMA
                 const int pw16 = X16 && !fuse && (h->dw[i].Cp % 32 == 0) ? 1 : 0;
-                if (!fuse) ops.push_back(make_dw_op(h->dw[i], cur, nb, ch, cwid, s, SSD_ACT_RELU6, dwo, h->pw[i].Cin_l, pw16, FL));
+                // batch 1-2, exact fp32: the pair as ONE launch of the latency form (dwpw_lat.hip)
+                const int lct = (!fuse && !X16) ? dwpw_lat_ct(h, h->dw[i], cw, nb, ch, cwid, s) : 0;
+                if (!fuse && !lct) ops.push_back(make_dw_op(h->dw[i], cur, nb, ch, cwid, s, SSD_ACT_RELU6, dwo, h->pw[i].Cin_l, pw16, FL));
                 const int dh = ch, dwid = cwid;
                 ch /= s; cwid /= s;
                 float *pwo;
@@ -393,10 +462,12 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                     float *full = i == 4 ? C3 : (i == 10 ? C4 : C5);
                     pwo = full + (long long)b0 * ch * cwid * cw.CoutP;
                 } else {
-                    pwo = fuse ? dwo : ((dwo == X) ? Y : X);    // fused: input `cur` is live until the launch ends
+                    pwo = (fuse || lct) ? dwo : ((dwo == X) ? Y : X);    // fused: input `cur` is live until the launch ends
                 }
                 if (fuse)
                     ops.push_back(make_dwpws_op(h->dw[i], cw, cur, nb, dh, dwid, s, SSD_ACT_RELU6, SSD_ACT_RELU6, pwo));
+                else if (lct)
+                    ops.push_back(make_dwpw_lat_op(lct, h->dw[i], cw, cur, nb, dh, dwid, s, SSD_ACT_RELU6, SSD_ACT_RELU6, pwo));
                 else   // c5 feeds only the FPN (lateral5, p6): in f16x3 mode it is written in split-fp16 rows
                     ops.push_back(make_conv_op(h, cw, dwo, pwo, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU6,
                                                {dense_level(ch, cwid, ch, cwid, cw.CoutP)}, true, pw16, (i == 12 && X16) ? 1 : 0, 0, h->flags_dev));

@@ -150,6 +150,19 @@ int dwpws_tile_m(int stride);
 int dwpws_tile_n(int stride, int CoutP);
 hipError_t launch_dwpw_stream(int stride, const DwPwSArgs &a, hipStream_t s);
 
+// depthwise -> pointwise in the latency form (dwpw_lat.hip, batch 1-2): the four-wave block of igemm_lat.hip whose position
+// operand is produced by the depthwise arithmetic instead of loaded --------------------------------------------------
+struct DwPwLArgs {
+    IgemmArgs g;                           // the pointwise product: in = the DEPTHWISE input [B,H,W,K], wt_lat, batch norm, act, one
+                                           // dense level (M = B*OH*OW rows of the depthwise output), Cin = K, n_tiles_n = CoutPad / (64 ct)
+    const float *dw_w;                     // [9][K] depthwise weights, physical channel order
+    const float *dw_mean, *dw_sf, *dw_beta;// [K] depthwise batch norm
+    int H, W;                              // depthwise input size
+    int dstride, dpad, dact;               // depthwise stride (1 | 2), pad_beg (TF 'SAME': 1 | 0), activation
+};
+bool dwpw_lat_supports(const DwPwLArgs &q, int ct);
+hipError_t launch_dwpw_lat(int ct /* 16-channel tiles per wave: 1 | 2 | 4 */, const DwPwLArgs &q, hipStream_t s);
+
 // elementwise / memory-bound kernels -----------------------------------------------------
 // source image [B,srcH,srcW,3] is NN-resized to [nh,nw], zero padded to [H,W] (even), normalised and convolved
 hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int nh, int nw, int H, int W,
