@@ -124,7 +124,7 @@ def latency_segments(detector):
     for _ in range(50):
         t0 = time.perf_counter(); np.copyto(slot["pin_in_np"], img[None]); t1 = time.perf_counter()
         slot["dev_in"].copy_(slot["pin_in"], non_blocking=True); torch.cuda.synchronize(); t2 = time.perf_counter()
-        e.forward(slot["dev_in"], out=slot["pin_views"]); torch.cuda.synchronize(); t3 = time.perf_counter()
+        e.forward(slot["dev_in"], records=slot["pin_out"]); torch.cuda.synchronize(); t3 = time.perf_counter()
         b, l, s, n = slot["host"]; k = s[0][:n[0]] > 0.5; _ = b[0][:n[0]][k], l[0][:n[0]][k], s[0][:n[0]][k]; t4 = time.perf_counter()
         for name, a, c in zip(seg, (t0, t1, t2, t3), (t1, t2, t3, t4)):
             seg[name].append((c - a) * 1e6)

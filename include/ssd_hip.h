@@ -158,6 +158,16 @@ int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, 
                 float *boxes_dev, int32_t *labels_dev, float *scores_dev,
                 int32_t *num_boxes_dev, void *stream);
 
+/* The same graph with the outputs as B fixed RECORDS -- the unit the all-gather of a data-parallel step moves (one process
+ * per GPU, images sharded, detections exchanged once per batch; the reference maps over images, nms.py:96-101, and has no
+ * multi-GPU code).  Record b starts at records_dev + b * ssd_record_words(h) 32-bit words:
+ *     boxes [T,4] f32 | scores [T] f32 | labels [T] i32 | num_boxes i32      T = num_classes * max_boxes_per_class
+ * (48 004 bytes at T = 2000).  records_dev: device memory, or pinned host memory (device-accessible at its own address).
+ * Asynchronous on `stream` like ssd_forward. */
+int32_t ssd_record_words(const ssd_handle *h);
+int ssd_forward_records(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W,
+                        void *records_dev, void *stream);
+
 /* Copy a retained intermediate of the last ssd_forward to the host in the reference's
  * logical NHWC channel order (synchronises).  Names: "c3","c4","c5" (backbone outputs),
  * "p3".."p7" (feature_extractor.py:71-76), "encoded_boxes" [B,N,4] and

@@ -17,7 +17,7 @@ seg = {k: [] for k in ("copyto_pinned", "h2d", "forward", "d2h", "filter")}
 for _ in range(50):
     t0 = time.perf_counter(); np.copyto(slot["pin_in_np"], img[None]); t1 = time.perf_counter()
     slot["dev_in"].copy_(slot["pin_in"], non_blocking=True); sync(); t2 = time.perf_counter()
-    e.forward(slot["dev_in"], out=slot["views"]); sync(); t3 = time.perf_counter()
+    e.forward(slot["dev_in"], records=slot["block"]); sync(); t3 = time.perf_counter()
     slot["pin_out"].copy_(slot["block"], non_blocking=True); torch.cuda.current_stream().synchronize(); t4 = time.perf_counter()
     b, l, s, n = slot["host"]; k = s[0][:n[0]] > 0.5; _ = b[0][:n[0]][k], l[0][:n[0]][k], s[0][:n[0]][k]; t5 = time.perf_counter()
     for name, a, c in zip(seg, (t0, t1, t2, t3, t4), (t1, t2, t3, t4, t5)):

@@ -189,7 +189,7 @@ extern "C" int ssd_finalize(ssd_handle *h)
 // another stream than the previous one it first waits for that one's last kernel (two host threads sharing a Detector on
 // their own streams, as tf.Session.run allows, inference/detector.py:34,52).
 static int forward_locked(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
-                          int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, hipStream_t s)
+                          int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, long long out_stride, hipStream_t s)
 {
     HIPCHK(hipSetDevice(h->cfg.device));
     if (B != h->pB || H != h->pH || W != h->pW) {
@@ -212,26 +212,26 @@ static int forward_locked(ssd_handle *h, const uint8_t *images_dev, int32_t B, i
     // (host enqueue 0.9 ms < 2.3 ms of kernels), so replay is OFF unless option graph = 1.
     const bool use_graph = ssd_opt(h, OPT_GRAPH, 0) != 0 && !h->capture_broken;
     if (!use_graph || h->profiling || h->plans.size() != 1)
-        return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, s);
+        return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, out_stride, s);
     if (!h->gstream) HIPCHK(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));    // (only a handle that replays graphs has one)
-    GraphKey key{images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, B, H, W};
+    GraphKey key{images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, B, H, W, out_stride};
     hipGraphExec_t exec = nullptr;
     for (auto &g : h->graphs)
         if (g.first == key) exec = g.second;
     if (!exec) {
         if (!(h->last_key == key)) {             // first sighting: run eagerly (lazy one-time inits happen here)
             h->last_key = key;
-            return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, s);
+            return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, out_stride, s);
         }
         hipGraph_t graph = nullptr;
         HIPCHK(hipStreamBeginCapture(h->gstream, hipStreamCaptureModeRelaxed));
-        int rc = enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, h->gstream);
+        int rc = enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, out_stride, h->gstream);
         hipError_t ce = hipStreamEndCapture(h->gstream, &graph);
         if (rc != SSD_OK || ce != hipSuccess || !graph) {
             if (graph) (void)hipGraphDestroy(graph);
             (void)hipGetLastError();
             h->capture_broken = true;            // capture unsupported here: stay eager from now on
-            return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, s);
+            return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, out_stride, s);
         }
         HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         (void)hipGraphDestroy(graph);
@@ -246,8 +246,8 @@ static int forward_locked(ssd_handle *h, const uint8_t *images_dev, int32_t B, i
     return SSD_OK;
 }
 
-extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
-                           int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, void *stream)
+static int forward_checked(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
+                           int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, long long out_stride, void *stream)
 {
     if (!h || !images_dev || !boxes_dev || !labels_dev || !scores_dev || !num_boxes_dev)
         return ssd_fail(SSD_ERR_INVALID, "ssd_forward: null argument");
@@ -261,9 +261,9 @@ extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, 
             return ssd_fail(SSD_ERR_INVALID, "ssd_forward: aspect ratio too extreme (resized image exceeds 64 Mpixel)");
     }
     hipStream_t s = (hipStream_t)stream;
-    const int rc = forward_locked(h, images_dev, B, H, W, boxes_dev, labels_dev, scores_dev, num_boxes_dev, s);
+    const int rc = forward_locked(h, images_dev, B, H, W, boxes_dev, labels_dev, scores_dev, num_boxes_dev, out_stride, s);
     if (rc == SSD_OK) {
-        // (not while a caller captures `s` into a graph of its own: an event recorded there belongs to that capture)
+        // (not while a caller captures `s` into a graph of its own: the stream then is not a queue of the device's)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
         if (cs == hipStreamCaptureStatusNone) {
@@ -272,6 +272,31 @@ extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, 
         }
     }
     return rc;
+}
+
+extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
+                           int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, void *stream)
+{
+    return forward_checked(h, images_dev, B, H, W, boxes_dev, labels_dev, scores_dev, num_boxes_dev, 0, stream);
+}
+
+// The same graph with its outputs as B fixed RECORDS (what the all-gather of a data-parallel step moves), record b
+// at records_dev + b * ssd_record_words(h) 32-bit words:
+//     boxes [T,4] f32 | scores [T] f32 | labels [T] i32 | num_boxes i32        T = num_classes * max_boxes_per_class
+// (48 004 bytes at T = 2 000).  One block instead of four tensors: a rank's output pointer can be its slice of the all-gather's
+// receive buffer (the collective runs in place) and one copy moves a batch's results to the host.
+extern "C" int32_t ssd_record_words(const ssd_handle *h)
+{
+    return h ? 6 * h->cfg.num_classes * h->cfg.max_boxes_per_class + 1 : 0;
+}
+
+extern "C" int ssd_forward_records(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, void *records_dev, void *stream)
+{
+    if (!h || !records_dev) return ssd_fail(SSD_ERR_INVALID, "ssd_forward_records: null argument");
+    if ((reinterpret_cast<uintptr_t>(records_dev) & 3) != 0) return ssd_fail(SSD_ERR_INVALID, "ssd_forward_records: records must be 4-byte aligned");
+    const long long T = (long long)h->cfg.num_classes * h->cfg.max_boxes_per_class;
+    int32_t *r = (int32_t *)records_dev;
+    return forward_checked(h, images_dev, B, H, W, (float *)r, r + 5 * T, (float *)(r + 4 * T), r + 6 * T, 6 * T + 1, stream);
 }
 
 extern "C" int ssd_get_tensor(ssd_handle *h, const char *name, float *dst, int64_t cap, int32_t *dims)

@@ -212,10 +212,11 @@ struct Plan {
 };
 
 struct GraphKey {
-    const void *img; void *boxes, *labels, *scores, *num; int B, H, W;
+    const void *img; void *boxes, *labels, *scores, *num; int B, H, W; long long out_stride = 0;
     bool operator==(const GraphKey &o) const
     {
-        return img == o.img && boxes == o.boxes && labels == o.labels && scores == o.scores && num == o.num && B == o.B && H == o.H && W == o.W;
+        return img == o.img && boxes == o.boxes && labels == o.labels && scores == o.scores && num == o.num && B == o.B && H == o.H && W == o.W &&
+               out_stride == o.out_stride;
     }
 };
 
@@ -268,4 +269,4 @@ struct ssd_handle {
 void free_plans(ssd_handle *h);
 int make_plans(ssd_handle *h, int B, int H, int W);
 int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, int32_t *labels_dev, float *scores_dev,
-                    int32_t *num_boxes_dev, hipStream_t s);
+                    int32_t *num_boxes_dev, long long out_stride, hipStream_t s);

@@ -1113,7 +1113,7 @@ int make_plans(ssd_handle *h, int B, int H, int W)
 // Enqueues one forward on stream `s` (plus the plans' internal streams): kernels only, no host
 // synchronisation -- also what a hipGraph capture records.
 int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, int32_t *labels_dev,
-                           float *scores_dev, int32_t *num_boxes_dev, hipStream_t s)
+                           float *scores_dev, int32_t *num_boxes_dev, long long out_stride, hipStream_t s)
 {
     h->cur_images = images_dev;
     if (h->profiling) {
@@ -1161,10 +1161,11 @@ int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, 
                 HIPCHK(hipStreamWaitEvent(sm, pl.ev_join_bb[c - 2], 0));
             }
         PostArgs p = pl.post;
-        p.boxes = boxes_dev + (size_t)pl.img0 * T * 4;
-        p.labels = labels_dev + (size_t)pl.img0 * T;
-        p.scores = scores_dev + (size_t)pl.img0 * T;
-        p.num = num_boxes_dev + pl.img0;
+        p.out_stride = out_stride;
+        p.boxes = boxes_dev + (out_stride ? (size_t)pl.img0 * out_stride : (size_t)pl.img0 * T * 4);
+        p.labels = labels_dev + (out_stride ? (size_t)pl.img0 * out_stride : (size_t)pl.img0 * T);
+        p.scores = scores_dev + (out_stride ? (size_t)pl.img0 * out_stride : (size_t)pl.img0 * T);
+        p.num = num_boxes_dev + (out_stride ? (size_t)pl.img0 * out_stride : (size_t)pl.img0);
         p.logit_lo = conservative_logit_bound(p.score_thr);
         Op pop;
         pop.cls = 4;

@@ -587,12 +587,13 @@ __global__ __launch_bounds__(256) void post_pack_kernel(const PostArgs p)
         carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
         __syncthreads();
     }
-    if (tid == 0) { pre[C] = carry; p.num[b] = carry; }
+    const long long rs = p.out_stride;                       // 0: dense tensors
+    if (tid == 0) { pre[C] = carry; p.num[rs ? b * rs : (long long)b] = carry; }
     __syncthreads();
     const int total = pre[C];
-    float *boxes = p.boxes + (long long)b * T * 4;
-    float *scores = p.scores + (long long)b * T;
-    int32_t *labels = p.labels + (long long)b * T;
+    float *boxes = p.boxes + (rs ? b * rs : (long long)b * T * 4);
+    float *scores = p.scores + (rs ? b * rs : (long long)b * T);
+    int32_t *labels = p.labels + (rs ? b * rs : (long long)b * T);
     // rows as 16-byte stores when the box block is 16-byte aligned (always, for the packed output block of ssd.py): the block
     // may live in pinned HOST memory (Engine.detect_host at small batches), where every partial write is a PCIe transaction
     const bool vec = ((reinterpret_cast<uintptr_t>(boxes) | reinterpret_cast<uintptr_t>(p.cls_boxes)) & 15) == 0;

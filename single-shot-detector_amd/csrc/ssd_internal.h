@@ -195,6 +195,8 @@ struct PostArgs {
                            // them zeroed for the next forward (no memset launches).  0: a caller's workspace, cleared per call
     float box_scaler[4];
     float *boxes; int32_t *labels; float *scores; int32_t *num;
+    long long out_stride;       // 32-bit words between the outputs of consecutive images, the same for all four pointers: 0 = the
+                                // four dense tensors (boxes T*4, labels / scores T, num 1), else the record stride (ssd_forward_records)
     // workspace carve-up
     unsigned long long *keys;   // [B][C][N]
     int *counts;                // [B][C]

@@ -60,19 +60,22 @@ def pack_detections(boxes, labels, scores, num):
 
 
 def unpack_detections(rec):
+    """(boxes, labels, scores, num) as VIEWS of a record block [B, 6T+1]: no copy, no launch."""
     B, words = rec.shape
     T = (words - 1) // 6
-    boxes = rec[:, :4 * T].contiguous().view(torch.float32).reshape(B, T, 4)
-    scores = rec[:, 4 * T:5 * T].contiguous().view(torch.float32)
-    labels = rec[:, 5 * T:6 * T].contiguous()
-    num = rec[:, 6 * T].contiguous()
+    boxes = rec[:, :4 * T].view(torch.float32).unflatten(1, (T, 4))
+    scores = rec[:, 4 * T:5 * T].view(torch.float32)
+    labels = rec[:, 5 * T:6 * T]
+    num = rec[:, 6 * T]
     return boxes, labels, scores, num
 
 
-def gather_records(rec, group=None):
-    """ONE all-gather of the [B_local, 6T+1] int32 records -> [world*B_local, 6T+1], rank order."""
+def gather_records(rec, group=None, out=None):
+    """ONE all-gather of the [B_local, 6T+1] int32 records -> [world*B_local, 6T+1], rank order.  `out`: the receive
+    buffer; when `rec` is this rank's slice of it the collective runs in place (RCCL: sendbuff == recvbuff + rank * count)."""
     world = dist.get_world_size(group)
-    out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    if out is None:
+        out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
     # One-buffer form everywhere (RCCL has it, and so does this image's gloo); only a backend that says it does not
     # implement it takes the list form.  Any other error is a real failure and propagates unchanged.
     try:
@@ -109,8 +112,37 @@ def all_gather_detections(boxes, labels, scores, num, group=None, total=None, fo
     return unpack_detections(torch.cat(rows, 0))
 
 
+_gather_buffers = {}
+
+
 def detect_sharded(engine, images_local, group=None, total=None, force=False):
     """One data-parallel step: this rank's shard through the HIP path, then the all-gather.
-    images_local: uint8 CUDA tensor [B_local,H,W,3]; `total`, `force`: see all_gather_detections."""
-    boxes, labels, scores, num = engine.forward(images_local)
-    return all_gather_detections(boxes, labels, scores, num, group=group, total=total, force=force)
+    images_local: uint8 CUDA tensor [B_local,H,W,3]; `total`, `force`: see all_gather_detections.
+    The engine writes its records straight into this rank's slice of the all-gather's receive buffer (ssd_forward_records),
+    the collective runs in place on it and the four results are views of the buffer: no pack / unpack launches, no stream
+    users beside RCCL's.  Uneven shards: every rank's slice is the largest shard's size; the rows beyond a rank's own
+    shard are dropped by one concatenation of row ranges."""
+    use = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
+    if not hasattr(engine, "record_words"):                # a stand-in engine (launcher tests): the generic path
+        boxes, labels, scores, num = engine.forward(images_local)
+        return all_gather_detections(boxes, labels, scores, num, group=group, total=total, force=force)
+    if not use:
+        return engine.forward(images_local)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = images_local.shape[0]
+    per = n if (total is None or total % world == 0) else -(-total // world)
+    if n > per:
+        raise ValueError("shard of %d images exceeds ceil(%d / %d)" % (n, total, world))
+    key = (id(engine), world, per, str(images_local.device))
+    buf = _gather_buffers.get(key)
+    if buf is None:
+        _gather_buffers.clear()
+        buf = _gather_buffers[key] = torch.zeros((world, per, engine.record_words), dtype=torch.int32, device=images_local.device)
+    engine.forward(images_local, records=buf[rank, :n])
+    inplace = dist.get_backend(group) == "nccl"
+    got = gather_records(buf[rank] if inplace else buf[rank].clone(), group, out=buf.view(world * per, -1))
+    if per == n and (total is None or total % world == 0):
+        return unpack_detections(got)
+    g3 = got.view(world, per, -1)
+    rows = [g3[r, :shard_range(total, r, world)[1] - shard_range(total, r, world)[0]] for r in range(world)]
+    return unpack_detections(torch.cat(rows, 0))

@@ -265,7 +265,7 @@ class Engine:
         self.T = int(params["num_classes"]) * int(params["max_boxes_per_class"])
         self._static = {}
         self._copy_streams = None
-        self.zero_copy_max_batch = 4     # detect_host: up to this many images the outputs are written straight into pinned host memory
+        self.zero_copy_max_batch = 1     # detect_host: up to this many images the records are written straight into pinned host memory
         self.h2d_chunks = 2              # detect_host: pieces of the staging copy + upload (measured: 1 / 2 / 3 / 4 pieces -> p50 1.769 / 1.752 / 1.755 / 1.769 ms)
         self.lock = threading.RLock()       # serialises the calls on this engine (tf.Session.run is thread-safe)
 
@@ -303,9 +303,12 @@ class Engine:
         with self.lock:
             _lib.set_option(key, value, self._h)
 
-    def forward(self, images, out=None):
+    def forward(self, images, out=None, records=None):
         """images: uint8 CUDA tensor [B,H,W,3] -> (boxes [B,T,4], labels [B,T] i32,
         scores [B,T], num_boxes [B] i32) CUDA tensors; asynchronous on the current stream.
+        The four outputs are views of ONE block of B fixed records (`records`: an int32 tensor [B, 6T+1] -- device memory
+        or pinned host memory -- created here when not given; ssd_forward_records): the unit the data-parallel all-gather
+        moves and one copy brings to the host.  `out` = four dense tensors of the caller's instead (ssd_forward).
         Thread-safe like tf.Session.run (inference/detector.py:34,52): calls on one engine are serialised (here and by the
         handle's own mutex), and the library orders the GPU work of consecutive forwards even across streams."""
         torch = _torch()
@@ -313,35 +316,51 @@ class Engine:
         if images.dim() != 4 or images.shape[3] != 3:
             raise ValueError("images must have shape [B,H,W,3]")
         B, H, W, _ = images.shape
-        dev = images.device
-        if out is None:
-            out = self._new_outputs(torch, B, dev)[1]
-        boxes, labels, scores, num = out
+        if out is not None:
+            boxes, labels, scores, num = out
+            for t in out:
+                if not t.is_contiguous():
+                    raise ValueError("out: four dense tensors (use records= for the packed block)")
+            with self.lock:
+                check(lib().ssd_forward(self._h, _ptr(images), B, H, W, _ptr(boxes), _ptr(labels),
+                                        _ptr(scores), _ptr(num), _stream(torch)))
+            return boxes, labels, scores, num
+        if records is None:
+            records = self.new_records(B, images.device)
+        if records.dtype != torch.int32 or tuple(records.shape) != (B, self.record_words) or not records.is_contiguous():
+            raise ValueError("records must be a contiguous int32 tensor [B, %d]" % self.record_words)
         with self.lock:
-            check(lib().ssd_forward(self._h, _ptr(images), B, H, W, _ptr(boxes), _ptr(labels),
-                                    _ptr(scores), _ptr(num), _stream(torch)))
-        return boxes, labels, scores, num
+            check(lib().ssd_forward_records(self._h, _ptr(images), B, H, W, _ptr(records), _stream(torch)))
+        return self.record_views(records)
+
+    @property
+    def record_words(self):
+        """32-bit words of one image's record: boxes [T,4] f32 | scores [T] f32 | labels [T] i32 | num_boxes i32."""
+        return 6 * self.T + 1
+
+    def new_records(self, B, dev):
+        return _torch().empty((B, self.record_words), dtype=_torch().int32, device=dev)
+
+    def record_views(self, rec):
+        """(boxes [B,T,4] f32, labels [B,T] i32, scores [B,T] f32, num_boxes [B] i32) as VIEWS of a record block [B, 6T+1]
+        (torch tensor or numpy array): no copy."""
+        T = self.T
+        B = rec.shape[0]
+        if isinstance(rec, np.ndarray):
+            return (rec[:, :4 * T].view(np.float32).reshape(B, T, 4), rec[:, 5 * T:6 * T], rec[:, 4 * T:5 * T].view(np.float32),
+                    rec[:, 6 * T])
+        torch = _torch()
+        return (rec[:, :4 * T].view(torch.float32).unflatten(1, (T, 4)), rec[:, 5 * T:6 * T],
+                rec[:, 4 * T:5 * T].view(torch.float32), rec[:, 6 * T])
 
     def _new_outputs(self, torch, B, dev):
-        """The four graph outputs as views of ONE int32 device block [boxes B*T*4 | labels B*T | scores B*T | num B]:
-        one copy moves all of them to the host."""
-        T = self.T
-        block = torch.empty((B * (6 * T + 1),), dtype=torch.int32, device=dev)
-        boxes = block[:B * T * 4].view(torch.float32).view(B, T, 4)
-        labels = block[B * T * 4:B * T * 5].view(B, T)
-        scores = block[B * T * 5:B * T * 6].view(torch.float32).view(B, T)
-        num = block[B * T * 6:]
-        return block, (boxes, labels, scores, num)
-
-    def _split_host(self, blk, B):
-        """numpy views of a host copy of such a block."""
-        T = self.T
-        return (blk[:B * T * 4].view(np.float32).reshape(B, T, 4), blk[B * T * 4:B * T * 5].reshape(B, T),
-                blk[B * T * 5:B * T * 6].view(np.float32).reshape(B, T), blk[B * T * 6:])
+        """(record block [B, 6T+1], its four views)."""
+        block = self.new_records(B, dev)
+        return block, self.record_views(block)
 
     def _slot(self, key, index=0):
-        """Persistent serving buffers of one input shape: device image, pinned host staging for the image, the packed
-        device outputs and their pinned host copy."""
+        """Persistent serving buffers of one input shape: device image, pinned host staging for the image, the device record
+        block and its pinned host copy."""
         torch = _torch()
         slot = self._static.get((key, index))
         if slot is None:
@@ -351,12 +370,7 @@ class Engine:
             pin_in = torch.empty(key, dtype=torch.uint8).pin_memory()
             pin_out = torch.empty(block.shape, dtype=torch.int32).pin_memory()
             slot = {"dev_in": torch.empty(key, dtype=torch.uint8, device=dev), "pin_in": pin_in, "pin_in_np": pin_in.numpy(),
-                    "block": block, "views": views, "pin_out": pin_out, "host": self._split_host(pin_out.numpy(), B)}
-            # the same four views over the PINNED block: pinned host memory is device-accessible at its own address, so the
-            # last kernel of a small forward can write the packed outputs straight into it (detect_host)
-            T = self.T
-            slot["pin_views"] = (pin_out[:B * T * 4].view(torch.float32).view(B, T, 4), pin_out[B * T * 4:B * T * 5].view(B, T),
-                                 pin_out[B * T * 5:B * T * 6].view(torch.float32).view(B, T), pin_out[B * T * 6:])
+                    "block": block, "views": views, "pin_out": pin_out, "host": self.record_views(pin_out.numpy())}
             while len(self._static) >= 8:
                 self._static.pop(next(iter(self._static)))
             self._static[(key, index)] = slot
@@ -381,7 +395,7 @@ class Engine:
             else:
                 slot["ev"] = torch.cuda.Event()
             slot["dev_in"].copy_(images, non_blocking=True)
-            out = self.forward(slot["dev_in"], out=slot["views"])
+            out = self.forward(slot["dev_in"], records=slot["block"])
             slot["ev"].record(cur)
             return out
 
@@ -411,11 +425,12 @@ class Engine:
                     np.copyto(pin_np[lo:hi], src[lo:hi])
                     dev_t[lo:hi].copy_(pin_t[lo:hi], non_blocking=True)
             if images.shape[0] <= self.zero_copy_max_batch:
-                # a few images: post_pack_kernel writes its 48 KB per image into the pinned block itself (16-byte rows over
-                # PCIe) -- no device-to-host copy behind the forward (11 us of a 1.7 ms call)
-                self.forward(slot["dev_in"], out=slot["pin_views"])
+                # one image: post_pack_kernel writes its 48 KB record into the pinned block itself (16-byte rows over
+                # PCIe) -- no device-to-host copy behind the forward (11 us of a 1.7 ms call).  (Records are 48 004 bytes:
+                # those of further images are not 16-byte aligned and would cross the bus in 4-byte writes.)
+                self.forward(slot["dev_in"], records=slot["pin_out"])
             else:
-                self.forward(slot["dev_in"], out=slot["views"])
+                self.forward(slot["dev_in"], records=slot["block"])
                 slot["pin_out"].copy_(slot["block"], non_blocking=True)
             torch.cuda.current_stream().synchronize()
             return slot["host"]
@@ -461,7 +476,7 @@ class Engine:
                 slot["dev_in"].copy_(slot["pin_in"], non_blocking=True)
                 e["h2d"].record(s_in)
             s_c.wait_event(e["h2d"])
-            self.forward(slot["dev_in"], out=slot["views"])
+            self.forward(slot["dev_in"], records=slot["block"])
             e["cmp"].record(s_c)
             with torch.cuda.stream(s_out):
                 s_out.wait_event(e["cmp"])

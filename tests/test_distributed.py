@@ -65,6 +65,69 @@ def test_all_gather_detections_gloo_world2():
     assert (res[0][2], res[0][3]) == (0, 4) and (res[1][2], res[1][3]) == (4, 7)
 
 
+class _RecordEngine:
+    """Stand-in with the engine's record interface (Engine.forward(images, records=...), record_words): writes the records
+    _records() defines for this rank straight into the block it is handed -- what ssd_forward_records does on the GPU."""
+
+    def __init__(self, rank, T):
+        self.rank, self.T, self.record_words = rank, T, 6 * T + 1
+
+    def forward(self, images, out=None, records=None):
+        import ssd_amd
+        from importlib import import_module
+        d = import_module("ssd_amd.distributed")
+        mine = tuple(t[:images.shape[0]] for t in _records(self.rank, 3, self.T))
+        if records is None:
+            return mine
+        records.copy_(d.pack_detections(*mine))
+        return d.unpack_detections(records)
+
+
+def _worker_sharded(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import ssd_amd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T = 40
+    eng = _RecordEngine(rank, T)
+    ok = True
+    # even shards: 3 + 3; the engine's records land in this rank's slice of the receive buffer, results are views of it
+    out = ssd_amd.detect_sharded(eng, torch.zeros((3, 8, 8, 3), dtype=torch.uint8), total=6)
+    for r in range(world):
+        for a, b in zip(out, _records(r, 3, T)):
+            ok &= bool(torch.equal(a[r * 3:(r + 1) * 3], b))
+    # uneven shards: 5 = 3 + 2, twice (the buffer is reused)
+    for _ in range(2):
+        lo, hi = ssd_amd.shard_range(5, rank, world)
+        out5 = ssd_amd.detect_sharded(eng, torch.zeros((hi - lo, 8, 8, 3), dtype=torch.uint8), total=5)
+        ok &= out5[0].shape == (5, T, 4) and out5[3].shape == (5,)
+        row = 0
+        for r in range(world):
+            l5, h5 = ssd_amd.shard_range(5, r, world)
+            for a, b in zip(out5, _records(r, 3, T)):
+                ok &= bool(torch.equal(a[row:row + h5 - l5], b[:h5 - l5]))
+            row += h5 - l5
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_detect_sharded_record_path_gloo_world2():
+    """detect_sharded with an engine that writes records (the product path): records -> this rank's slice of the receive
+    buffer -> ONE all-gather -> views; even and uneven shards."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1]
+
+
 def test_pack_unpack_roundtrip_and_record_size():
     sys.path.insert(0, ROOT)
     import ssd_amd

@@ -353,6 +353,19 @@ back = d.unpack_detections(got)
 assert all(torch.equal(a, b) for a, b in zip(back, out))
 full = ssd_amd.detect_sharded(eng, frames)
 assert all(torch.equal(a, b) for a, b in zip(full, out))
+# the collective path itself at world 1 (force): the engine writes its records into this rank's slice of the receive buffer,
+# RCCL gathers in place, the results are views of that buffer -- even shard, then a "global batch" the world does not divide
+forced = ssd_amd.detect_sharded(eng, frames, total=2, force=True)
+torch.cuda.synchronize()
+assert all(torch.equal(a, b) for a, b in zip(forced, out)) and forced[0].data_ptr() != out[0].data_ptr()
+recs = eng.new_records(2, frames.device)
+again = eng.forward(frames, records=recs)
+assert recs.shape == (2, 12001) and recs.element_size() * recs.shape[1] == 48004        # SURVEY 8e
+assert all(torch.equal(a, b) for a, b in zip(again, out)) and again[0].data_ptr() == recs.data_ptr()
+assert torch.equal(recs, d.pack_detections(*out))
+dense = tuple(torch.empty_like(t.contiguous()) for t in out)
+eng.forward(frames, out=dense)                  # four dense tensors of the caller's (ssd_forward)
+assert all(torch.equal(a, b) for a, b in zip(dense, out))
 dist.barrier(); dist.destroy_process_group()
 print("RCCL_OK", int(out[3].sum()))
 """
