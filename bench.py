@@ -114,7 +114,8 @@ def latency_batch1(detector):
 
 def latency_segments(detector):
     """Where a batch-1 Detector call spends its time (attribution: every segment followed by a synchronisation, so the
-    sum exceeds the pipelined call): staging memcpy, upload, forward (results into pinned host memory), score filter."""
+    sum exceeds the pipelined call -- ssd_forward_host stages and uploads the image in pieces, the upload of one under the
+    host copy of the next): staging memcpy, upload, forward (results into pinned host memory), score filter."""
     e = detector.engine
     img = np.random.default_rng(0).integers(0, 256, (H, W, 3), dtype=np.uint8)
     for _ in range(5):

@@ -123,6 +123,7 @@ int ssd_get_precision(ssd_handle *h);
  *   "nsub"            0 auto | 1..8: staggered sub-batch plans                                            (0)
  *   "level_split"     0 | 1 | 2: head towers of levels 6-7 as launches of their own (batch <= 2): every layer / the first (0)
  *   "nms_fast_max"    -1 default | n >= 0: candidate lists up to n stay in one wave's registers          (-1)
+ *   "h2d_chunks"      2 | 1..16: pieces of ssd_forward_host's staging copy + upload                       (2)
  *   "fuse_dw"         -1 default | bit mask of depthwise+pointwise pairs that run as one launch          (-1)
  *   "graph"           0 | 1: hipGraph replay of a repeating forward                                      (0)
  *   "debug_sync"      0 | 1: announce every op on stderr, run it alone, wait for it, print its time      (0)
@@ -167,6 +168,13 @@ int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, 
 int32_t ssd_record_words(const ssd_handle *h);
 int ssd_forward_records(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W,
                         void *records_dev, void *stream);
+/* Detector.__call__'s own form (inference/detector.py:51-52 feeds a HOST array on every call): images_host is ordinary
+ * (pageable) host memory; the library copies it through its pinned staging buffer into device memory in option
+ * "h2d_chunks" pieces (piece k crosses the bus under the host copy of piece k + 1) and runs ssd_forward_records on
+ * `stream`.  On return images_host may be reused; the upload and the forward are asynchronous on `stream`.
+ * `records`: device memory or pinned host memory, as for ssd_forward_records. */
+int ssd_forward_host(ssd_handle *h, const uint8_t *images_host, int32_t B, int32_t H, int32_t W,
+                     void *records, void *stream);
 
 /* Copy a retained intermediate of the last ssd_forward to the host in the reference's
  * logical NHWC channel order (synchronises).  Names: "c3","c4","c5" (backbone outputs),

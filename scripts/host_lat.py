@@ -28,8 +28,10 @@ ts = []
 for _ in range(110):
     t0 = time.perf_counter(); det(img, score_threshold=0.5); ts.append((time.perf_counter() - t0) * 1e3)
 print("Detector.__call__ p50 %.3f ms (mean %.3f)" % (np.percentile(ts[10:], 50), np.mean(ts[10:])))
-for nc in (1, 2, 3, 4, 6):
-    e.h2d_chunks = nc
+for nc in (1, 2, 3, 4, 6, 8):
+    e.set_option("h2d_chunks", nc)           # ssd_forward_host: pieces of the staging copy + upload
+    for _ in range(5):
+        det(img, score_threshold=0.5)
     ts = []
     for _ in range(110):
         t0 = time.perf_counter(); det(img, score_threshold=0.5); ts.append((time.perf_counter() - t0) * 1e3)

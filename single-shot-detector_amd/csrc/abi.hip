@@ -17,7 +17,7 @@ extern "C" const char *ssd_last_error(void) { return g_err.c_str(); }
 static Options g_opts;                 // process-wide values (ssd_set_option with a NULL handle)
 static std::mutex g_opts_mu;
 static const char *const OPT_NAMES[OPT_COUNT] = {"igemm_tile", "igemm16", "igemm_96", "lateral_split", "backbone_split", "nsub",
-                                                 "level_split", "nms_fast_max", "debug_sync", "fuse_dw", "graph", "igemm_lat", "igemm_deep64", "streams", "fpn_group", "head_serial", "side_priority", "tower_group", "fpn_p6_first", "dwpw_lat", "fpn_p7_group", "event_fence", "lat_one"};
+                                                 "level_split", "nms_fast_max", "debug_sync", "fuse_dw", "graph", "igemm_lat", "igemm_deep64", "streams", "fpn_group", "head_serial", "side_priority", "tower_group", "fpn_p6_first", "dwpw_lat", "h2d_chunks", "fpn_p7_group", "event_fence", "lat_one"};
 int ssd_opt_index(const char *key)
 {
     for (int i = 0; i < OPT_COUNT; ++i)
@@ -151,6 +151,8 @@ extern "C" void ssd_destroy(ssd_handle *h)
     if (h->ev_gout) (void)hipEventDestroy(h->ev_gout);
     if (h->ev_last) (void)hipEventDestroy(h->ev_last);
     if (h->gstream) (void)hipStreamDestroy(h->gstream);
+    if (h->stage_pin) (void)hipHostFree(h->stage_pin);
+    if (h->stage_dev) (void)hipFree(h->stage_dev);
     if (h->flags_dev) (void)hipFree(h->flags_dev);
     h->wpool.free_all();
     delete h;
@@ -246,12 +248,10 @@ static int forward_locked(ssd_handle *h, const uint8_t *images_dev, int32_t B, i
     return SSD_OK;
 }
 
-static int forward_checked(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
-                           int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, long long out_stride, void *stream)
+// (the caller holds h->mu)
+static int forward_checked_locked(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
+                                  int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, long long out_stride, void *stream)
 {
-    if (!h || !images_dev || !boxes_dev || !labels_dev || !scores_dev || !num_boxes_dev)
-        return ssd_fail(SSD_ERR_INVALID, "ssd_forward: null argument");
-    std::lock_guard<std::mutex> g(h->mu);
     if (!h->finalized) return ssd_fail(SSD_ERR_STATE, "ssd_forward before ssd_finalize");
     if (B < 1 || H < 1 || W < 1 || h->cfg.min_dimension < 128 || h->cfg.min_dimension % 128)
         return ssd_fail(SSD_ERR_INVALID, "ssd_forward: B, H, W must be positive and min_dimension a multiple of 128 (pipeline.py:152)");
@@ -272,6 +272,15 @@ static int forward_checked(ssd_handle *h, const uint8_t *images_dev, int32_t B, 
         }
     }
     return rc;
+}
+
+static int forward_checked(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
+                           int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, long long out_stride, void *stream)
+{
+    if (!h || !images_dev || !boxes_dev || !labels_dev || !scores_dev || !num_boxes_dev)
+        return ssd_fail(SSD_ERR_INVALID, "ssd_forward: null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    return forward_checked_locked(h, images_dev, B, H, W, boxes_dev, labels_dev, scores_dev, num_boxes_dev, out_stride, stream);
 }
 
 extern "C" int ssd_forward(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
@@ -297,6 +306,48 @@ extern "C" int ssd_forward_records(ssd_handle *h, const uint8_t *images_dev, int
     const long long T = (long long)h->cfg.num_classes * h->cfg.max_boxes_per_class;
     int32_t *r = (int32_t *)records_dev;
     return forward_checked(h, images_dev, B, H, W, (float *)r, r + 5 * T, (float *)(r + 4 * T), r + 6 * T, 6 * T + 1, stream);
+}
+
+// The boundary's own form (inference/detector.py:51-52: a HOST image in on every call): pageable host memory -> the handle's
+// pinned staging buffer -> its device image, in `h2d_chunks` pieces so that piece k crosses the bus under the host copy of
+// piece k + 1 -- one C loop instead of a Python one (two numpy / torch calls per piece cost more than a piece's copy) --
+// then ssd_forward_records on the same stream.  The host copy is synchronous (on return `images_host` may be reused), the rest
+// asynchronous on `stream`.
+extern "C" int ssd_forward_host(ssd_handle *h, const uint8_t *images_host, int32_t B, int32_t H, int32_t W, void *records, void *stream)
+{
+    if (!h || !images_host || !records) return ssd_fail(SSD_ERR_INVALID, "ssd_forward_host: null argument");
+    if (B < 1 || H < 1 || W < 1) return ssd_fail(SSD_ERR_INVALID, "ssd_forward_host: B, H, W must be positive");
+    if ((reinterpret_cast<uintptr_t>(records) & 3) != 0) return ssd_fail(SSD_ERR_INVALID, "ssd_forward_host: records must be 4-byte aligned");
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t bytes = (size_t)B * H * W * 3;
+    // the previous call's upload may still be reading the staging buffer when the caller did not wait for it
+    if (h->stage_busy) { HIPCHK(hipStreamSynchronize(h->stage_stream)); h->stage_busy = false; }
+    if (bytes > h->stage_bytes) {
+        HIPCHK(hipDeviceSynchronize());
+        if (h->stage_pin) { (void)hipHostFree(h->stage_pin); h->stage_pin = nullptr; }
+        if (h->stage_dev) { (void)hipFree(h->stage_dev); h->stage_dev = nullptr; }
+        h->stage_bytes = 0;
+        HIPCHK(hipHostMalloc((void **)&h->stage_pin, bytes + 256, hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&h->stage_dev, bytes + 256));
+        h->stage_bytes = bytes;
+    }
+    int nchunk = ssd_opt(h, OPT_H2D_CHUNKS, 2);      // (measured: 1 / 2 / 3 / 4 / 6 / 8 pieces -> Detector p50 1.695 / 1.678 / 1.691 / 1.698 / 1.717 / 1.735 ms: a hipMemcpyAsync costs the host ~10 us)
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > 16) nchunk = 16;
+    if (bytes < ((size_t)1 << 20)) nchunk = 1;
+    const size_t step = ((bytes + nchunk - 1) / nchunk + 4095) & ~(size_t)4095;
+    for (size_t lo = 0; lo < bytes; lo += step) {
+        const size_t n = bytes - lo < step ? bytes - lo : step;
+        memcpy(h->stage_pin + lo, images_host + lo, n);
+        HIPCHK(hipMemcpyAsync(h->stage_dev + lo, h->stage_pin + lo, n, hipMemcpyHostToDevice, s));
+    }
+    h->stage_stream = s;
+    h->stage_busy = true;
+    const long long T = (long long)h->cfg.num_classes * h->cfg.max_boxes_per_class;
+    int32_t *r = (int32_t *)records;
+    return forward_checked_locked(h, h->stage_dev, B, H, W, (float *)r, r + 5 * T, (float *)(r + 4 * T), r + 6 * T, 6 * T + 1, stream);
 }
 
 extern "C" int ssd_get_tensor(ssd_handle *h, const char *name, float *dst, int64_t cap, int32_t *dims)

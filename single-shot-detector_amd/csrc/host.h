@@ -54,6 +54,7 @@ enum SsdOpt {
     OPT_FPN_P6_FIRST,       // 3 (default): fpn p6 -> p7 on the main stream, the laterals beside them | 0: p6 -> p7 on the third stream | 1 / 2: ... and the grouped launch waits for p6 / p7
     OPT_DWPW_LAT,           // 0 (default) | 1 | 2 | 4: depthwise + pointwise pairs the streaming kernel leaves apart as ONE launch of
                             // dwpw_lat.hip (measured slower than the pair, plan.hip); 1 = channel tiles per wave chosen per layer, 2 / 4 pin them
+    OPT_H2D_CHUNKS,         // 2 (default) | 1 .. 16: pieces of ssd_forward_host's staging copy + upload (piece k uploads under the host copy of k + 1)
     OPT_FPN_P7_GROUP,       // 1 (default) | 0: fpn p7 as a fourth level of the grouped p3 + p4 + p5 launch (batch <= 2, exact fp32)
     OPT_EVENT_FENCE,        // 0 (default): the library's ordering events carry no system-scope fence (hipEventDisableSystemFence: they order
                             // streams of ONE device) | 1: default event flags (a cache writeback per record: ~8-12 us per cross-stream edge)
@@ -249,6 +250,11 @@ struct ssd_handle {
     hipStream_t last_stream = nullptr;
     bool have_last = false;
     hipEvent_t ev_last = nullptr;
+    // ssd_forward_host: pinned staging + device image, grown on demand; the stream whose copy last read the staging buffer
+    uint8_t *stage_pin = nullptr, *stage_dev = nullptr;
+    size_t stage_bytes = 0;
+    hipStream_t stage_stream = nullptr;
+    bool stage_busy = false;
     // hipGraph replay
     hipStream_t gstream = nullptr;
     hipEvent_t ev_gin = nullptr, ev_gout = nullptr;

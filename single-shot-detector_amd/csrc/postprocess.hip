@@ -247,16 +247,29 @@ __global__ __launch_bounds__(256) void post_scan_kernel(const PostArgs p)
     if (q_n > 0) drain(e_lo == 0xFFFFFFFFu ? 0u : e_lo, (unsigned)(total * per - 1));
 }
 
+// Wave-wide maximum of a 32-bit value on the DPP path (row shifts inside the rows of 16 lanes, then the gfx9 row broadcasts:
+// lane 63 ends up with the maximum of all 64 lanes): seven cross-lane moves fused into the VALU instead of six
+// ds_bpermute round trips through the LDS crossbar.  All 64 lanes must be active.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false));     // row_shr:1
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false));     // row_shr:2
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false));     // row_shr:4
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false));     // row_shr:8: lane 15 of a row = the row's max
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));     // row_bcast:15 into rows 1, 3
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));     // row_bcast:31 into rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// ... of a 64-bit key = (score bits << 32 | ~anchor): the largest score first, then, among the lanes that hold it, the
+// largest low word (the smallest anchor) -- two 32-bit reductions give exactly the 64-bit maximum.  The result is
+// wave-uniform.  (The first form, six butterfly steps of two ds_bpermute each, was ~0.3 us of every NMS round.)
 __device__ __forceinline__ u64 wave_max_u64(u64 v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned lo = __shfl_xor((unsigned)(v & 0xFFFFFFFFu), off, 64);
-        const unsigned hi = __shfl_xor((unsigned)(v >> 32), off, 64);
-        const u64 o = ((u64)hi << 32) | lo;
-        v = o > v ? o : v;
-    }
-    return v;
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)(v & 0xFFFFFFFFu);
+    const unsigned bh = wave_max_u32(hi);
+    const unsigned bl = wave_max_u32(hi == bh ? lo : 0u);
+    return ((u64)bh << 32) | bl;
 }
 
 #define NMS_R 8      // candidates per thread kept in registers
@@ -493,10 +506,29 @@ __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
         const unsigned lo_bits = __float_as_uint(p.score_thr > 0.0f ? p.score_thr : 0.0f);
         int shift = 0;
         while (((0x3F800000u - lo_bits) >> shift) >= (unsigned)NBIN) ++shift;
+        // The list's keys once into registers (up to 32 per thread, all loads in flight together): the histogram and the
+        // compaction passes below then read registers.  (As two loops over global memory each pass was a chain of n / 256
+        // dependent L2 round trips: 16 of them for the bench frames' class of 4 085 candidates, twice.)
+        constexpr int KR = 32;
+        u64 kreg[KR];
+        const bool inreg = n <= NMS_MID * KR;                   // block-uniform
+        if (inreg) {
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                const int i = tid + NMS_MID * r;
+                kreg[r] = i < n ? keys[i] : 0ull;               // (a key is never 0: its score exceeds a positive threshold)
+            }
+        }
         for (int i = tid; i < NBIN; i += NMS_MID) hist[i] = 0;
         if (tid == 0) trial_kept = -1;
         __syncthreads();
-        for (int i = tid; i < n; i += NMS_MID) atomicAdd(&hist[((unsigned)(keys[i] >> 32) - lo_bits) >> shift], 1u);
+        if (inreg) {
+#pragma unroll
+            for (int r = 0; r < KR; ++r)
+                if (kreg[r] != 0ull) atomicAdd(&hist[((unsigned)(kreg[r] >> 32) - lo_bits) >> shift], 1u);
+        } else {
+            for (int i = tid; i < n; i += NMS_MID) atomicAdd(&hist[((unsigned)(keys[i] >> 32) - lo_bits) >> shift], 1u);
+        }
         __syncthreads();
         // cut_bin[k] = the smallest bin whose suffix count (candidates in bins >= it) is still <= cap_k, for the two caps
         // 128 and 512.  Wave 0, lane l owns bins 32 l .. 32 l + 31: lane totals, a suffix scan over the lanes, and the one lane
@@ -534,9 +566,17 @@ __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
             if (k == 1 && cb == cut_bin[0]) break;          // the same candidates again
             if (tid == 0) chunk_n = 0;
             __syncthreads();
-            for (int i = tid; i < n; i += NMS_MID) {
-                const u64 kk = keys[i];
-                if ((int)(((unsigned)(kk >> 32) - lo_bits) >> shift) >= cb) chunk[atomicAdd(&chunk_n, 1)] = kk;
+            if (inreg) {
+#pragma unroll
+                for (int r = 0; r < KR; ++r) {
+                    const u64 kk = kreg[r];
+                    if (kk != 0ull && (int)(((unsigned)(kk >> 32) - lo_bits) >> shift) >= cb) chunk[atomicAdd(&chunk_n, 1)] = kk;
+                }
+            } else {
+                for (int i = tid; i < n; i += NMS_MID) {
+                    const u64 kk = keys[i];
+                    if ((int)(((unsigned)(kk >> 32) - lo_bits) >> shift) >= cb) chunk[atomicAdd(&chunk_n, 1)] = kk;
+                }
             }
             __syncthreads();
             const int nn = chunk_n;

@@ -266,7 +266,6 @@ class Engine:
         self._static = {}
         self._copy_streams = None
         self.zero_copy_max_batch = 1     # detect_host: up to this many images the records are written straight into pinned host memory
-        self.h2d_chunks = 2              # detect_host: pieces of the staging copy + upload (measured: 1 / 2 / 3 / 4 pieces -> p50 1.769 / 1.752 / 1.755 / 1.769 ms)
         self.lock = threading.RLock()       # serialises the calls on this engine (tf.Session.run is thread-safe)
 
     @property
@@ -410,27 +409,16 @@ class Engine:
             raise ValueError("images must be a uint8 array of shape [B, height, width, 3]")
         with self.lock:
             slot = self._slot(tuple(images.shape))
-            nchunk = self.h2d_chunks if images.nbytes >= (1 << 20) else 1
-            if nchunk <= 1:
-                np.copyto(slot["pin_in_np"], images)
-                slot["dev_in"].copy_(slot["pin_in"], non_blocking=True)
-            else:
-                # staging copy and upload in pieces: the upload of piece k runs under the host's copy of piece k + 1
-                # (one 640x896 frame: 39 us of memcpy + 43 us of PCIe in a row, scripts/host_lat.py)
-                src = np.ascontiguousarray(images).reshape(-1)
-                pin_np, pin_t, dev_t = slot["pin_in_np"].reshape(-1), slot["pin_in"].view(-1), slot["dev_in"].view(-1)
-                step = -(-src.size // nchunk)
-                for lo in range(0, src.size, step):
-                    hi = min(lo + step, src.size)
-                    np.copyto(pin_np[lo:hi], src[lo:hi])
-                    dev_t[lo:hi].copy_(pin_t[lo:hi], non_blocking=True)
-            if images.shape[0] <= self.zero_copy_max_batch:
-                # one image: post_pack_kernel writes its 48 KB record into the pinned block itself (16-byte rows over
-                # PCIe) -- no device-to-host copy behind the forward (11 us of a 1.7 ms call).  (Records are 48 004 bytes:
-                # those of further images are not 16-byte aligned and would cross the bus in 4-byte writes.)
-                self.forward(slot["dev_in"], records=slot["pin_out"])
-            else:
-                self.forward(slot["dev_in"], records=slot["block"])
+            src = np.ascontiguousarray(images)
+            B, H, W, _ = src.shape
+            # ssd_forward_host: staging copy + upload in pieces (one C loop) and the forward, on the current stream.  One image:
+            # post_pack_kernel writes its 48 KB record into the pinned block itself (16-byte rows over PCIe) -- no
+            # device-to-host copy behind the forward.  (Records are 48 004 bytes: those of further images are not 16-byte
+            # aligned and would cross the bus in 4-byte writes -- they go through the device block and one copy.)
+            zc = B <= self.zero_copy_max_batch
+            rec = slot["pin_out"] if zc else slot["block"]
+            check(lib().ssd_forward_host(self._h, src.ctypes.data, B, H, W, _ptr(rec), _stream(torch)))
+            if not zc:
                 slot["pin_out"].copy_(slot["block"], non_blocking=True)
             torch.cuda.current_stream().synchronize()
             return slot["host"]
