@@ -24,15 +24,20 @@
 #include <type_traits>
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+#define DWL_SLICE 1664           // bytes between the 32-channel slices of the depthwise table in LDS (1 536 of data + 128)
 static __device__ __forceinline__ int dl_swz(int r) { return (int)((0x32765410u >> (4 * ((r >> 1) & 7))) & 7u) ^ ((r & 1) << 2); }   // = lat_swz (igemm_lat.hip)
 
 template <int CT, int STRIDE>
-__global__ __launch_bounds__(256) void dwpw_lat_kernel(const DwPwLArgs q)
+__global__ __launch_bounds__(256, (CT <= 2 ? 3 : 1)) void dwpw_lat_kernel(const DwPwLArgs q)
 {
     const IgemmArgs &a = q.g;
     constexpr int BNW = CT * 16, BN = 4 * BNW;
     constexpr unsigned OOB = 0x80000000u;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 4096];      // [stage][K-step of the slice][16 rows x 128 B]
+    // LDS: [stage][K-step of the slice][16 rows x 128 B] A images, then the layer's depthwise table -- per 32-channel slice
+    // 9 taps + mean + sf + beta x 32 channels (DwW::pack), slices DWL_SLICE bytes apart: the two slices an iteration reads
+    // must not share banks (1 536 B = 6 x 256 B would put them on the same 32)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *const tab = lds + 2 * 4096;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -50,10 +55,13 @@ __global__ __launch_bounds__(256) void dwpw_lat_kernel(const DwPwLArgs q)
     const int KC = K >> 5, NI = K >> 6;
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, (int)((long long)a.B * H * W * K * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void *)q.dw_w, 0, 9 * K * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)q.dw_mean, 0, K * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc((void *)q.dw_sf, 0, K * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void *)q.dw_beta, 0, K * 4, 0x00020000);
+    {   // the depthwise table of the whole layer into LDS, once per block (K / 32 slices of 96 sixteen-byte pieces)
+        const int npiece = KC * 96;
+        for (int i = tid; i < npiece; i += 256) {
+            const int sl = i / 96, o = i - sl * 96;
+            *(v4f *)(tab + sl * DWL_SLICE + o * 16) = *(const v4f *)(q.dw_pack + (long long)sl * 384 + o * 4);
+        }
+    }
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.wt_lat, 0, (int)((long long)a.CoutPad * K * 4), 0x00020000);
 
     // ---- producer item: position r of the tile, channels 4c .. 4c + 3 of the slice
@@ -91,25 +99,24 @@ __global__ __launch_bounds__(256) void dwpw_lat_kernel(const DwPwLArgs q)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) wbase[ct] = ((n0 >> 4) + ct) * KC * 2048 + lane * 16;
 
-    v4f xr[9], wd[9], bm, bs, bb;                       // the producer's operands of ONE slice
+    v4f xr[9];                                          // the nine taps of ONE slice (the weights come from the LDS table)
     auto issue_prod = [&](int it) __attribute__((always_inline)) {
         const int so = it * 256;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            xr[t] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)xoff[t], so, 0));
-            wd[t] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(drsrc, c * 16, t * K * 4 + so, 0));
-        }
-        bm = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, c * 16, so, 0));
-        bs = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(srsrc, c * 16, so, 0));
-        bb = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(brsrc, c * 16, so, 0));
+        for (int t = 0; t < 9; ++t) xr[t] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)xoff[t], so, 0));
     };
     const int dact = q.dact;
-    auto produce = [&](int stage) __attribute__((always_inline)) {
+    const int toff = (c >> 3) * DWL_SLICE + (c & 7) * 16;        // this thread's column of the table within an iteration's two slices
+    auto produce = [&](int stage, int it) __attribute__((always_inline)) {
+        const unsigned char *tb = tab + it * (2 * DWL_SLICE) + toff;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t) {
+            const v4f wd = *(const v4f *)(tb + t * 128);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = fmaf(xr[t][i], wd[t][i], acc[i]);
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(xr[t][i], wd[i], acc[i]);
+        }
+        const v4f bm = *(const v4f *)(tb + 9 * 128), bs = *(const v4f *)(tb + 10 * 128), bb = *(const v4f *)(tb + 11 * 128);
         v4f v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -164,27 +171,48 @@ __global__ __launch_bounds__(256) void dwpw_lat_kernel(const DwPwLArgs q)
     // passed that barrier, with its reads complete, before any wave writes here.
     issue_prod(0);
     issue_w(std::integral_constant<int, 0>{}, 0);
-    produce(0);
+    __syncthreads();                                         // the table is in LDS
+    produce(0, 0);
     issue_prod(NI > 1 ? 1 : 0);
     __syncthreads();
     lread(0);
-    auto iter = [&](auto set_tag, int it) __attribute__((always_inline)) {
+    // One iteration that has a successor, as ONE straight-line region with the instruction mix pinned (sched_group_barrier):
+    // behind every MFMA of slice `it` its share of the NEXT slice's production (table reads first, the fmaf chain, the two
+    // LDS writes last) and of the loads two slices / one slice ahead.  Issued as blocks -- production, then 17 loads, then 32
+    // MFMAs -- the four waves of a block queued their loads together, sat in the texture-address path's queue and reached
+    // their MFMAs late, and every block of a CU did so at the same time: the phases added (35 us per 512 -> 512 layer with
+    // per-thread depthwise weights from global memory, 26.5 with the LDS table, profiles/r04_batch1_option_ab.log).
+    auto iter_mid = [&](auto set_tag, int it) __attribute__((always_inline)) {
         constexpr int S = decltype(set_tag)::value;
-        if (it + 1 < NI) {                                   // block-uniform
-            produce((it + 1) & 1);
-            issue_prod(it + 2 < NI ? it + 2 : it + 1);
-            issue_w(std::integral_constant<int, S ^ 1>{}, it + 1);
-        }
+        constexpr int NM = 16 * CT, NV = 9 + 4 * CT, VAL = (72 + NM - 1) / NM;
+        __builtin_amdgcn_sched_barrier(0);
+        produce((it + 1) & 1, it + 1);
+        issue_w(std::integral_constant<int, S ^ 1>{}, it + 1);
+        issue_prod(it + 2 < NI ? it + 2 : it + 1);
         mfmas(set_tag);
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);             // the slice's twelve table reads up front: they land under
+#pragma unroll                                                           // the first MFMAs (read one by one in front of its fmaf
+        for (int i = 0; i < NM; ++i) {                                   // group, each cost the wave an LDS round trip between two MFMAs)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  // one MFMA
+            if (i > 0) __builtin_amdgcn_sched_group_barrier(0x002, VAL, 0);                     // producer arithmetic
+            if ((i * NV) / NM != ((i + 1) * NV) / NM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a load
+            if (i >= NM - 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                 // the A image's two writes
+        }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        if (it + 1 < NI) lread((it + 1) & 1);
+        lread((it + 1) & 1);
     };
     int it = 0;
-    for (; it + 2 <= NI; it += 2) {
-        iter(std::integral_constant<int, 0>{}, it);
-        iter(std::integral_constant<int, 1>{}, it + 1);
+    for (; it + 2 < NI; it += 2) {
+        iter_mid(std::integral_constant<int, 0>{}, it);
+        iter_mid(std::integral_constant<int, 1>{}, it + 1);
     }
-    if (it < NI) iter(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < NI) {                                       // NI - it == 2
+        iter_mid(std::integral_constant<int, 0>{}, it);
+        mfmas(std::integral_constant<int, 1>{});
+    } else {                                                 // NI - it == 1
+        mfmas(std::integral_constant<int, 0>{});
+    }
 
     epilogue_16x16<1, CT>(a, L, acc, m0, n0, lane);
 }
@@ -193,6 +221,7 @@ bool dwpw_lat_supports(const DwPwLArgs &q, int ct)
 {
     const IgemmArgs &a = q.g;
     if (ct != 1 && ct != 2 && ct != 4) return false;
+    if (2 * 4096 + (a.Cin >> 5) * DWL_SLICE > 64 * 1024 || !q.dw_pack) return false;      // the layer's depthwise table lives in LDS
     if (a.Cin < 64 || a.Cin % 64 != 0 || a.CoutPad % (64 * ct) != 0 || a.Cout % 4 != 0 || !a.wt_lat || !a.mean || a.bias || a.res || a.out2) return false;
     if (a.in_fmt || a.out_fmt || a.res_fmt || a.nlevels != 1 || a.taps != 1) return false;
     if ((q.dstride != 1 && q.dstride != 2) || q.dpad < 0 || q.dpad > 1) return false;
@@ -207,8 +236,9 @@ bool dwpw_lat_supports(const DwPwLArgs &q, int ct)
 template <int CT>
 static hipError_t launch_c(const DwPwLArgs &q, long long nblk, hipStream_t s)
 {
-    if (q.dstride == 1) hipLaunchKernelGGL((dwpw_lat_kernel<CT, 1>), dim3((unsigned)nblk), dim3(256), 0, s, q);
-    else hipLaunchKernelGGL((dwpw_lat_kernel<CT, 2>), dim3((unsigned)nblk), dim3(256), 0, s, q);
+    const int lds = 2 * 4096 + (q.g.Cin >> 5) * DWL_SLICE;
+    if (q.dstride == 1) hipLaunchKernelGGL((dwpw_lat_kernel<CT, 1>), dim3((unsigned)nblk), dim3(256), lds, s, q);
+    else hipLaunchKernelGGL((dwpw_lat_kernel<CT, 2>), dim3((unsigned)nblk), dim3(256), lds, s, q);
     return hipGetLastError();
 }
 

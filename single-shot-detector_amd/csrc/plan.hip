@@ -293,22 +293,22 @@ static DwPwLArgs dwpw_lat_args(int ct, const DwW &d, const ConvW &cw, const floa
     L.out_rstride = cw.CoutP; L.out_bstride = (long long)OH * OW * cw.CoutP;
     L.dP = ssd_udiv_make((unsigned)(OH * OW)); L.dOW = ssd_udiv_make((unsigned)OW);
     L.stride = 1; L.pad = 0;
-    q.dw_w = d.w; q.dw_mean = d.mean; q.dw_sf = d.sf; q.dw_beta = d.beta;
+    q.dw_pack = d.pack;
     q.H = H; q.W = W; q.dstride = stride; q.dpad = stride == 1 ? 1 : 0; q.dact = dact;
     return q;
 }
 
 int dwpw_lat_ct(const ssd_handle *h, const DwW &d, const ConvW &cw, int B, int H, int W, int stride)
 {
-    // Measured (profiles/r04_batch1_option_ab.log, r04_batch1_timeline_dwpw_lat.txt): bit-identical and SLOWER than the pair
-    // it replaces -- a 512 -> 512 layer at 40x56 takes 35 us as one launch against 7.5 + 19 as two (batch-1 forward 1.589 ->
-    // 1.664 ms).  Every thread issues 21 sixteen-byte loads per 64-channel slice (9 taps, 9 depthwise weights, 3 batch-norm
-    // vectors: 84 wave instructions per block and slice on the CU's one texture-address path, against 1 024 cycles of MFMA per
-    // wave), they are consumed one slice later, and at 204 VGPRs two blocks per CU leave 48 of 560 blocks for a second round.
-    // What the design would need is dwpw_stream.hip's: 2-D position tiles with the input patch and the depthwise weights
-    // staged once per block in LDS (LDS-DMA), i.e. a 9x smaller load count.  OFF unless asked for (option dwpw_lat >= 1).
-    const int opt = ssd_opt(h, OPT_DWPW_LAT, 0);
-    if (opt <= 0 || cw.taps != 1 || d.Cp != cw.CinP || !cw.mean || cw.bias || !cw.wlat || !d.w || !d.mean) return 0;
+    // Measured (profiles/r04_batch1_option_ab.log, r04_batch1_timeline_dwpw_lat*.txt), a 512 -> 512 layer at 40x56 against the
+    // 7.5 + 19 us of the pair it replaces: 35 us with the depthwise weights loaded per thread from global memory (21 sixteen-byte
+    // loads per thread and slice on the CU's one texture-address path, two rounds of blocks at 204 VGPRs), 26.5 with the layer's
+    // depthwise table in LDS (three blocks per CU), 26 with the iteration interleaved (sched_group_barrier) -- the batch-1 forward
+    // 1.588 -> 1.570 ms, nine launches fewer.  What still separates it from ~18 us: 36 + 32 wave loads per block and slice
+    // (taps + 1x1 weights) against 1 024 MFMA cycles per wave -- dwpw_stream.hip's LDS-DMA patch staging would cut the 36 to 9.
+    // Auto: batch 1, the launches make_conv_op would give the four-wave latency form; option dwpw_lat = 0 keeps the pairs.
+    const int opt = ssd_opt(h, OPT_DWPW_LAT, -1);
+    if (opt == 0 || cw.taps != 1 || d.Cp != cw.CinP || !cw.mean || cw.bias || !cw.wlat || !d.pack) return 0;
     if ((stride != 1 && stride != 2) || (stride == 2 && ((H | W) & 1))) return 0;
     const long long M = (long long)B * (H / stride) * (W / stride);
     int ct = 0;
@@ -316,6 +316,7 @@ int dwpw_lat_ct(const ssd_handle *h, const DwW &d, const ConvW &cw, int B, int H
     else {
         // auto: the launches of one or two 64x64 tiles per CU that make_conv_op gives the four-wave latency form (batch 1-2)
         const long long b64 = ((M + 63) / 64) * ((cw.CoutPad + 63) / 64);
+        if (opt < 0 && (B != 1 || b64 > 640 || cw.CinP < 256)) return 0;     // (batch 2: 2.951 ms with the pairs, 2.978 fused)
         ct = cw.CoutPad % 128 == 0 ? 2 : 1;
         const long long waves2 = ((M + 15) / 16) * (cw.CoutPad / 32);
         if (ct == 2 && waves2 < 2048) ct = cw.CoutPad % 128 == 0 && waves2 >= 1024 ? 2 : 1;

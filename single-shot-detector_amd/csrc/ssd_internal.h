@@ -155,8 +155,7 @@ hipError_t launch_dwpw_stream(int stride, const DwPwSArgs &a, hipStream_t s);
 struct DwPwLArgs {
     IgemmArgs g;                           // the pointwise product: in = the DEPTHWISE input [B,H,W,K], wt_lat, batch norm, act, one
                                            // dense level (M = B*OH*OW rows of the depthwise output), Cin = K, n_tiles_n = CoutPad / (64 ct)
-    const float *dw_w;                     // [9][K] depthwise weights, physical channel order
-    const float *dw_mean, *dw_sf, *dw_beta;// [K] depthwise batch norm
+    const float *dw_pack;                  // [K/32][12][32]: per 32-channel slice 9 taps, mean, sf, beta of the depthwise layer (DwW::pack)
     int H, W;                              // depthwise input size
     int dstride, dpad, dact;               // depthwise stride (1 | 2), pad_beg (TF 'SAME': 1 | 0), activation
 };
