@@ -12,7 +12,7 @@ ssd_amd._lib.use_diag()        # libssd_hip_diag.so: the -DSSD_DIAG build (inclu
 L = ssd_amd.lib()
 TILES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "128x256", 4: "256x128", 5: "64x64", 6: "128x96",
          20: "lat 1x1", 21: "lat 1x2", 22: "lat 2x1", 23: "lat 2x2", 24: "lat w2 1x1", 25: "lat w4 1x1", 26: "lat w4 2x1",
-         27: "lat w4 1x2", 28: "lat il", 29: "lat il D8", 30: "lat il D16", 31: "lat il nm", 32: "lat il D8 nm", 7: "64x64 deep", -1: "auto"}
+         27: "lat w4 1x2", 28: "lat il", 29: "lat il D8", 30: "lat il D16", 31: "lat il nm", 32: "lat il D8 nm", 33: "abl no lds", 34: "abl no lds,x", 35: "abl no lds,x,w", 36: "abl mfma only", 7: "64x64 deep", -1: "auto"}
 
 
 def run(name, H, W, Cin, Cout, k, stride, tiles, pyramid=0, reps=10):
@@ -27,7 +27,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "lat1":      # the one-wave latency form
     for rnd in range(2):
         for shape in (("fpn p6 3x3 s2 1024->256 20x28", 20, 28, 1024, 256, 3, 2), ("fpn p7 3x3 s2 256->256 10x14", 10, 14, 256, 256, 3, 2),
                       ("lateral5 1x1 1024->256 20x28", 20, 28, 1024, 256, 1, 1)):
-            run(*shape, [20, 28, 29, 30, 31, 32])
+            run(*shape, [20, 30, 33, 34, 35, 36])
     sys.exit(0)
 for rnd in range(2):
     run("tower 3x3 256->256 5 levels", 80, 112, 256, 256, 3, 1, [0, 1, 5], pyramid=1)

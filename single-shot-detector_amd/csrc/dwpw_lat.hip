@@ -38,6 +38,8 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 3 : 1)) void dwpw_lat_kernel(const 
     // must not share banks (1 536 B = 6 x 256 B would put them on the same 32)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *const tab = lds + 2 * 4096;
+    typedef __attribute__((address_space(3))) void *lds_as_t;
+    const int lds0 = (int)(size_t)(lds_as_t)lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -126,9 +128,10 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 3 : 1)) void dwpw_lat_kernel(const 
             if (dact == 2) y = y < 6.0f ? y : 6.0f;
             v[i] = y;
         }
-        unsigned char *base = lds + stage * 4096;
-        *(v2f *)(base + wlo) = v2f{v[0], v[2]};
-        *(v2f *)(base + whi) = v2f{v[1], v[3]};
+        // (ds_write2_b32 takes the two dwords from the registers where they are: igemm_lat.hip lstore; the explicit wait because the
+        //  barrier behind the iteration must find these writes complete and the compiler does not count them)
+        asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(lds0 + stage * 4096 + wlo), "v"(v[0]), "v"(v[2]) : "memory");
+        asm volatile("ds_write2_b32 %0, %1, %2 offset1:1\n\ts_waitcnt lgkmcnt(0)" ::"v"(lds0 + stage * 4096 + whi), "v"(v[1]), "v"(v[3]) : "memory");
     };
     v4f wr[2][2][CT][2];            // [set][K-step of the slice][channel tile][half]
     auto issue_w = [&](auto set_tag, int it) __attribute__((always_inline)) {

@@ -169,15 +169,25 @@ __global__ __launch_bounds__(64 * WB) void igemm_lat_kernel(const IgemmArgs a)
             }
         }
     };
+    // ds_write2_b32 takes its two dwords from two registers WHERE THEY ARE (elements 0, 2 / 1, 3 of the loaded chunk); the
+    // 64-bit store the compiler makes of any C form needs them copied side by side first -- two v_mov per store, and every
+    // vector instruction is added to the exact-fp32 MFMA's time on its SIMD (alone on the chip fpn p6 53 -> 41 us,
+    // profiles/r04_lat_one_wave.log).  LDS operations of one wave execute in order; an operation the compiler does not
+    // track only makes its counted waits a little longer.
+    typedef __attribute__((address_space(3))) void *lds_as_t;
+    const int lds0 = (int)(size_t)(lds_as_t)lds;                 // the image's byte address in LDS
     auto lstore = [&](int stage, auto set_tag) __attribute__((always_inline)) {
         constexpr int S = decltype(set_tag)::value;
-        unsigned char *base = lds + stage * (PT * 2048);
+        const int base = lds0 + stage * (PT * 2048);
 #pragma unroll
         for (int u = 0; u < NX; ++u)
             if (xact[u]) {
-                *(v2f *)(base + woff_lo[u]) = v2f{xr[S][u][0], xr[S][u][2]};
-                *(v2f *)(base + woff_hi[u]) = v2f{xr[S][u][1], xr[S][u][3]};
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(base + woff_lo[u]), "v"(xr[S][u][0]), "v"(xr[S][u][2]) : "memory");
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(base + woff_hi[u]), "v"(xr[S][u][1]), "v"(xr[S][u][3]) : "memory");
             }
+        // several waves share the image: the barrier behind this must find the writes complete, and the compiler's wait in front
+        // of it does not count operations it did not emit
+        if constexpr (WB > 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     v4f xf[2][PT][2];                // fragments by LDS stage
     auto lread = [&](auto stage_tag) __attribute__((always_inline)) {
@@ -273,21 +283,30 @@ __global__ __launch_bounds__(64 * WB) void igemm_lat_kernel(const IgemmArgs a)
             auto M = [&](int hf, int e) __attribute__((always_inline)) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[S][0][hf][e], xf[S & 1][0][hf][e], acc[0][0], 0, 0, 0);
             };
+            // (IL >= 2: timing ablations of the diagnostics build, results wrong -- 2 without the LDS round trip, 3 also without
+            //  the position loads, 4 also without the weight loads, 5 also without the load stream's bookkeeping)
             SSD_SB; M(0, 0); SSD_SB;
-            *(v2f *)(base + woff_lo[0]) = v2f{xr[N][0][0], xr[N][0][2]};
-            *(v2f *)(base + woff_hi[0]) = v2f{xr[N][0][1], xr[N][0][3]};
+            if constexpr (IL < 2) {
+                // (ds_write2_b32: see lstore)
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(lds0 + STN * (PT * 2048) + woff_lo[0]), "v"(xr[N][0][0]), "v"(xr[N][0][2]) : "memory");
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(lds0 + STN * (PT * 2048) + woff_hi[0]), "v"(xr[N][0][1]), "v"(xr[N][0][3]) : "memory");
+            }
             SSD_SB; M(0, 1); SSD_SB;
-            *(v2f *)(base + woff_lo[1]) = v2f{xr[N][1][0], xr[N][1][2]};
-            *(v2f *)(base + woff_hi[1]) = v2f{xr[N][1][1], xr[N][1][3]};
+            if constexpr (IL < 2) {
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(lds0 + STN * (PT * 2048) + woff_lo[1]), "v"(xr[N][1][0]), "v"(xr[N][1][2]) : "memory");
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(lds0 + STN * (PT * 2048) + woff_hi[1]), "v"(xr[N][1][1]), "v"(xr[N][1][3]) : "memory");
+            }
             SSD_SB; M(0, 2); SSD_SB;
-            xf[STN][0][0] = *(const v4f *)(base + roff[0]);
-            xf[STN][0][1] = *(const v4f *)(base + roff[1]);
+            if constexpr (IL < 2) {
+                xf[STN][0][0] = *(const v4f *)(base + roff[0]);
+                xf[STN][0][1] = *(const v4f *)(base + roff[1]);
+            }
             SSD_SB; M(0, 3); SSD_SB;
-            issue_w(std::integral_constant<int, T>{});
+            if constexpr (IL < 4) issue_w(std::integral_constant<int, T>{});
             SSD_SB; M(1, 0); SSD_SB;
-            issue_x(std::integral_constant<int, T>{});
+            if constexpr (IL < 3) issue_x(std::integral_constant<int, T>{});
             SSD_SB; M(1, 1); SSD_SB;
-            advance();
+            if constexpr (IL < 5) advance();
             SSD_SB; M(1, 2); SSD_SB; M(1, 3); SSD_SB;
         };
 #undef SSD_SB
@@ -369,6 +388,12 @@ hipError_t launch_igemm_lat(int tile, const IgemmArgs &a, int total_tiles_m, hip
     case IGEMM_LAT_1x1_IL: case IGEMM_LAT_1x1_NM: return launch_l<1, 1, 4, 1, 1>(a, total_tiles_m, s);
     case IGEMM_LAT_1x1_D8: case IGEMM_LAT_1x1_D8_NM: return launch_l<1, 1, 8, 1, 1>(a, total_tiles_m, s);
     case IGEMM_LAT_1x1_D16: return launch_l<1, 1, 16, 1, 1>(a, total_tiles_m, s);
+#ifdef SSD_DIAG   // timing ablations of the interleaved K-step (results wrong): libssd_hip_diag.so only
+    case 33: return launch_l<1, 1, 16, 1, 2>(a, total_tiles_m, s);
+    case 34: return launch_l<1, 1, 16, 1, 3>(a, total_tiles_m, s);
+    case 35: return launch_l<1, 1, 16, 1, 4>(a, total_tiles_m, s);
+    case 36: return launch_l<1, 1, 16, 1, 5>(a, total_tiles_m, s);
+#endif
     case IGEMM_LAT_1x2: return launch_l<1, 2, 4>(a, total_tiles_m, s);
     case IGEMM_LAT_2x1: return launch_l<2, 1, 4>(a, total_tiles_m, s);
     case IGEMM_LAT_2x2: return launch_l<2, 2, 2>(a, total_tiles_m, s);

@@ -303,12 +303,13 @@ int dwpw_lat_ct(const ssd_handle *h, const DwW &d, const ConvW &cw, int B, int H
     // Measured (profiles/r04_batch1_option_ab.log, r04_batch1_timeline_dwpw_lat*.txt), a 512 -> 512 layer at 40x56 against the
     // 7.5 + 19 us of the pair it replaces: 35 us with the depthwise weights loaded per thread from global memory (21 sixteen-byte
     // loads per thread and slice on the CU's one texture-address path, two rounds of blocks at 204 VGPRs), 26.5 with the layer's
-    // depthwise table in LDS (three blocks per CU), 26 with the iteration interleaved (sched_group_barrier) -- the batch-1 forward
-    // 1.588 -> 1.570 ms, nine launches fewer.  What still separates it from ~18 us: 36 + 32 wave loads per block and slice
-    // (taps + 1x1 weights) against 1 024 MFMA cycles per wave -- dwpw_stream.hip's LDS-DMA patch staging would cut the 36 to 9.
-    // Auto: batch 1, the launches make_conv_op would give the four-wave latency form; option dwpw_lat = 0 keeps the pairs.
-    const int opt = ssd_opt(h, OPT_DWPW_LAT, -1);
-    if (opt == 0 || cw.taps != 1 || d.Cp != cw.CinP || !cw.mean || cw.bias || !cw.wlat || !d.pack) return 0;
+    // depthwise table in LDS (three blocks per CU), 26 with the iteration interleaved (sched_group_barrier): the pair's time,
+    // nine launches fewer, the batch-1 forward within +-5 us of the pairs (1.582 against 1.579 ms once the pairs' 1x1 kernel
+    // had lost its v_mov packing too).  What still separates it from ~18 us: 36 + 32 wave loads per block and slice (taps +
+    // 1x1 weights) against 1 024 MFMA cycles per wave -- dwpw_stream.hip's LDS-DMA patch staging would cut the 36 to 9.
+    // OFF unless asked for (option dwpw_lat >= 1); batch 2: 2.951 ms with the pairs, 2.978 fused.
+    const int opt = ssd_opt(h, OPT_DWPW_LAT, 0);
+    if (opt <= 0 || cw.taps != 1 || d.Cp != cw.CinP || !cw.mean || cw.bias || !cw.wlat || !d.pack) return 0;
     if ((stride != 1 && stride != 2) || (stride == 2 && ((H | W) & 1))) return 0;
     const long long M = (long long)B * (H / stride) * (W / stride);
     int ct = 0;
@@ -316,7 +317,6 @@ int dwpw_lat_ct(const ssd_handle *h, const DwW &d, const ConvW &cw, int B, int H
     else {
         // auto: the launches of one or two 64x64 tiles per CU that make_conv_op gives the four-wave latency form (batch 1-2)
         const long long b64 = ((M + 63) / 64) * ((cw.CoutPad + 63) / 64);
-        if (opt < 0 && (B != 1 || b64 > 640 || cw.CinP < 256)) return 0;     // (batch 2: 2.951 ms with the pairs, 2.978 fused)
         ct = cw.CoutPad % 128 == 0 ? 2 : 1;
         const long long waves2 = ((M + 15) / 16) * (cw.CoutPad / 32);
         if (ct == 2 && waves2 < 2048) ct = cw.CoutPad % 128 == 0 && waves2 >= 1024 ? 2 : 1;

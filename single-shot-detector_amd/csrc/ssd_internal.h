@@ -116,7 +116,11 @@ enum IgemmLatTile { IGEMM_LAT_1x1 = 20, IGEMM_LAT_1x2 = 21, IGEMM_LAT_2x1 = 22, 
                     // share of the staging work), 4 / 8 / 16 K-steps of operands in flight, and the tile order that keeps the
                     // position tiles of ONE channel tile on one XCD (its weights then pass through that L2 once)
                     IGEMM_LAT_1x1_IL = 28, IGEMM_LAT_1x1_D8 = 29, IGEMM_LAT_1x1_D16 = 30, IGEMM_LAT_1x1_NM = 31, IGEMM_LAT_1x1_D8_NM = 32 };
+#ifdef SSD_DIAG
+static inline bool igemm_is_lat(int tile) { return tile >= IGEMM_LAT_1x1 && tile <= 36; }      // 33 .. 36: ablations of the interleaved K-step
+#else
 static inline bool igemm_is_lat(int tile) { return tile >= IGEMM_LAT_1x1 && tile <= IGEMM_LAT_1x1_D8_NM; }
+#endif
 int igemm_lat_bm(int tile);
 int igemm_lat_bn(int tile);
 bool igemm_lat_n_major(int tile);

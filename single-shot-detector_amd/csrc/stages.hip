@@ -276,7 +276,7 @@ extern "C" int ssd_dw_pw(const float *in_dev, int32_t B, int32_t H, int32_t W, i
         for (int p : outmap) { b.mean.push_back(p < 0 ? 0.f : pw_mean[p]); b.sf.push_back(p < 0 ? 0.f : pw_sf[p]); b.beta.push_back(p < 0 ? 0.f : pw_beta[p]); }
         SSDCHK(upload_bn(pool, b, cw));
         // option dwpw_lat = 1 | 2 | 4 (process-wide): the latency-form kernel (dwpw_lat.hip) where it takes the shape
-        const int lopt = ssd_opt(nullptr, OPT_DWPW_LAT, -1);
+        const int lopt = ssd_opt(nullptr, OPT_DWPW_LAT, 0);
         const int lct = lopt > 0 ? dwpw_lat_ct(nullptr, d, cw, B, H, W, stride) : 0;
         if (lopt > 1 && lct != lopt)         // a pinned form must run or fail: the parity tests rely on it
             return ssd_fail(SSD_ERR_INVALID, "ssd_dw_pw: option dwpw_lat pins a block form that does not take this shape (K % 64 == 0, padded width % (64 ct) == 0)");
