@@ -29,6 +29,13 @@ if len(sys.argv) > 2 and sys.argv[2] == "lat1":      # the one-wave latency form
                       ("lateral5 1x1 1024->256 20x28", 20, 28, 1024, 256, 1, 1)):
             run(*shape, [20, 30, 33, 34, 35, 36])
     sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "pw":        # the backbone's 1x1 layers at a serving batch: 32x32x2 tiles against the four-wave latency form
+    for rnd in range(2):
+        for shape in (("pw 256->256 80x112", 80, 112, 256, 256, 1, 1), ("pw 256->512 40x56", 40, 56, 256, 512, 1, 1),
+                      ("pw 512->512 40x56", 40, 56, 512, 512, 1, 1), ("pw 512->1024 20x28", 20, 28, 512, 1024, 1, 1),
+                      ("pw 1024->1024 20x28", 20, 28, 1024, 1024, 1, 1)):
+            run(*shape, [0, 1, 5, 7, 25, 26, 27])
+    sys.exit(0)
 for rnd in range(2):
     run("tower 3x3 256->256 5 levels", 80, 112, 256, 256, 3, 1, [0, 1, 5], pyramid=1)
 run("fpn p3 3x3 256->256 80x112", 80, 112, 256, 256, 3, 1, [0])

@@ -492,9 +492,151 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         // depthwise -> 1x1 pairs of the units as one launch each (option fuse_dw = 0 keeps them apart)
         bool sn_fuse = SSD_FUSE_SHUFFLE_DEFAULT;
         if (ssd_opt(h, OPT_FUSE_DW, -1) >= 0) sn_fuse = ssd_opt(h, OPT_FUSE_DW, -1) != 0;
+        const int h4 = h2 / 2, w4 = w2 / 2;
+        // ---- Two half-batch chains on the plan's two streams, as MobileNet's backbone above: the backbone is ~45 short kernels
+        // far from any bound (fused units 0.07-0.21 of the HBM rate, 1x1 layers of 2-8 K-steps), one chain's load / store
+        // phases sit under the other's arithmetic; FPN and heads stay full-batch launches.  Each stage is ONE allocation
+        // [X' buffers of chain 0 | X' buffers of chain 1 | stage output S of the whole batch]: a chain's destination maps
+        // address its own X' region and its images' rows of S.  Option backbone_split = 1 keeps one chain.
+        bool chained = false;
+        {
+            int nhalf = B >= 4 ? 2 : 1;
+            { const int v = ssd_opt(h, OPT_BACKBONE_SPLIT, 0); if (v >= 1 && v <= 2 && v <= B) nhalf = v; }
+            bool ok = sn_fuse && nhalf == 2;
+            const int nb_of[2] = {B / 2, B - B / 2};
+            struct StageGeo { int ch, cw, oh, ow, D, Dp, Cc, n_units, ipw, idw; long long xbytes[2], xoff[2], soff, total; };
+            StageGeo geo[3];
+            {
+                int ch = h4, cw = w4, ipw = 0, idw = 0;
+                for (int st = 0; ok && st < 3; ++st) {
+                    StageGeo &g = geo[st];
+                    g.ch = ch; g.cw = cw; g.oh = ch / 2; g.ow = cw / 2; g.ipw = ipw; g.idw = idw; g.n_units = units[st];
+                    const ConvW &after = h->pw[ipw + 1], &after2 = h->pw[ipw + 2];
+                    g.Dp = after.CoutP; g.D = after.Cout_l; g.Cc = round_up(2 * g.D, 32);
+                    long long off = 0;
+                    for (int hf = 0; hf < 2; ++hf) {
+                        g.xbytes[hf] = (long long)nb_of[hf] * g.oh * g.ow * g.Dp * 4;
+                        g.xoff[hf] = off;
+                        off += g.xbytes[hf] * (g.n_units - 1);
+                    }
+                    g.soff = off;
+                    g.total = off + (long long)B * g.oh * g.ow * g.Cc * 4;
+                    ok = g.total < (1LL << 31) && (g.D & 1) == 0;
+                    for (int hf = 0; ok && hf < 2; ++hf) {
+                        ok = dwpws_eligible(h->dw[idw], after, nb_of[hf], ch, cw, 2) && dwpws_eligible(h->dw[idw + 1], after2, nb_of[hf], ch, cw, 2);
+                        for (int j = 2; ok && j <= g.n_units; ++j)
+                            ok = dwpws_eligible(h->dw[idw + j], h->pw[ipw + 3 + 2 * (j - 2) + 1], nb_of[hf], g.oh, g.ow, 1);
+                    }
+                    ipw += 3 + 2 * (g.n_units - 1); idw += 2 + (g.n_units - 1);
+                    ch = g.oh; cw = g.ow;
+                }
+            }
+            if (ok) {
+                chained = true;
+                float *stage[3];
+                for (int st = 0; st < 3; ++st) {
+                    SSDCHK(falloc(&stage[st], geo[st].total / 4));
+                    HIPCHK(hipMemset(stage[st], 0, (size_t)geo[st].total));       // pad channels are never written: they stay zero
+                }
+                const StageGeo &g2 = geo[2];
+                const ConvW &c5w = h->pw[g2.ipw + 3 + 2 * (g2.n_units - 1)];
+                SSDCHK(falloc(&C5, (long long)B * g2.oh * g2.ow * c5w.CoutP));
+                std::vector<Op> half_ops[2];
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int b0 = hf == 0 ? 0 : nb_of[0], nb = nb_of[hf];
+                    std::vector<Op> &ops = half_ops[hf];
+                    float *F, *MP;
+                    SSDCHK(falloc(&F, (long long)nb * h2 * w2 * fc));
+                    SSDCHK(falloc(&MP, (long long)nb * h4 * w4 * fc));
+                    {
+                        Op op;
+                        op.cls = 3;
+                        op.flops = 2.0 * 27 * (double)nb * h2 * w2 * 24;
+                        op.bytes = (double)nb * H * W * 3 + (double)nb * h2 * w2 * 24 * 4.0;
+                        ssd_handle *hh = h;
+                        const DwW f = h->first;
+                        const int act = h->firstAct;
+                        const size_t off = img_off + (size_t)b0 * srcH * srcW * 3;
+                        op.run = [=](hipStream_t s) {
+                            return launch_first_conv(hh->cur_images + off, nb, srcH, srcW, rnh, rnw, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s);
+                        };
+                        ops.push_back(op);
+                        Op mp;
+                        mp.cls = 5; mp.flops = 0;
+                        mp.bytes = ((double)nb * h2 * w2 + (double)nb * h4 * w4) * 24 * 4.0;
+                        mp.run = [=](hipStream_t s) { return launch_maxpool(F, nb, h2, w2, fc, MP, s); };
+                        ops.push_back(mp);
+                    }
+                    const float *cur = MP;
+                    for (int st = 0; st < 3; ++st) {
+                        const StageGeo &g = geo[st];
+                        const ConvW &before = h->pw[g.ipw], &after = h->pw[g.ipw + 1], &after2 = h->pw[g.ipw + 2];
+                        const DwW &d1 = h->dw[g.idw], &d2 = h->dw[g.idw + 1];
+                        const int D = g.D, Dp = g.Dp, n_units = g.n_units;
+                        const long long rows = (long long)nb * g.oh * g.ow;
+                        float *t1, *U;
+                        SSDCHK(falloc(&t1, (long long)nb * g.ch * g.cw * before.CoutP));
+                        SSDCHK(falloc(&U, rows * Dp));
+                        const int rs0 = Dp * 4, rs1 = g.Cc * 4;
+                        // the chain's rows of S start b0 images into the stage output
+                        const long long s_chain = g.soff + (long long)b0 * g.oh * g.ow * rs1;
+                        struct Src { int prod, col; };
+                        std::vector<Src> x(D), y(D);
+                        for (int d = 0; d < D; ++d) { x[d] = Src{0, d}; y[d] = Src{1, d}; }
+                        std::vector<std::vector<int>> omap(n_units + 1, std::vector<int>(Dp, -1));
+                        auto place = [&](const Src &v, long long off, int physcol, int sel) {
+                            omap[v.prod][ssd_phys_of_logical(v.col)] = (int)(off + (long long)physcol * 4) | sel;
+                        };
+                        for (int j = 2; j <= n_units; ++j) {
+                            std::vector<Src> z(2 * D);
+                            for (int d = 0; d < D; ++d) { z[2 * d] = x[d]; z[2 * d + 1] = y[d]; }
+                            for (int k = 0; k < D; ++k) place(z[k], g.xoff[hf] + (long long)(j - 2) * g.xbytes[hf], ssd_phys_of_logical(k), 0);
+                            for (int d = 0; d < D; ++d) { x[d] = Src{j, d}; y[d] = z[D + d]; }
+                        }
+                        for (int c = 0; c < 2 * D; ++c) place(c < D ? x[c] : y[c - D], s_chain, ssd_phys_of_logical(c), 1);
+                        std::vector<const int *> omap_dev(n_units + 1, nullptr);
+                        for (int p = 0; p <= n_units; ++p) {
+                            int *dv;
+                            SSDCHK(ap.upload(&dv, omap[p]));
+                            omap_dev[p] = dv;
+                        }
+                        float *sb = stage[st];
+                        ops.push_back(make_conv_op(h, before, cur, t1, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU,
+                                                   {dense_level(g.ch, g.cw, g.ch, g.cw, before.CoutP)}, true));
+                        ops.push_back(make_dwpws_op(d1, after, t1, nb, g.ch, g.cw, 2, SSD_ACT_NONE, SSD_ACT_RELU, sb, omap_dev[1], g.total, rs0, rs1));
+                        ops.push_back(make_dwpws_op(d2, after2, cur, nb, g.ch, g.cw, 2, SSD_ACT_NONE, SSD_ACT_RELU, sb, omap_dev[0], g.total, rs0, rs1));
+                        for (int j = 2; j <= n_units; ++j) {
+                            const ConvW &b2 = h->pw[g.ipw + 3 + 2 * (j - 2)], &a2 = h->pw[g.ipw + 3 + 2 * (j - 2) + 1];
+                            const DwW &dd = h->dw[g.idw + j];
+                            const float *xin = sb + (g.xoff[hf] + (long long)(j - 2) * g.xbytes[hf]) / 4;
+                            ops.push_back(make_conv_op(h, b2, xin, U, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU, {dense_level(g.oh, g.ow, g.oh, g.ow, Dp)}, true));
+                            ops.push_back(make_dwpws_op(dd, a2, U, nb, g.oh, g.ow, 1, SSD_ACT_NONE, SSD_ACT_RELU, sb, omap_dev[j], g.total, rs0, rs1));
+                        }
+                        cur = sb + s_chain / 4;
+                    }
+                    ops.push_back(make_conv_op(h, c5w, cur, C5 + (long long)b0 * g2.oh * g2.ow * c5w.CoutP, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU,
+                                               {dense_level(g2.oh, g2.ow, g2.oh, g2.ow, c5w.CoutP)}, true, 0, X16, 0, FL));
+                }
+                for (int st = 0; st < 2; ++st) {
+                    float *S = stage[st] + geo[st].soff / 4;
+                    if (st == 0) C3 = S; else C4 = S;
+                    pl.retained[st == 0 ? "c3" : "c4"] = Retained{S, B, geo[st].oh, geo[st].ow, 2 * geo[st].D, geo[st].Cc, true};
+                }
+                pl.retained["c5"] = Retained{C5, B, g2.oh, g2.ow, c5w.Cout_l, c5w.CoutP, true, X16};
+                for (size_t i = 0; i < std::max(half_ops[0].size(), half_ops[1].size()); ++i)
+                    for (int hf = 0; hf < 2; ++hf)
+                        if (i < half_ops[hf].size()) {
+                            Op op = half_ops[hf][i];
+                            op.stream = hf;
+                            pl.ops.push_back(op);
+                            id_bb_last[hf] = (int)pl.ops.size() - 1;
+                            if (hf == 1) pl.last_aux = id_bb_last[hf];
+                        }
+            }
+        }
+        if (!chained) {
         float *F, *MP;
         SSDCHK(falloc(&F, (long long)B * h2 * w2 * fc));
-        const int h4 = h2 / 2, w4 = w2 / 2;
         SSDCHK(falloc(&MP, (long long)B * h4 * w4 * fc));
         {
             Op op;
@@ -645,6 +787,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         pl.ops.push_back(make_conv_op(h, c5, cur, C5, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
                                       {dense_level(ch, cwid, ch, cwid, c5.CoutP)}, true, 0, X16, 0, FL));
         pl.retained["c5"] = Retained{C5, B, ch, cwid, c5.Cout_l, c5.CoutP, true, X16};
+        }
     }
 
     // ---------------- FPN (feature_extractor.py:40-76)
