@@ -164,14 +164,18 @@ def roofline_block(prof, precision, steps, traffic_key=None):
     flop = c["flops"] / n
     ach = flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     peak = PEAK_FP32_MFMA_TFLOPS if precision == "f32" else PEAK_F16X3_TFLOPS
-    traffic, src = None, None
+    traffic, src, t_alg, t_kernel = None, None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")    # scripts/collect_profiles.sh: separate --pmc passes
     if os.path.exists(tpath):
         t = json.load(open(tpath)).get(traffic_key or precision, {})
+        t_alg, t_kernel = t.get("algorithmic_bytes_per_launch"), t.get("kernel")
         traffic, src = t.get("hbm_bytes_per_launch"), "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
             "this command, FETCH x2 per the gfx950 correction; a committed measurement, not re-measured in this run): " + str(t.get("source", ""))
     return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-            "traffic": traffic, "traffic_source": src, "kernel": KERNEL_NAMES[name],
+            "traffic": traffic, "traffic_source": src,
+            # `traffic` is the counter bytes of ONE kernel instance (the class's dominant one); its own algorithmic bytes beside it
+            # (algorithmic_gbyte_per_launch below is the average over ALL launches of the class: not the same denominator)
+            "traffic_kernel": t_kernel, "traffic_algorithmic_bytes": t_alg, "kernel": KERNEL_NAMES[name],
             "peak_note": ("dense exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32)" if precision == "f32"
                           else "dense F16 MFMA peak 2516.8 TFLOP/s / 3 MFMA terms per product"),
             "launches_per_step": c["launches"] / steps, "avg_launch_ms": avg_ms,

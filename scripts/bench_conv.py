@@ -29,6 +29,13 @@ if len(sys.argv) > 2 and sys.argv[2] == "lat1":      # the one-wave latency form
                       ("lateral5 1x1 1024->256 20x28", 20, 28, 1024, 256, 1, 1)):
             run(*shape, [20, 30, 33, 34, 35, 36])
     sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "sn":        # ShuffleNet's conv1x1_before layers (K = 58 / 116 / 232: 2 / 4 / 8 K-steps) at the serving batch
+    for rnd in range(2):
+        for shape in (("sn 58->58 80x80", 80, 80, 58, 58, 1, 1), ("sn 116->116 40x40", 40, 40, 116, 116, 1, 1),
+                      ("sn 232->232 20x20", 20, 20, 232, 232, 1, 1), ("sn 116->116 80x80", 80, 80, 116, 116, 1, 1),
+                      ("sn 232->232 40x40", 40, 40, 232, 232, 1, 1)):
+            run(*shape, [-1, 0, 1, 5, 25, 26, 27])
+    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "pw":        # the backbone's 1x1 layers at a serving batch: 32x32x2 tiles against the four-wave latency form
     for rnd in range(2):
         for shape in (("pw 256->256 80x112", 80, 112, 256, 256, 1, 1), ("pw 256->512 40x56", 40, 56, 256, 512, 1, 1),

@@ -77,7 +77,11 @@ if stats:
                          "%.1f" % (union_ms(v) * 1e6 / max(len(v), 1)) if v else ""])
 
 nfwd = max(1, sum(len(v) for k, v in iv.items() if "post_pack" in k))      # one per forward (the backbone may run as two chains)
-c3 = [x for k, v in iv.items() if ("igemm_kernel" in k and ", 9, 0" in k) or "igemm16_kernel<9" in k for x in v]
+import re
+# every instance whose TAPS template argument is 9: igemm_kernel<WM, WN, wm, wn, 9, ...> (all tile forms, the deep-prefetch
+# 64x64 instance included), igemm_lat_kernel<PT, CT, 9, ...> (fpn p6 / p7 at batch 1-2), igemm16_kernel<9, ...>
+is3x3 = lambda k: bool(re.search(r"igemm_kernel<\d+, \d+, \d+, \d+, 9,", k) or re.search(r"igemm_lat_kernel<\d+, \d+, 9,", k) or "igemm16_kernel<9" in k)
+c3 = [x for k, v in iv.items() if is3x3(k) for x in v]
 class_line = ("all 3x3 igemm kernels (bench.py class conv3x3_mfma): %d launches in %d forwards, union %.3f ms per forward"
               " = %.4f ms per launch\n" % (len(c3), nfwd, union_ms(c3) / nfwd, union_ms(c3) / max(len(c3), 1)))
 with open(out + "/pmc_summary.txt", "w") as fo:

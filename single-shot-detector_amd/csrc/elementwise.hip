@@ -459,6 +459,48 @@ hipError_t launch_maxpool(const float *in, int B, int H, int W, int C, float *ou
 }
 
 // ---------------------------------------------------------------------------------------
+// The FPN's top-down merges as one elementwise launch (feature_extractor.py:64-69, nearest_neighbor_upsample :79-100):
+//     x4 = up2(x5) + lateral4(c4),   x3 = up2(x4) + lateral3(c3)          out[2i+a, 2j+b] = in[i, j]
+// on lateral convolutions that ran EARLY, without their upsampled operand (batch 1: they finish beside the backbone's last
+// layers, and what is left behind c5 is lateral5 and this kernel instead of a chain of three launches, plan.hip).  Each sum
+// is one fp32 addition, exactly what the lateral convolution's epilogue performs when it adds the operand itself.
+// One thread = 4 channels of one x3 position; the thread of the even (y, x) also writes its x4 value.
+__global__ __launch_bounds__(256) void fpn_merge_kernel(const float *__restrict__ x5, const float *__restrict__ l4, float *__restrict__ x4,
+                                                         float *__restrict__ x3, int B, int H3, int W3, int C)
+{
+    const int C4 = C >> 2, H4 = H3 >> 1, W4 = W3 >> 1, H5 = H4 >> 1, W5 = W4 >> 1;
+    const long long total = (long long)B * H3 * W3 * C4;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4) * 4;
+        long long q = idx / C4;
+        const int x = (int)(q % W3);
+        q /= W3;
+        const int y = (int)(q % H3), b = (int)(q / H3);
+        const long long o4 = (((long long)b * H4 + (y >> 1)) * W4 + (x >> 1)) * C + c;
+        const v4f a5 = *(const v4f *)(x5 + (((long long)b * H5 + (y >> 2)) * W5 + (x >> 2)) * C + c);
+        const v4f a4 = *(const v4f *)(l4 + o4);
+        v4f v4, v3 = *(const v4f *)(x3 + idx * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v4[e] = a5[e] + a4[e];
+            v3[e] = v4[e] + v3[e];
+        }
+        *(v4f *)(x3 + idx * 4) = v3;
+        if (!((y | x) & 1)) *(v4f *)(x4 + o4) = v4;
+    }
+}
+
+hipError_t launch_fpn_merge(const float *x5, const float *l4, float *x4, float *x3, int B, int H3, int W3, int C, hipStream_t s)
+{
+    if (C % 4 || (H3 & 3) || (W3 & 3) || B < 1) return hipErrorInvalidValue;
+    const long long total = (long long)B * H3 * W3 * (C / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(fpn_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x5, l4, x4, x3, B, H3, W3, C);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 __device__ __forceinline__ int phys_of_logical(int l) { const int r = l & 7; return (l & ~7) + ((r & 1) ? 4 + (r >> 1) : (r >> 1)); }
 __device__ __forceinline__ int logical_of_phys(int p) { const int r = p & 7; return (p & ~7) + (r < 4 ? 2 * r : 2 * (r - 4) + 1); }
 

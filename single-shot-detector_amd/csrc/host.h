@@ -54,6 +54,8 @@ enum SsdOpt {
     OPT_FPN_P6_FIRST,       // 3 (default): fpn p6 -> p7 on the main stream, the laterals beside them | 0: p6 -> p7 on the third stream | 1 / 2: ... and the grouped launch waits for p6 / p7
     OPT_DWPW_LAT,           // 0 (default) | 1 | 2 | 4: depthwise + pointwise pairs the streaming kernel leaves apart as ONE launch of dwpw_lat.hip
                             // (measured = the pair's time, plan.hip); 1 = wherever it takes the shape, channel tiles per wave chosen per layer; 2 / 4 pin them
+    OPT_FPN_EARLY_LAT,      // -1 auto (batch <= 2, one backbone chain, exact fp32) | 0 | 1: lateral3 / lateral4 early beside the backbone's last
+                            // layers, their top-down sums as one elementwise launch behind lateral5
     OPT_H2D_CHUNKS,         // 2 (default) | 1 .. 16: pieces of ssd_forward_host's staging copy + upload (piece k uploads under the host copy of k + 1)
     OPT_FPN_P7_GROUP,       // 1 (default) | 0: fpn p7 as a fourth level of the grouped p3 + p4 + p5 launch (batch <= 2, exact fp32)
     OPT_EVENT_FENCE,        // 0 (default): the library's ordering events carry no system-scope fence (hipEventDisableSystemFence: they order

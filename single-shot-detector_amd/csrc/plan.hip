@@ -382,6 +382,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     float *C3 = nullptr, *C4 = nullptr, *C5 = nullptr;
     const int h2 = H / 2, w2 = W / 2;
     int id_bb_last[4] = {-1, -1, -1, -1};     // last backbone op of each chain (MobileNet split), -1: no such chain
+    int id_c4 = -1;                            // the op that completes c4 when the backbone is ONE chain (then c3 precedes it on the same stream)
     if (h->cfg.backbone == SSD_BACKBONE_MOBILENET) {
         // The backbone is a chain of ~30 short, latency-bound kernels (two blocks per CU each waiting for one
         // round of loads).  From 4 images on it runs as two half-batch chains on the plan's two streams, so that
@@ -472,6 +473,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 else   // c5 feeds only the FPN (lateral5, p6): in f16x3 mode it is written in split-fp16 rows
                     ops.push_back(make_conv_op(h, cw, dwo, pwo, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU6,
                                                {dense_level(ch, cwid, ch, cwid, cw.CoutP)}, true, pw16, (i == 12 && X16) ? 1 : 0, 0, h->flags_dev));
+                if (i == 10 && nhalf == 1) id_c4 = (int)ops.size() - 1;          // Conv2d_11_pointwise = c4 (one chain: pl.ops keeps this index)
                 cur = pwo;
             }
         }
@@ -808,6 +810,8 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     // tails (measured: paired tower layers run at 0.91 of the MFMA peak, a lone one at 0.85).
     auto push = [&](Op op, int stream, std::vector<int> deps = {}) {
         op.stream = stream;
+        std::sort(deps.begin(), deps.end());                     // (one wait per producer: with p7 inside the grouped launch the towers
+        deps.erase(std::unique(deps.begin(), deps.end()), deps.end());      //  name that launch twice)
         op.deps = deps;
         pl.ops.push_back(op);
         if (stream == 1) pl.last_aux = (int)pl.ops.size() - 1;
@@ -838,6 +842,19 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     // one kernel boundary leave the critical path c5 -> p6 -> p7 -> grouped -> towers.  Same k-ordered chain, same bits.
     const bool p7grouped = swap67 && !p7side && ssd_opt(h, OPT_FPN_P7_GROUP, 1) != 0;
     const int s_lat = swap67 ? 2 : 0;
+    // Batch <= 2 (swap67), one backbone chain: lateral4(c4) and lateral3(c3) -- WITHOUT their upsampled operands -- on the third
+    // stream as soon as c4 exists (c3 precedes it on the caller's stream), beside the backbone's last four layers; behind c5
+    // the third stream then runs lateral5 and ONE elementwise launch for both top-down sums (fpn_merge_kernel) instead of a
+    // chain of three convolutions: since p6 lost its v_mov packing (62 -> 44 us) that chain (55 us beside p6) was the longer
+    // side of the fork in front of the grouped launch.  Same additions, same bits.  Option fpn_early_lat = 0 / 1 pins it.
+    bool early = swap67 && !X16 && id_c4 >= 0;
+    { const int pin = ssd_opt(h, OPT_FPN_EARLY_LAT, -1); if (pin >= 0) early = early && pin != 0; }
+    float *L4T = nullptr;
+    if (early) {
+        SSDCHK(falloc(&L4T, (long long)B * py.h[1] * py.w[1] * 256));
+        push(make_conv_op(h, h->lat[0], C3, X3, nullptr, nullptr, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true), s_lat, {id_c4});
+        push(make_conv_op(h, h->lat[1], C4, L4T, nullptr, nullptr, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true), s_lat);
+    }
     std::vector<int> l5_deps;
     for (int c = 1; c < 4; ++c) if (id_bb_last[c] >= 0) l5_deps.push_back(id_bb_last[c]);
     if (swap67) l5_deps.push_back(id_c5);
@@ -875,14 +892,26 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     // output follow the mode
     int LF = X16 && h->lat[1].tile == IGEMM_128x128 && h->lat[0].tile == IGEMM_128x128 ? 2 : 0;
     if (!ssd_opt(h, OPT_LATERAL_SPLIT, 1)) LF = 0;       // A/B runs: 0 keeps them on the exact MFMA
-    const int id_l4 = push(make_conv_op(h, h->lat[1], C4, X4, nullptr, X5, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true, LF, X16, X16, FL), s_lat);
+    int id_l4, id_merge = -1;
+    if (early) {
+        Op m;
+        m.cls = 5; m.flops = 0;
+        m.bytes = ((double)B * py.h[0] * py.w[0] * 2 + (double)B * py.h[1] * py.w[1] * 2 + (double)B * py.h[2] * py.w[2]) * 256 * 4.0;
+        const int mh = py.h[0], mw = py.w[0];
+        float *l4t = L4T;
+        m.run = [=](hipStream_t s) { return launch_fpn_merge(X5, l4t, X4, X3, B, mh, mw, 256, s); };
+        id_l4 = id_merge = push(m, s_lat);
+    } else {
+        id_l4 = push(make_conv_op(h, h->lat[1], C4, X4, nullptr, X5, B, 1, 0, SSD_ACT_NONE, {lvl(1, 256)}, true, LF, X16, X16, FL), s_lat);
+    }
     int id_p4, id_p3;
     if (!grouped) {
         LevelDesc d = lvl(1, 256);
         d.out_off = py.off[1];
         id_p4 = push(make_conv_op(h, h->pconv[1], X4, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 1, {id_l4});
     }
-    const int id_l3 = push(make_conv_op(h, h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true, LF, X16, X16, FL), s_lat);
+    const int id_l3 = early ? id_merge
+                            : push(make_conv_op(h, h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true, LF, X16, X16, FL), s_lat);
     if (p7side) {
         LevelDesc d7 = dense_level(py.h[3], py.w[3], py.h[4], py.w[4], 256);
         d7.out_off = py.off[4];

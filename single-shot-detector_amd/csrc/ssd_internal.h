@@ -176,6 +176,8 @@ hipError_t launch_depthwise(const float *in, int B, int H, int W, int C, const f
                             const float *beta, int act, float *out, hipStream_t s, int out16 = 0 /* 1: S16 rows */,
                             int *flags = nullptr /* out16: bit 0 set when a value left the fp16 range */);
 hipError_t launch_maxpool(const float *in, int B, int H, int W, int C, float *out, hipStream_t s);
+// x4 = up2(x5) + l4, x3 = up2(x4) + x3 (in place); x5 [B,H3/4,W3/4,C], l4 / x4 [B,H3/2,W3/2,C], x3 [B,H3,W3,C] (elementwise.hip)
+hipError_t launch_fpn_merge(const float *x5, const float *l4, float *x4, float *x3, int B, int H3, int W3, int C, hipStream_t s);
 // out[r][j] = (tab[2j]==0 ? x : y)[r][tab[2j+1]] (0 if tab[2j] < 0); tab is device memory
 hipError_t launch_gather_channels(const float *x, int xs, const float *y, int ys, long long rows, const int *tab,
                                   int Cout, float *out, hipStream_t s);
