@@ -103,9 +103,11 @@ int ssd_get_precision(ssd_handle *h);
  * the only one it reads).  `h` == NULL sets the process-wide value, which the handle-less stage entry points below use and
  * which a handle falls back to for an option it has not been given itself; with a handle the call synchronises and drops
  * the cached layer plan.  Keys (value; default):
- *   "igemm_tile"      0 auto | 128 | 64 pin the tile of the 128x128-class launches | 20..27 pin a tile of the latency form
+ *   "igemm_tile"      0 auto | 128 | 64 pin the tile of the 128x128-class launches | 20..32 pin a tile of the latency form
  *                     wherever that form applies: 20..23 one wave per block (1x1, 1x2, 2x1, 2x2 sixteen-wide units), 24..27
- *                     two / four waves per block sharing the positions through LDS                       (0)
+ *                     two / four waves per block sharing the positions through LDS, 28..32 the one-accumulator wave with its
+ *                     K-step interleaved (4 / 8 / 16 K-steps of operands in flight; 31, 32: channel-tile-major order) (0)
+ *   "lat_one"         30 | 20 | 28..32: the one-wave tile the plan gives its tiny launches (fpn p6, lateral5)  (30)
  *   "igemm_lat"       1 | 0: small exact-fp32 launches on the latency form (v_mfma_f32_16x16x4_f32)      (1)
  *   "igemm_deep64"    -1 auto | 0 | 1: 64x64 tiles with operand loads three K-steps ahead                (-1)
  *   "streams"         0 auto | 1: every kernel of a forward on one stream, in plan order | 2: the internal streams at the
@@ -114,8 +116,12 @@ int ssd_get_precision(ssd_handle *h);
  *   "tower_group"     0 | 1: layer i of the box and the class tower as one launch over 2 x 5 levels      (0)
  *   "head_serial"     -1 auto | 0 | 1: the box head behind the class logits instead of beside them       (-1)
  *   "side_priority"   0 | 1 | 2: the streams of fpn p6 / p7 at the lowest / highest dispatch priority    (0)
- *   "fpn_p6_first"    3: fpn p6 -> p7 on the caller's stream, the lateral chain beside them (batch <= 2) | 0: p6 -> p7 on the
- *                     third stream | 1 | 2: ... and the grouped fpn launch waits for p6 / for p7         (3)
+ *   "fpn_p6_first"    3: fpn p6 (-> p7) on the caller's stream, the lateral chain beside them (batch <= 2) | 0: p6 -> p7 on the
+ *                     third stream | 1 | 2: ... and the grouped fpn launch waits for p6 / for p7 | 4: p7 beside the grouped launch (3)
+ *   "fpn_p7_group"    1 | 0: fpn p7 as a fourth level of the grouped p3 + p4 + p5 launch (batch <= 2, F32)   (1)
+ *   "fpn_early_lat"   -1 auto | 0 | 1: lateral3 / lateral4 early, their top-down sums as one elementwise launch (batch <= 2) (-1)
+ *   "dwpw_lat"        0 | 1 | 2 | 4: MobileNet Conv2d_5..13 depthwise + pointwise pairs as one latency-form launch (dwpw_lat.hip) (0)
+ *   "event_fence"     0 | 1: the library's stream-ordering events with the default flags (system-scope fence per record) (0)
  *   "igemm16"         -1 auto | 0 | 1: F16X3 launches on the 256x256-tile kernel                         (-1)
  *   "igemm_96"        1 | 0: 128x96 tiles for widths 96 divides and 128 does not (read by ssd_finalize)  (1)
  *   "lateral_split"   1 | 0: F16X3 laterals split fp32 rows while staging them                           (1)

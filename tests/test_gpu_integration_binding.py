@@ -53,6 +53,19 @@ def test_documented_ctypes_binding(cuda, ssd):
     n = int(num.cpu()[0])
     keep = scores[0, :n].cpu().numpy() > score_threshold                      # inference/detector.py:54-58
     got = boxes[0, :n].cpu().numpy()[keep], labels[0, :n].cpu().numpy()[keep], scores[0, :n].cpu().numpy()[keep]
+    # ... and the host form (second half): a host array in, one 48 004-byte record in pinned host memory out
+    lib.ssd_record_words.restype = ctypes.c_int32
+    lib.ssd_record_words.argtypes = [ctypes.c_void_p]
+    RW = lib.ssd_record_words(h)
+    assert RW == 6 * T + 1
+    rec = torch.empty((1, RW), dtype=torch.int32).pin_memory()
+    check(lib.ssd_forward_host(h, ctypes.c_void_p(image.ctypes.data), ctypes.c_int32(1), ctypes.c_int32(image.shape[0]), ctypes.c_int32(image.shape[1]),
+                               p(rec), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.current_stream().synchronize()
+    r = rec.numpy()[0]
+    assert int(r[6 * T]) == n
+    assert np.array_equal(r[:4 * T].view(np.float32).reshape(T, 4), boxes[0].cpu().numpy())
+    assert np.array_equal(r[4 * T:5 * T].view(np.float32), scores[0].cpu().numpy()) and np.array_equal(r[5 * T:6 * T], labels[0].cpu().numpy())
     # errors come back as codes + text, nothing throws across the ABI
     assert lib.ssd_forward(h, None, 1, 1, 1, None, None, None, None, None) != 0 and b"null" in lib.ssd_last_error()
     lib.ssd_destroy.argtypes = [ctypes.c_void_p]
