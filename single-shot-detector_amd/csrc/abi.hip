@@ -323,7 +323,10 @@ extern "C" int ssd_forward_host(ssd_handle *h, const uint8_t *images_host, int32
     hipStream_t s = (hipStream_t)stream;
     const size_t bytes = (size_t)B * H * W * 3;
     // the previous call's upload may still be reading the staging buffer when the caller did not wait for it
-    if (h->stage_busy) { HIPCHK(hipStreamSynchronize(h->stage_stream)); h->stage_busy = false; }
+    if (h->stage_busy) {
+        if (hipStreamSynchronize(h->stage_stream) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipDeviceSynchronize()); }   // (the caller destroyed that stream)
+        h->stage_busy = false;
+    }
     if (bytes > h->stage_bytes) {
         HIPCHK(hipDeviceSynchronize());
         if (h->stage_pin) { (void)hipHostFree(h->stage_pin); h->stage_pin = nullptr; }

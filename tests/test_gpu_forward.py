@@ -60,8 +60,9 @@ def test_golden_tiny(cuda, ssd):
     eng.close()
 
 
-@pytest.mark.parametrize("backbone,H,W,B", [("mobilenet", 128, 256, 9), ("shufflenet", 128, 128, 2)])
+@pytest.mark.parametrize("backbone,H,W,B", [("mobilenet", 128, 256, 9), ("shufflenet", 128, 128, 2), ("shufflenet", 128, 128, 5)])
 def test_forward_vs_oracle_small(cuda, ssd, oracle_graph, backbone, H, W, B):
+    # (ShuffleNet at 5 images: its backbone as two UNEVEN half-batch chains, 2 + 3 images, round 4)
     params = {"backbone": backbone, "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
               "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
     Wt = ssd.synthetic_weights(params, seed=11, logits_bias=-4.0)
@@ -78,6 +79,11 @@ def test_forward_vs_oracle_small(cuda, ssd, oracle_graph, backbone, H, W, B):
     out1 = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(img[:1].copy()).cuda())]
     for a, b in zip(out, out1):
         assert np.array_equal(a[:1], b)
+    if B >= 4:      # one backbone chain instead of two: the same bits
+        eng.set_option("backbone_split", 1)
+        out2 = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(img).cuda())]
+        for a, b in zip(out, out2):
+            assert np.array_equal(a, b)
     eng.close()
 
 
@@ -164,7 +170,11 @@ def test_small_batch_plan_variants_are_bit_identical(cuda, ssd, oracle_graph, H,
         for n in names:
             assert np.array_equal(base_t[n], keep[n].reshape(base_t[n].shape)), n
     variants = [{"igemm_lat": 0}, {"fpn_group": 0}, {"igemm_deep64": 0}, {"streams": 1}, {"head_serial": 1}, {"side_priority": 1},
-                {"side_priority": 2}, {"fpn_p6_first": 0}, {"fpn_p6_first": 1}, {"fpn_p6_first": 2}, {"tower_group": 1}, {"tower_group": 1, "streams": 1}, {"level_split": 2}, {"level_split": 1}, {"streams": 2}, {"igemm_tile": 20}, {"igemm_tile": 25}, {"igemm_lat": 0, "fpn_group": 0, "igemm_deep64": 0}]
+                {"side_priority": 2}, {"fpn_p6_first": 0}, {"fpn_p6_first": 1}, {"fpn_p6_first": 2}, {"tower_group": 1}, {"tower_group": 1, "streams": 1}, {"level_split": 2}, {"level_split": 1}, {"streams": 2}, {"igemm_tile": 20}, {"igemm_tile": 25}, {"igemm_lat": 0, "fpn_group": 0, "igemm_deep64": 0},
+                # round 4: p7 out of the grouped launch, the laterals in their chain, fenced events, the other one-wave forms, p7 beside
+                # the grouped launch, the depthwise + pointwise pairs of Conv2d_5 .. 13 as one latency-form launch
+                {"fpn_p7_group": 0}, {"fpn_early_lat": 0}, {"fpn_early_lat": 0, "fpn_p7_group": 0}, {"event_fence": 1}, {"lat_one": 20},
+                {"lat_one": 28}, {"lat_one": 32}, {"fpn_p6_first": 4}, {"dwpw_lat": 1}, {"dwpw_lat": 2}]
     for v in variants:
         for k, val in v.items():
             eng.set_option(k, val)
