@@ -140,7 +140,13 @@ def detect_sharded(engine, images_local, group=None, total=None, force=False):
         buf = _gather_buffers[key] = torch.zeros((world, per, engine.record_words), dtype=torch.int32, device=images_local.device)
     engine.forward(images_local, records=buf[rank, :n])
     inplace = dist.get_backend(group) == "nccl"
-    got = gather_records(buf[rank] if inplace else buf[rank].clone(), group, out=buf.view(world * per, -1))
+    try:
+        got = gather_records(buf[rank] if inplace else buf[rank].clone(), group, out=buf.view(world * per, -1))
+    except RuntimeError:
+        if not inplace:
+            raise
+        # a process-group build that refuses a send buffer inside the receive buffer: one copy, then the same collective
+        got = gather_records(buf[rank].clone(), group, out=buf.view(world * per, -1))
     if per == n and (total is None or total % world == 0):
         return unpack_detections(got)
     g3 = got.view(world, per, -1)
