@@ -108,6 +108,7 @@ int ssd_get_precision(ssd_handle *h);
  *                     two / four waves per block sharing the positions through LDS, 28..32 the one-accumulator wave with its
  *                     K-step interleaved (4 / 8 / 16 K-steps of operands in flight; 31, 32: channel-tile-major order) (0)
  *   "lat_one"         30 | 20 | 28..32: the one-wave tile the plan gives its tiny launches (fpn p6, lateral5)  (30)
+ *   "front_fuse"      -1 auto | 0 | 1: MobileNet's first convolution + Conv2d_1 as one launch (front.hip)         (-1)
  *   "igemm_lat"       1 | 0: small exact-fp32 launches on the latency form (v_mfma_f32_16x16x4_f32)      (1)
  *   "igemm_deep64"    -1 auto | 0 | 1: 64x64 tiles with operand loads three K-steps ahead                (-1)
  *   "streams"         0 auto | 1: every kernel of a forward on one stream, in plan order | 2: the internal streams at the
@@ -268,6 +269,20 @@ int ssd_first_conv(const uint8_t *images_dev, int32_t B, int32_t H, int32_t W,
                    const float *w_host /* [3,3,3,Cout] */, int32_t Cout,
                    const float *bn_mean_host, const float *bn_sf_host,
                    const float *bn_beta_host, int32_t act, float *out_dev, void *stream);
+
+/* MobileNet's first three layers as ONE launch -- what the layer plan runs for frames that arrive at the network's input
+ * size (option "front_fuse"): ssd_first_conv (create_pb.py:42-47; mobilenet_v1.py:34,49: 3 -> 32) followed by ssd_dw_pw at
+ * stride 1 (mobilenet_v1.py:59-67: depthwise 3x3, pointwise 32 -> 64), the 32-channel tensor kept in LDS.  Only these
+ * widths (C0 == 32, Cout == 64; SSD_ERR_INVALID otherwise); bit-identical to the two calls it replaces.
+ * images_dev [B,H,W,3] uint8, H and W even; out_dev [B,H/2,W/2,Cout]. */
+int ssd_front_block(const uint8_t *images_dev, int32_t B, int32_t H, int32_t W,
+                    const float *w0_host /* [3,3,3,C0] */, int32_t C0, const float *bn0_mean_host,
+                    const float *bn0_sf_host, const float *bn0_beta_host, int32_t act0,
+                    const float *dw_w_host /* [3,3,C0,1] */, const float *dw_mean_host,
+                    const float *dw_sf_host, const float *dw_beta_host, int32_t dw_act,
+                    const float *pw_w_host /* [1,1,C0,Cout] */, int32_t Cout, const float *pw_mean_host,
+                    const float *pw_sf_host, const float *pw_beta_host, int32_t pw_act,
+                    float *out_dev, void *stream);
 
 /* slim.max_pool2d 3x3 stride 2 'SAME' (shufflenet_v2.py:51-54). */
 int ssd_maxpool3x3s2(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t C,

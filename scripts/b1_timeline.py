@@ -1,6 +1,6 @@
 """Kernel timeline of ONE batch-1 forward out of a `rocprofv3 --kernel-trace --output-format csv` directory.
 usage: python scripts/b1_timeline.py <trace dir> [which forward from the end, default 2]
-A forward = the kernels from a first_conv* launch up to and including the next post_pack_kernel.  Prints
+A forward = the kernels from a first_conv* / front_kernel launch up to and including the next post_pack_kernel.  Prints
 start (us from the forward's first kernel), duration, kernel, grid, queue; then the span and per-kernel-family sums."""
 import collections, csv, glob, sys
 d = sys.argv[1]
@@ -16,7 +16,7 @@ if len(ends) < back + 1:
     sys.exit("not enough forwards in the trace")
 hi = ends[-back]
 lo = ends[-back - 1] + 1
-while lo < hi and "first_conv" not in rows[lo][2]:
+while lo < hi and "first_conv" not in rows[lo][2] and "front_kernel" not in rows[lo][2]:
     lo += 1
 fw = rows[lo:hi + 1]
 t0 = fw[0][0]

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SOURCES = ["abi.hip", "weights.hip", "plan.hip", "stages.hip", "igemm.hip", "igemm_lat.hip", "igemm16.hip", "dwpw_stream.hip", "dwpw_lat.hip",
+_SOURCES = ["abi.hip", "weights.hip", "plan.hip", "stages.hip", "igemm.hip", "igemm_lat.hip", "igemm16.hip", "dwpw_stream.hip", "dwpw_lat.hip", "front.hip",
             "elementwise.hip", "postprocess.hip"]
 _LIB_PATH = os.path.join(_CSRC, "libssd_hip.so")
 _DIAG_PATH = os.path.join(_CSRC, "libssd_hip_diag.so")       # -DSSD_DIAG build, scripts/ only
@@ -155,6 +155,7 @@ SIGNATURES = {
                                         _vp, _vp]),
     "ssd_dw_pw": (ctypes.c_int, [_vp, _i, _i, _i, _i, _f, _i, _f, _f, _f, _i, _f, _i, _f, _f, _f, _i, _vp, _vp]),
     "ssd_first_conv": (ctypes.c_int, [_vp, _i, _i, _i, _f, _i, _f, _f, _f, _i, _vp, _vp]),
+    "ssd_front_block": (ctypes.c_int, [_vp, _i, _i, _i, _f, _i, _f, _f, _f, _i, _f, _f, _f, _f, _i, _f, _i, _f, _f, _f, _i, _vp, _vp]),
     "ssd_maxpool3x3s2": (ctypes.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "ssd_concat_shuffle_split": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _i, _vp, _vp, _vp]),
     "ssd_postprocess_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i, _i]),

@@ -17,7 +17,7 @@ extern "C" const char *ssd_last_error(void) { return g_err.c_str(); }
 static Options g_opts;                 // process-wide values (ssd_set_option with a NULL handle)
 static std::mutex g_opts_mu;
 static const char *const OPT_NAMES[OPT_COUNT] = {"igemm_tile", "igemm16", "igemm_96", "lateral_split", "backbone_split", "nsub",
-                                                 "level_split", "nms_fast_max", "debug_sync", "fuse_dw", "graph", "igemm_lat", "igemm_deep64", "streams", "fpn_group", "head_serial", "side_priority", "tower_group", "fpn_p6_first", "dwpw_lat", "fpn_early_lat", "h2d_chunks", "fpn_p7_group", "event_fence", "lat_one"};
+                                                 "level_split", "nms_fast_max", "debug_sync", "fuse_dw", "graph", "igemm_lat", "igemm_deep64", "streams", "fpn_group", "head_serial", "side_priority", "tower_group", "fpn_p6_first", "dwpw_lat", "fpn_early_lat", "h2d_chunks", "fpn_p7_group", "event_fence", "lat_one", "front_fuse"};
 int ssd_opt_index(const char *key)
 {
     for (int i = 0; i < OPT_COUNT; ++i)

@@ -1,0 +1,281 @@
+// MobileNet's first three layers in ONE kernel: Conv2d_0 (3x3 stride 2 on the uint8 frame, 3 -> 32, batch norm, ReLU6;
+// mobilenet_v1.py:37-45 behind the normalisation of model.py / detector.py) -> Conv2d_1_depthwise (3x3, batch norm, ReLU6)
+// -> Conv2d_1_pointwise (32 -> 64, batch norm, ReLU6; mobilenet_v1.py:59-67, depthwise_conv.py:5-26).  The 32-channel
+// tensor at half resolution -- the second-largest tensor of a forward, 18.3 MB per 640x896 frame, written by one launch
+// and read back by the next -- never exists: a block computes the first convolution for the 14 x 18 patch its 12 x 16
+// output tile's depthwise taps read (1.31x the arithmetic of the plain layer, 27 fused multiply-adds per value) and keeps
+// it in LDS.  One launch less per forward, 36.6 MB less traffic per frame.
+//
+//   tile        12 x 16 output positions of one image x all 64 output channels; a block walks tiles b, b + G, ...
+//   phase 1     first convolution: one LANE = one patch position, all 32 channels (the arithmetic of first_conv_px_kernel,
+//               elementwise.hip: 27 inputs unpacked and normalised once, wave-uniform weights from scalar loads, the
+//               (ky,kx,ci)-ordered fmaf chain, batch norm in three separately rounded steps, activation); positions outside
+//               the layer's output are the depthwise layer's zero padding.  The frame bytes of the NEXT tile are fetched
+//               here and used one tile later.
+//   phase 2     depthwise 3x3: a thread = 4 channels x one column x 6 rows (8 patch rows x 3 columns read once); the
+//               (ky,kx)-ordered fmaf chain, batch norm, activation of dwpw_stream.hip -> the A image of the 1x1
+//   phase 3     1x1 on v_mfma_f32_32x32x2_f32, weights (the wave's fragments stay in registers for the whole kernel) as the
+//               A operand and positions as the B operand, k in channel order = the chain of igemm.hip; 12 accumulator
+//               tiles of 32 channels x 32 positions, three per wave
+//   phase 4     batch norm + activation, 16-byte stores straight from the accumulators (a lane holds 4 consecutive channels
+//               of one position), as dwpw_stream.hip's dense epilogue
+// Bit-identical to first_conv_px_kernel -> dwpw_stream_kernel (and so to the three-kernel chain and the oracle).
+#include "ssd_internal.h"
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int TY = 12, TX = 16, PH = TY + 2, PW = TX + 2, NSLOT = PH * PW;     // 252 patch positions: lanes 0 .. 251 of the block
+constexpr int OFF_A = NSLOT * 128, OFF_P = OFF_A + TY * TX * 128, LDS_BYTES = OFF_P + 3 * 64 * 4;
+static_assert(NSLOT <= 256 && LDS_BYTES <= 64 * 1024, "one lane per patch position, two blocks per CU");
+}
+
+// (the read-only operands as `const __restrict__` kernel parameters: with them inside the by-value struct the compiler cannot
+//  prove the first convolution's weights invariant and loads them per lane into vector registers instead of with scalar loads)
+struct FrontDims { int B, H, W, act0, dact, act, tiles_y, tiles_x; };
+__global__ __launch_bounds__(256, 2) void front_kernel(const uint8_t *__restrict__ a_img, const float *__restrict__ a_w0,
+                                                        const float *__restrict__ a_m0, const float *__restrict__ a_s0,
+                                                        const float *__restrict__ a_b0, const float *__restrict__ a_dwpack,
+                                                        const float *__restrict__ a_wt, const float *__restrict__ a_mean,
+                                                        const float *__restrict__ a_sf, const float *__restrict__ a_beta,
+                                                        float *__restrict__ a_out, const FrontDims a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W, OH = H >> 1, OW = W >> 1;
+    const int tiles_img = a.tiles_y * a.tiles_x, total = a.B * tiles_img;
+    const float inv255 = (float)(1.0 / 255.0);
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_img, 0, (int)((long long)a.B * H * W * 3), 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_out, 0, (int)((long long)a.B * OH * OW * 64 * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    // ---- per-thread constants
+    // phase 1: patch position of this lane
+    const int ppy = tid / PW, ppx = tid - ppy * PW;
+    // phase 2: 4 channels c4, column dcol, rows 6 dhalf .. 6 dhalf + 5
+    const int c4 = tid & 7;
+    v4f dwv[9], dmean, dsf, dbeta;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dwv[t] = *(const v4f *)(a_dwpack + t * 32 + c4 * 4);
+    dmean = *(const v4f *)(a_dwpack + 9 * 32 + c4 * 4);
+    dsf = *(const v4f *)(a_dwpack + 10 * 32 + c4 * 4);
+    dbeta = *(const v4f *)(a_dwpack + 11 * 32 + c4 * 4);
+    // phase 3: accumulator tile j of this wave = pair 3 wave + j of (position tile m = pair >> 1, channel tile n = pair & 1)
+    v4f wf[3][4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int n = (3 * wave + j) & 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wf[j][g] = *(const v4f *)(a_wt + (n * 32 + (lane & 31)) * 32 + (2 * g + (lane >> 5)) * 4);
+    }
+    int roff[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) roff[g] = (lane & 31) * 128 + (((2 * g + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4);
+    // phase 4: batch norm of the 64 output channels -> LDS
+    {
+        float *pp = (float *)(lds + OFF_P);
+        if (tid < 64) { pp[tid] = a_mean[tid]; pp[64 + tid] = a_sf[tid]; pp[128 + tid] = a_beta[tid]; }
+    }
+    const bool dact_on = a.dact >= 1, pact_on = a.act >= 1;
+    const float dact_hi = a.dact == 2 ? 6.0f : __builtin_inff(), pact_hi = a.act == 2 ? 6.0f : __builtin_inff();
+
+    // the frame bytes under this lane's patch position of tile `t`: three filter rows of 9 contiguous bytes, each as three
+    // aligned dwords (the arithmetic of first_conv_px_kernel); positions outside the layer's output are fetched clamped
+    // and zeroed after the activation
+    unsigned raw[9];
+    auto fetch = [&](int t) {
+        const int b = t / tiles_img, r = t - b * tiles_img, ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        int fy = ty * TY - 1 + ppy, fx = tx * TX - 1 + ppx;
+        fy = fy < 0 ? 0 : (fy >= OH ? OH - 1 : fy);
+        fx = fx < 0 ? 0 : (fx >= OW ? OW - 1 : fx);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * fy + ky;
+            const int ad = ((b * H + (iy < H ? iy : 0)) * W + 2 * fx) * 3;
+            const int a0 = tid < NSLOT ? (ad & ~3) : (int)OOB;
+            raw[ky * 3 + 0] = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 0, 0);
+            raw[ky * 3 + 1] = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 4, 0);
+            raw[ky * 3 + 2] = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 8, 0);
+        }
+    };
+    int t = blockIdx.x;
+    if (t < total) fetch(t);
+    __syncthreads();
+
+    for (; t < total; t += (int)gridDim.x) {
+        const int b = t / tiles_img, rt = t - b * tiles_img, ty = rt / a.tiles_x, tx = rt - ty * a.tiles_x;
+        // ---- phase 1: first convolution of this lane's patch position -> patch row tid (chunk c at slot c ^ (tid & 7))
+        {
+            const int fy = ty * TY - 1 + ppy, fx = tx * TX - 1 + ppx;
+            const bool inside = tid < NSLOT && (unsigned)fy < (unsigned)OH && (unsigned)fx < (unsigned)OW;
+            const int cy = fy < 0 ? 0 : (fy >= OH ? OH - 1 : fy), cx = fx < 0 ? 0 : (fx >= OW ? OW - 1 : fx);
+            const bool xok = 2 * cx + 2 < W;
+            float x[27];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = 2 * cy + ky;
+                const bool yok = ky < 2 || iy < H;
+                const int ad = ((b * H + (iy < H ? iy : 0)) * W + 2 * cx) * 3;
+                const int sh = ad & 3;
+                const unsigned w0 = raw[ky * 3], w1 = raw[ky * 3 + 1], w2 = raw[ky * 3 + 2];
+                const unsigned d0 = __builtin_amdgcn_alignbyte(w1, w0, sh);
+                const unsigned d1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                const unsigned d2 = w2 >> (8 * sh);
+                const unsigned char px[9] = {(unsigned char)d0, (unsigned char)(d0 >> 8), (unsigned char)(d0 >> 16), (unsigned char)(d0 >> 24),
+                                             (unsigned char)d1, (unsigned char)(d1 >> 8), (unsigned char)(d1 >> 16), (unsigned char)(d1 >> 24),
+                                             (unsigned char)d2};
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    float v = (float)px[k] * inv255;
+                    v = 2.0f * v - 1.0f;
+                    if (ky == 2 && !yok) v = 0.0f;
+                    if (k >= 6 && !xok) v = 0.0f;
+                    x[ky * 9 + k] = v;
+                }
+            }
+            // the next tile's bytes: in flight until the next iteration's phase 1
+            if (t + (int)gridDim.x < total) fetch(t + (int)gridDim.x);
+            unsigned char *prow = lds + tid * 128;
+#pragma unroll 1
+            for (int ch = 0; ch < 32; ch += 16) {           // wave-uniform; 16 accumulators per pass over the 27 taps
+                float acc[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 27; ++k) {
+                    const float *wr = a_w0 + k * 32 + ch;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] = fmaf(x[k], wr[i], acc[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float tq = (acc[i] - a_m0[ch + i]) * a_s0[ch + i];
+                    float v = tq + a_b0[ch + i];
+                    if (a.act0 >= 1) v = v > 0.0f ? v : 0.0f;
+                    if (a.act0 == 2) v = v < 6.0f ? v : 6.0f;
+                    acc[i] = inside ? v : 0.0f;
+                }
+                if (tid < NSLOT) {
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4)
+                        *(v4f *)(prow + (((((ch + i) >> 2)) ^ (tid & 7)) << 4)) = (v4f){acc[i], acc[i + 1], acc[i + 2], acc[i + 3]};
+                }
+            }
+        }
+        __syncthreads();                 // (1) the patch is complete; the previous tile's MFMAs have read the A image
+        // ---- phase 2: depthwise 3x3 + batch norm + activation -> A image rows (dhalf * 6 + o) * 16 + dcol
+        {
+            // (the thread index through an opaque copy: the 24 + 6 swizzled LDS addresses below are loop invariants, and
+            //  hoisted out of the tile loop they cost ~60 registers -- with them the kernel spilled)
+            int tz = tid;
+            asm volatile("" : "+v"(tz));
+            const int c4 = tz & 7, dcol = (tz >> 3) & 15, dhalf = tz >> 7;
+            // rows in a rolling window: patch row r is tap row 0 of output r, row 1 of output r - 1, row 2 of output r - 2 --
+            // every output still receives its taps in (ky,kx) order
+            v4f part[3];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                v4f xr[3];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int slot = (dhalf * 6 + r) * PW + dcol + kx;
+                    xr[kx] = *(const v4f *)(lds + slot * 128 + ((c4 ^ (slot & 7)) << 4));
+                }
+#pragma unroll
+                for (int ky = 2; ky >= 0; --ky) {
+                    const int o = r - ky;
+                    if (o < 0 || o >= 6) continue;
+                    v4f &v = part[o % 3];
+                    if (ky == 0) v = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaf(xr[kx][e], dwv[ky * 3 + kx][e], v[e]);
+                    if (ky == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float tq = (v[e] - dmean[e]) * dsf[e];
+                            v[e] = tq + dbeta[e];
+                            if (dact_on) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.0f, dact_hi);
+                        }
+                        const int m = (dhalf * 6 + o) * TX + dcol;
+                        *(v4f *)(lds + OFF_A + m * 128 + ((c4 ^ ((m >> 1) & 7)) << 4)) = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();                 // (2) the A image is complete; the patch is free for the next tile
+        // ---- phases 3 + 4: 1x1 and epilogue of this wave's three accumulator tiles
+        {
+            const float *pp = (const float *)(lds + OFF_P);
+            const int eh = lane >> 5;
+            v16f acc[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v4f af[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) af[j] = *(const v4f *)(lds + OFF_A + ((3 * wave + j) >> 1) * 4096 + roff[g]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j][g][k], af[j][k], acc[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                // acc[j][r]: channel nt * 32 + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), position mt * 32 + (lane & 31) of the tile
+                const int pair = 3 * wave + j, mt = pair >> 1, nt = pair & 1;
+                const int p = mt * 32 + (lane & 31);
+                const int oy = ty * TY + (p >> 4), ox = tx * TX + (p & 15);
+                const bool ok = oy < OH && ox < OW;
+                const int pos = (b * OH + oy) * OW + ox;
+#pragma unroll
+                for (int m4 = 0; m4 < 4; ++m4) {
+                    const int cl = nt * 32 + 8 * m4 + 4 * eh;
+                    const v4f mean = *(const v4f *)(pp + cl), sf = *(const v4f *)(pp + 64 + cl), beta = *(const v4f *)(pp + 128 + cl);
+                    v4f v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float xv = acc[j][4 * m4 + e];
+                        const float tq = (xv - mean[e]) * sf[e];
+                        xv = tq + beta[e];
+                        if (pact_on) xv = __builtin_amdgcn_fmed3f(xv, 0.0f, pact_hi);
+                        v[e] = xv;
+                    }
+                    const unsigned o = ok ? (unsigned)((pos * 64 + cl) * 4) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), orsrc, (int)o, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+bool front_supports(int B, int H, int W, int C0, int K, int Cout)
+{
+    if (C0 != 32 || K != 32 || Cout != 64 || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return false;
+    return (long long)B * H * W * 3 < (1LL << 31) && (long long)B * (H / 2) * (W / 2) * 64 * 4 < (1LL << 31);
+}
+
+hipError_t launch_front(const FrontArgs &q, hipStream_t s)
+{
+    if (!q.img || !q.w0 || !q.m0 || !q.s0 || !q.b0 || !q.dwpack || !q.wt || !q.mean || !q.sf || !q.beta || !q.out) return hipErrorInvalidValue;
+    if (!front_supports(q.B, q.H, q.W, 32, 32, 64)) return hipErrorInvalidValue;
+    const int OH = q.H / 2, OW = q.W / 2;
+    if (q.tiles_y != (OH + TY - 1) / TY || q.tiles_x != (OW + TX - 1) / TX) return hipErrorInvalidValue;
+    const long long total = (long long)q.B * q.tiles_y * q.tiles_x;
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    const int grid = (int)(total < 512 ? total : 512);      // two resident blocks per CU, a block walks tiles b, b + grid, ...
+    const FrontDims d = {q.B, q.H, q.W, q.act0, q.dact, q.act, q.tiles_y, q.tiles_x};
+    hipLaunchKernelGGL(front_kernel, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, q.img, q.w0, q.m0, q.s0, q.b0, q.dwpack, q.wt, q.mean, q.sf,
+                       q.beta, q.out, d);
+    return hipGetLastError();
+}
+
+int front_tile_y() { return TY; }
+int front_tile_x() { return TX; }

@@ -61,6 +61,7 @@ enum SsdOpt {
     OPT_EVENT_FENCE,        // 0 (default): the library's ordering events carry no system-scope fence (hipEventDisableSystemFence: they order
                             // streams of ONE device) | 1: default event flags (a cache writeback per record: ~8-12 us per cross-stream edge)
     OPT_LAT_ONE,            // 20 | 28 .. 32: the one-wave tile of igemm_lat.hip the plan gives its tiny launches (fpn p6 / p7 / lateral5 at batch 1-2)
+    OPT_FRONT_FUSE,         // -1 auto | 0 | 1: MobileNet's first convolution + Conv2d_1 (depthwise + pointwise) as one launch (front.hip)
     OPT_COUNT
 };
 #define SSD_OPT_UNSET INT_MIN
@@ -177,6 +178,8 @@ bool dwpws_eligible(const DwW &d, const ConvW &cw, int B, int H, int W, int stri
 Op make_dwpws_op(const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact, int act,
                  float *out, const int *omap = nullptr, long long out_bytes = 0, int rs0 = 0, int rs1 = 0);
 int dwpw_lat_ct(const struct ssd_handle *h, const DwW &d, const ConvW &cw, int B, int H, int W, int stride);   // 0: not this kernel's
+// front.hip: first convolution + Conv2d_1 in one launch; the frame pointer is the handle's cur_images + img_off at run time
+Op make_front_op(struct ssd_handle *h, size_t img_off, const DwW &f, int act0, const DwW &d, const ConvW &cw, int B, int H, int W, int dact, int act, float *out);
 Op make_dwpw_lat_op(int ct, const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact, int act, float *out);
 LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long in_off = 0, long long out_off = 0,
                       int param_off = 0, long long res_off = 0);

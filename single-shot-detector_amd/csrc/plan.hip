@@ -270,6 +270,29 @@ Op make_dwpws_op(const DwW &d, const ConvW &cw, const float *in, int B, int H, i
     return op;
 }
 
+// MobileNet's first convolution + Conv2d_1 as one launch (front.hip): the frames at the network's input size, 32 -> 32 -> 64
+Op make_front_op(ssd_handle *h, size_t img_off, const DwW &f, int act0, const DwW &d, const ConvW &cw, int B, int H, int W, int dact, int act, float *out)
+{
+    FrontArgs q;
+    memset(&q, 0, sizeof(q));
+    q.w0 = f.w; q.m0 = f.mean; q.s0 = f.sf; q.b0 = f.beta; q.dwpack = d.pack;
+    q.wt = cw.wt; q.mean = cw.mean; q.sf = cw.sf; q.beta = cw.beta; q.out = out;
+    q.B = B; q.H = H; q.W = W; q.act0 = act0; q.dact = dact; q.act = act;
+    q.tiles_y = (H / 2 + front_tile_y() - 1) / front_tile_y();
+    q.tiles_x = (W / 2 + front_tile_x() - 1) / front_tile_x();
+    Op op;
+    op.cls = 6;
+    const double M = (double)B * (H / 2) * (W / 2);
+    op.flops = (2.0 * 27 * cw.Cin_l + 2.0 * 9 * cw.Cin_l + 2.0 * cw.Cin_l * cw.Cout_l) * M;
+    op.bytes = (double)B * H * W * 3 + M * cw.Cout_l * 4.0;
+    op.run = [q, h, img_off](hipStream_t s) {
+        FrontArgs r = q;
+        r.img = h->cur_images + img_off;
+        return launch_front(r, s);
+    };
+    return op;
+}
+
 // depthwise + pointwise on the latency-form kernel (dwpw_lat.hip): the pairs of a batch-1 / batch-2 forward that the streaming
 // kernel leaves apart (MobileNet Conv2d_5 .. 13).  Returns the channel tiles per wave (0: not this kernel's launch).
 //   ct   block = 16 positions x 64 ct channels; the block recomputes its positions' depthwise values once per channel tile of
@@ -430,7 +453,13 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             float *X, *Y;
             SSDCHK(falloc(&X, maxf));
             SSDCHK(falloc(&Y, maxf));
-            {
+            // first convolution + Conv2d_1 as ONE launch (front.hip) when the frames arrive at the network's input size and
+            // the three layers have MobileNet-1.0's widths; option front_fuse = 0 / 1 pins it
+            bool front = srcH == H && srcW == W && rnh == H && rnw == W && ((fuse_mask >> 0) & 1) && h->first.mean && h->dw[0].pack &&
+                         h->pw[0].taps == 1 && h->pw[0].mean && !h->pw[0].bias && front_supports(nb, H, W, h->firstCp, h->dw[0].Cp, h->pw[0].CoutP) &&
+                         h->pw[0].CinP == 32 && MB_STRIDE[0] == 1;
+            { const int pin = ssd_opt(h, OPT_FRONT_FUSE, -1); if (pin >= 0) front = front && pin != 0; }
+            if (!front) {
                 Op op;
                 op.cls = 3;
                 op.flops = 2.0 * 27 * (double)nb * h2 * w2 * h->pw[0].Cin_l;
@@ -450,6 +479,12 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 const int s = MB_STRIDE[i];
                 float *dwo = (cur == X) ? Y : X;
                 const ConvW &cw = h->pw[i];
+                if (i == 0 && front) {
+                    ops.push_back(make_front_op(h, img_off + (size_t)b0 * srcH * srcW * 3, h->first, h->firstAct, h->dw[0], cw, nb, H, W,
+                                                SSD_ACT_RELU6, SSD_ACT_RELU6, dwo));
+                    cur = dwo;
+                    continue;
+                }
                 const bool fuse = ((fuse_mask >> i) & 1) && dwpws_eligible(h->dw[i], cw, nb, ch, cwid, s);
                 // f16x3: an unfused pair hands the depthwise result (exact fp32, in [0, 6]) to its pointwise
                 // convolution in split-fp16 rows, and the pointwise product runs as 3 x f16 MFMA

@@ -166,6 +166,24 @@ struct DwPwLArgs {
 bool dwpw_lat_supports(const DwPwLArgs &q, int ct);
 hipError_t launch_dwpw_lat(int ct /* 16-channel tiles per wave: 1 | 2 | 4 */, const DwPwLArgs &q, hipStream_t s);
 
+// MobileNet's first three layers in one launch (front.hip): first convolution 3x3 stride 2 on the uint8 frame (3 -> 32) ->
+// depthwise 3x3 -> pointwise 32 -> 64, each with its batch norm and activation; the 32-channel tensor stays in LDS --------
+struct FrontArgs {
+    const uint8_t *img;                    // [B,H,W,3] uint8 frames at the network's input size (identity resize), H and W even
+    const float *w0, *m0, *s0, *b0;        // first convolution: [27][32] weights (physical output order), batch norm [32]
+    const float *dwpack;                   // [12][32]: 9 taps, mean, sf, beta of the depthwise layer (DwW::pack, one slice)
+    const float *wt;                       // [>= 64][32] pointwise weights (igemm B layout, taps = 1)
+    const float *mean, *sf, *beta;         // [64] pointwise batch norm
+    float *out;                            // [B,H/2,W/2,64] dense
+    int B, H, W;
+    int act0, dact, act;
+    int tiles_y, tiles_x;                  // ceil((H/2) / front_tile_y()), ceil((W/2) / front_tile_x())
+};
+bool front_supports(int B, int H, int W, int C0, int K, int Cout);
+int front_tile_y();
+int front_tile_x();
+hipError_t launch_front(const FrontArgs &q, hipStream_t s);
+
 // elementwise / memory-bound kernels -----------------------------------------------------
 // source image [B,srcH,srcW,3] is NN-resized to [nh,nw], zero padded to [H,W] (even), normalised and convolved
 hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int nh, int nw, int H, int W,

@@ -336,6 +336,64 @@ extern "C" int ssd_first_conv(const uint8_t *images_dev, int32_t B, int32_t H, i
     return rc;
 }
 
+// MobileNet's first three layers as the one launch the layer plan uses for them (front.hip): first convolution 3x3 stride 2
+// 'SAME' on the normalised uint8 frames -> depthwise 3x3 -> pointwise 1x1, each with batch norm and activation.
+extern "C" int ssd_front_block(const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, const float *w0_host, int32_t C0,
+                               const float *bn0_mean, const float *bn0_sf, const float *bn0_beta, int32_t act0,
+                               const float *dw_w_host, const float *dw_mean, const float *dw_sf, const float *dw_beta, int32_t dw_act,
+                               const float *pw_w_host, int32_t Cout, const float *pw_mean, const float *pw_sf, const float *pw_beta,
+                               int32_t pw_act, float *out_dev, void *stream)
+{
+    if (!images_dev || !w0_host || !bn0_mean || !bn0_sf || !bn0_beta || !dw_w_host || !dw_mean || !dw_sf || !dw_beta || !pw_w_host ||
+        !pw_mean || !pw_sf || !pw_beta || !out_dev || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || act0 < 0 || act0 > 2 ||
+        dw_act < 0 || dw_act > 2 || pw_act < 0 || pw_act > 2)
+        return ssd_fail(SSD_ERR_INVALID, "ssd_front_block: bad arguments (H, W must be even)");
+    if (!front_supports(B, H, W, C0, C0, Cout))
+        return ssd_fail(SSD_ERR_INVALID, "ssd_front_block: shape not supported (32 -> 32 -> 64 channels, every tensor below 2 GiB)");
+    hipStream_t s = (hipStream_t)stream;
+    DevPool pool;
+    auto body = [&]() -> int {
+        const int Cp = 32, CoutP = 64;
+        std::vector<int> map = phys_map(C0, Cp), outmap = phys_map(Cout, CoutP);
+        DwW f, d;
+        f.Cp = d.Cp = Cp;
+        std::vector<float> w0((size_t)27 * Cp, 0.f), wd((size_t)9 * Cp, 0.f), m0, s0, b0, m, sf, be;
+        for (int t = 0; t < 27; ++t)
+            for (int p = 0; p < Cp; ++p) w0[(size_t)t * Cp + p] = w0_host[(size_t)t * C0 + map[p]];
+        for (int t = 0; t < 9; ++t)
+            for (int p = 0; p < Cp; ++p) wd[(size_t)t * Cp + p] = dw_w_host[(size_t)t * C0 + map[p]];
+        for (int p : map) {
+            m0.push_back(bn0_mean[p]); s0.push_back(bn0_sf[p]); b0.push_back(bn0_beta[p]);
+            m.push_back(dw_mean[p]); sf.push_back(dw_sf[p]); be.push_back(dw_beta[p]);
+        }
+        SSDCHK(pool.upload(&f.w, w0)); SSDCHK(pool.upload(&f.mean, m0)); SSDCHK(pool.upload(&f.sf, s0)); SSDCHK(pool.upload(&f.beta, b0));
+        SSDCHK(pack_dw(pool, wd, m, sf, be, d));
+        ConvW cw;
+        SSDCHK(pack_conv(nullptr, pool, pw_w_host, 1, C0, Cout, map, outmap, cw));
+        BnHost b;
+        for (int p : outmap) { b.mean.push_back(pw_mean[p]); b.sf.push_back(pw_sf[p]); b.beta.push_back(pw_beta[p]); }
+        SSDCHK(upload_bn(pool, b, cw));
+        float *tout;
+        const long long rout = (long long)B * (H / 2) * (W / 2);
+        SSDCHK(pool.alloc((void **)&tout, (size_t)rout * CoutP * 4));
+        FrontArgs q;
+        memset(&q, 0, sizeof(q));
+        q.img = images_dev; q.w0 = f.w; q.m0 = f.mean; q.s0 = f.sf; q.b0 = f.beta; q.dwpack = d.pack;
+        q.wt = cw.wt; q.mean = cw.mean; q.sf = cw.sf; q.beta = cw.beta; q.out = tout;
+        q.B = B; q.H = H; q.W = W; q.act0 = act0; q.dact = dw_act; q.act = pw_act;
+        q.tiles_y = (H / 2 + front_tile_y() - 1) / front_tile_y();
+        q.tiles_x = (W / 2 + front_tile_x() - 1) / front_tile_x();
+        HIPCHK(launch_front(q, s));
+        HIPCHK(launch_permute_channels(tout, rout, Cout, CoutP, 0, out_dev, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return SSD_OK;
+    };
+    int rc = body();
+    (void)hipStreamSynchronize(s);
+    pool.free_all();
+    return rc;
+}
+
 extern "C" int ssd_maxpool3x3s2(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t C, float *out_dev, void *stream)
 {
     if (!in_dev || !out_dev || B < 1 || C < 1 || (C & 3) || (H & 1) || (W & 1) || H < 2 || W < 2)

@@ -134,6 +134,33 @@ def first_conv(images, w, bn=None, act=None):
     return out
 
 
+def front_block(images, w0, bn0, act0, dw_w, dw_bn, dw_act, pw_w, pw_bn, pw_act):
+    """MobileNet's first three layers as the one launch the layer plan uses (front.hip): first_conv followed by dw_pw at
+    stride 1, the 32-channel tensor kept on chip (mobilenet_v1.py:34-67).  Only 3 -> 32 -> 32 -> 64 channels."""
+    torch = _torch()
+    _check_dev(torch, images, torch.uint8, "images")
+    w0 = np.ascontiguousarray(w0, dtype=np.float32)
+    dw_w = np.ascontiguousarray(dw_w, dtype=np.float32)
+    pw_w = np.ascontiguousarray(pw_w, dtype=np.float32)
+    B, H, W, three = images.shape
+    if three != 3 or w0.shape[:3] != (3, 3, 3):
+        raise ValueError("images must be [B,H,W,3] and the first weights [3,3,3,C0]")
+    C0 = w0.shape[3]
+    if dw_w.shape != (3, 3, C0, 1) or pw_w.shape[:3] != (1, 1, C0):
+        raise ValueError("weights must be [3,3,C0,1] and [1,1,C0,Cout]")
+    Cout = pw_w.shape[3]
+    out = torch.empty((B, H // 2, W // 2, Cout), dtype=torch.float32, device=images.device)
+    k0 = [_fp(v) for v in bn0]
+    kd = [_fp(v) for v in dw_bn]
+    kp = [_fp(v) for v in pw_bn]
+    fp = ctypes.POINTER(ctypes.c_float)
+    check(lib().ssd_front_block(_ptr(images), B, H, W, w0.ctypes.data_as(fp), C0, k0[0][1], k0[1][1], k0[2][1], ACT[act0],
+                                dw_w.ctypes.data_as(fp), kd[0][1], kd[1][1], kd[2][1], ACT[dw_act],
+                                pw_w.ctypes.data_as(fp), Cout, kp[0][1], kp[1][1], kp[2][1], ACT[pw_act],
+                                _ptr(out), _stream(torch)))
+    return out
+
+
 def maxpool3x3s2(x):
     torch = _torch()
     _check_dev(torch, x, torch.float32, "x")

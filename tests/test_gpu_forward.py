@@ -174,7 +174,9 @@ def test_small_batch_plan_variants_are_bit_identical(cuda, ssd, oracle_graph, H,
                 # round 4: p7 out of the grouped launch, the laterals in their chain, fenced events, the other one-wave forms, p7 beside
                 # the grouped launch, the depthwise + pointwise pairs of Conv2d_5 .. 13 as one latency-form launch
                 {"fpn_p7_group": 0}, {"fpn_early_lat": 0}, {"fpn_early_lat": 0, "fpn_p7_group": 0}, {"event_fence": 1}, {"lat_one": 20},
-                {"lat_one": 28}, {"lat_one": 32}, {"fpn_p6_first": 4}, {"dwpw_lat": 1}, {"dwpw_lat": 2}]
+                {"lat_one": 28}, {"lat_one": 32}, {"fpn_p6_first": 4}, {"dwpw_lat": 1}, {"dwpw_lat": 2},
+                # the first convolution and Conv2d_1 as two launches again (front.hip off)
+                {"front_fuse": 0}, {"front_fuse": 0, "fuse_dw": 0}]
     for v in variants:
         for k, val in v.items():
             eng.set_option(k, val)

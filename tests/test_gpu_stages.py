@@ -312,6 +312,51 @@ def test_first_conv(cuda, ssd, oracle_ops, B, H, W, Cout, act):
     assert close(got, ref, "first conv") == 1.0
 
 
+# front.hip: first convolution + Conv2d_1 in one launch.  640x896 / 4 (tiles 12 x 16 of the 80 x 112 output: ragged last tile row),
+# a frame smaller than one tile, sizes that leave ragged tiles on both axes, more tiles than resident blocks (persistent loop),
+# every activation combination
+@pytest.mark.parametrize("B,H,W,acts", [(1, 160, 224, ("relu6", "relu6", "relu6")), (2, 10, 14, ("relu6", "relu6", "relu6")),
+                                        (3, 50, 70, ("relu", None, "relu6")), (1, 26, 34, (None, "relu6", None)),
+                                        (2, 640, 896, ("relu6", "relu6", "relu6")), (5, 128, 160, ("relu6", "relu", "relu"))])
+def test_front_block(cuda, ssd, oracle_ops, B, H, W, acts):
+    rng = np.random.default_rng(H * 7 + W)
+    img = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    if H >= 50:
+        img[0, :3] = 0; img[0, -3:] = 255; img[-1, :, :2] = 255; img[-1, :, -2:] = 0       # edges: pad taps next to extreme pixels
+    w0 = (rng.standard_normal((3, 3, 3, 32)) * 0.3).astype(np.float32)
+    wd = rng.standard_normal((3, 3, 32, 1)).astype(np.float32)
+    wp = (rng.standard_normal((1, 1, 32, 64)) * np.sqrt(2.0 / 32)).astype(np.float32)
+    g0, b0, m0, v0 = bn_params(rng, 32)
+    g1, b1, m1, v1 = bn_params(rng, 32)
+    g2, b2, m2, v2 = bn_params(rng, 64)
+    bn0, bn1, bn2 = (m0, oracle_ops.bn_scale(g0, v0), b0), (m1, oracle_ops.bn_scale(g1, v1), b1), (m2, oracle_ops.bn_scale(g2, v2), b2)
+    x = dev(cuda, img)
+    got = ssd.ssd.front_block(x, w0, bn0, acts[0], wd, bn1, acts[1], wp, bn2, acts[2])
+    # bit-identical to the two launches it replaces ...
+    sep = ssd.ssd.dw_pw(ssd.ssd.first_conv(x, w0, bn=bn0, act=acts[0]), wd, 1, bn1, acts[1], wp, bn2, acts[2])
+    assert cuda.equal(got, sep), int((got != sep).sum())
+    # ... and the oracle's three layers
+    if B * H * W <= 3 * 50 * 70 or (H, W) == (160, 224):
+        c0 = oracle_ops.bn_act(oracle_ops.conv2d(oracle_ops.preprocess(img), w0, 2, "SAME"), g0, b0, m0, v0, acts[0])
+        mid = oracle_ops.bn_act(oracle_ops.depthwise3x3(c0, wd, 1), g1, b1, m1, v1, acts[1])
+        ref = oracle_ops.bn_act(oracle_ops.conv2d(mid, wp, 1, "SAME"), g2, b2, m2, v2, acts[2])
+        assert close(got.cpu().numpy(), ref, "front block") == 1.0
+    # the persistent loop and the one-tile-ahead frame fetch: the same launch again, the same bits
+    for _ in range(3):
+        assert cuda.equal(got, ssd.ssd.front_block(x, w0, bn0, acts[0], wd, bn1, acts[1], wp, bn2, acts[2]))
+
+
+def test_front_block_unsupported_widths_fail_loudly(cuda, ssd):
+    img = cuda.zeros((1, 16, 16, 3), dtype=cuda.uint8, device="cuda")
+    bn = lambda c: (np.zeros(c, np.float32), np.ones(c, np.float32), np.zeros(c, np.float32))
+    with pytest.raises(Exception):
+        ssd.ssd.front_block(img, np.zeros((3, 3, 3, 24), np.float32), bn(24), "relu", np.zeros((3, 3, 24, 1), np.float32), bn(24), "relu",
+                            np.zeros((1, 1, 24, 64), np.float32), bn(64), "relu")
+    with pytest.raises(Exception):
+        ssd.ssd.front_block(img, np.zeros((3, 3, 3, 32), np.float32), bn(32), "relu", np.zeros((3, 3, 32, 1), np.float32), bn(32), "relu",
+                            np.zeros((1, 1, 32, 128), np.float32), bn(128), "relu")
+
+
 def test_maxpool_and_shuffle(cuda, ssd, oracle_ops):
     rng = np.random.default_rng(11)
     x = rng.standard_normal((2, 16, 24, 24)).astype(np.float32)
