@@ -108,7 +108,8 @@ int ssd_get_precision(ssd_handle *h);
  *                     two / four waves per block sharing the positions through LDS, 28..32 the one-accumulator wave with its
  *                     K-step interleaved (4 / 8 / 16 K-steps of operands in flight; 31, 32: channel-tile-major order) (0)
  *   "lat_one"         30 | 20 | 28..32: the one-wave tile the plan gives its tiny launches (fpn p6, lateral5)  (30)
- *   "front_fuse"      -1 auto | 0 | 1: MobileNet's first convolution + Conv2d_1 as one launch (front.hip)         (-1)
+ *   "front_fuse"      -1 auto | 0 | 1: the backbone's first layers as one launch (front.hip): MobileNet's first
+ *                     convolution + Conv2d_1, ShuffleNet's first convolution + max pool                   (-1)
  *   "igemm_lat"       1 | 0: small exact-fp32 launches on the latency form (v_mfma_f32_16x16x4_f32)      (1)
  *   "igemm_deep64"    -1 auto | 0 | 1: 64x64 tiles with operand loads three K-steps ahead                (-1)
  *   "streams"         0 auto | 1: every kernel of a forward on one stream, in plan order | 2: the internal streams at the
@@ -283,6 +284,15 @@ int ssd_front_block(const uint8_t *images_dev, int32_t B, int32_t H, int32_t W,
                     const float *pw_w_host /* [1,1,C0,Cout] */, int32_t Cout, const float *pw_mean_host,
                     const float *pw_sf_host, const float *pw_beta_host, int32_t pw_act,
                     float *out_dev, void *stream);
+
+/* ShuffleNet's first two layers as ONE launch -- what the layer plan runs for frames that arrive at the network's input size
+ * (option "front_fuse"): ssd_first_conv (shufflenet_v2.py:37,50: 3 -> 24) followed by ssd_maxpool3x3s2 (:51-54), the
+ * half-resolution tensor kept in LDS.  Only Cout == 24, H and W multiples of 4 (SSD_ERR_INVALID otherwise); bit-identical
+ * to the two calls it replaces.  out_dev [B,H/4,W/4,Cout]. */
+int ssd_first_conv_maxpool(const uint8_t *images_dev, int32_t B, int32_t H, int32_t W,
+                           const float *w_host /* [3,3,3,Cout] */, int32_t Cout,
+                           const float *bn_mean_host, const float *bn_sf_host,
+                           const float *bn_beta_host, int32_t act, float *out_dev, void *stream);
 
 /* slim.max_pool2d 3x3 stride 2 'SAME' (shufflenet_v2.py:51-54). */
 int ssd_maxpool3x3s2(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t C,

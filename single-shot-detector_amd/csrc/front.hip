@@ -32,6 +32,54 @@ constexpr int OFF_A = NSLOT * 128, OFF_P = OFF_A + TY * TX * 128, LDS_BYTES = OF
 static_assert(NSLOT <= 256 && LDS_BYTES <= 64 * 1024, "one lane per patch position, two blocks per CU");
 }
 
+// The frame bytes under the 3x3 stride-2 window of first-convolution output (cy, cx) of image b (coordinates inside the layer's
+// output): three filter rows of 9 contiguous bytes at byte ((b H + 2 cy + ky) W + 2 cx) 3, each fetched as three aligned
+// dwords -- the addressing of first_conv_px_kernel (elementwise.hip).  Row 2 cy + 2 may lie below the frame (even H): it is
+// fetched from row 0 and masked in frame_unpack.
+static __device__ __forceinline__ void frame_fetch(const __amdgpu_buffer_rsrc_t irsrc, bool live, int b, int H, int W, int cy, int cx,
+                                                   unsigned (&raw)[9])
+{
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * cy + ky;
+        const int ad = ((b * H + (iy < H ? iy : 0)) * W + 2 * cx) * 3;
+        const int a0 = live ? (ad & ~3) : (int)0x80000000u;
+        raw[ky * 3 + 0] = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 0, 0);
+        raw[ky * 3 + 1] = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 4, 0);
+        raw[ky * 3 + 2] = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 8, 0);
+    }
+}
+
+// ... -> the 27 normalised inputs x / 255 -> 2 x - 1 in (ky, kx, ci) order; taps below / right of the frame ('SAME' on even
+// sizes pads there only) are 0.  The arithmetic of first_conv_px_kernel, value for value.
+static __device__ __forceinline__ void frame_unpack(const unsigned (&raw)[9], int b, int H, int W, int cy, int cx, float (&x)[27])
+{
+    const float inv255 = (float)(1.0 / 255.0);
+    const bool xok = 2 * cx + 2 < W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * cy + ky;
+        const bool yok = ky < 2 || iy < H;
+        const int ad = ((b * H + (iy < H ? iy : 0)) * W + 2 * cx) * 3;
+        const int sh = ad & 3;
+        const unsigned w0 = raw[ky * 3], w1 = raw[ky * 3 + 1], w2 = raw[ky * 3 + 2];
+        const unsigned d0 = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        const unsigned d1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        const unsigned d2 = w2 >> (8 * sh);
+        const unsigned char px[9] = {(unsigned char)d0, (unsigned char)(d0 >> 8), (unsigned char)(d0 >> 16), (unsigned char)(d0 >> 24),
+                                     (unsigned char)d1, (unsigned char)(d1 >> 8), (unsigned char)(d1 >> 16), (unsigned char)(d1 >> 24),
+                                     (unsigned char)d2};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            float v = (float)px[k] * inv255;
+            v = 2.0f * v - 1.0f;
+            if (ky == 2 && !yok) v = 0.0f;
+            if (k >= 6 && !xok) v = 0.0f;
+            x[ky * 9 + k] = v;
+        }
+    }
+}
+
 // (the read-only operands as `const __restrict__` kernel parameters: with them inside the by-value struct the compiler cannot
 //  prove the first convolution's weights invariant and loads them per lane into vector registers instead of with scalar loads)
 struct FrontDims { int B, H, W, act0, dact, act, tiles_y, tiles_x; };
@@ -47,7 +95,6 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const uint8_t *__restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = a.H, W = a.W, OH = H >> 1, OW = W >> 1;
     const int tiles_img = a.tiles_y * a.tiles_x, total = a.B * tiles_img;
-    const float inv255 = (float)(1.0 / 255.0);
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_img, 0, (int)((long long)a.B * H * W * 3), 0x00020000);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_out, 0, (int)((long long)a.B * OH * OW * 64 * 4), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
@@ -91,15 +138,7 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const uint8_t *__restrict
         int fy = ty * TY - 1 + ppy, fx = tx * TX - 1 + ppx;
         fy = fy < 0 ? 0 : (fy >= OH ? OH - 1 : fy);
         fx = fx < 0 ? 0 : (fx >= OW ? OW - 1 : fx);
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = 2 * fy + ky;
-            const int ad = ((b * H + (iy < H ? iy : 0)) * W + 2 * fx) * 3;
-            const int a0 = tid < NSLOT ? (ad & ~3) : (int)OOB;
-            raw[ky * 3 + 0] = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 0, 0);
-            raw[ky * 3 + 1] = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 4, 0);
-            raw[ky * 3 + 2] = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 8, 0);
-        }
+        frame_fetch(irsrc, tid < NSLOT, b, H, W, fy, fx, raw);
     };
     int t = blockIdx.x;
     if (t < total) fetch(t);
@@ -112,30 +151,8 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const uint8_t *__restrict
             const int fy = ty * TY - 1 + ppy, fx = tx * TX - 1 + ppx;
             const bool inside = tid < NSLOT && (unsigned)fy < (unsigned)OH && (unsigned)fx < (unsigned)OW;
             const int cy = fy < 0 ? 0 : (fy >= OH ? OH - 1 : fy), cx = fx < 0 ? 0 : (fx >= OW ? OW - 1 : fx);
-            const bool xok = 2 * cx + 2 < W;
             float x[27];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int iy = 2 * cy + ky;
-                const bool yok = ky < 2 || iy < H;
-                const int ad = ((b * H + (iy < H ? iy : 0)) * W + 2 * cx) * 3;
-                const int sh = ad & 3;
-                const unsigned w0 = raw[ky * 3], w1 = raw[ky * 3 + 1], w2 = raw[ky * 3 + 2];
-                const unsigned d0 = __builtin_amdgcn_alignbyte(w1, w0, sh);
-                const unsigned d1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
-                const unsigned d2 = w2 >> (8 * sh);
-                const unsigned char px[9] = {(unsigned char)d0, (unsigned char)(d0 >> 8), (unsigned char)(d0 >> 16), (unsigned char)(d0 >> 24),
-                                             (unsigned char)d1, (unsigned char)(d1 >> 8), (unsigned char)(d1 >> 16), (unsigned char)(d1 >> 24),
-                                             (unsigned char)d2};
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    float v = (float)px[k] * inv255;
-                    v = 2.0f * v - 1.0f;
-                    if (ky == 2 && !yok) v = 0.0f;
-                    if (k >= 6 && !xok) v = 0.0f;
-                    x[ky * 9 + k] = v;
-                }
-            }
+            frame_unpack(raw, b, H, W, cy, cx, x);
             // the next tile's bytes: in flight until the next iteration's phase 1
             if (t + (int)gridDim.x < total) fetch(t + (int)gridDim.x);
             unsigned char *prow = lds + tid * 128;
@@ -254,6 +271,123 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const uint8_t *__restrict
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ShuffleNet's first two layers in one kernel: Conv1 (3x3 stride 2 on the uint8 frame, 3 -> 24, batch norm, ReLU) -> MaxPool
+// (3x3 stride 2 'SAME'; shufflenet_v2.py:50-54).  The 24-channel tensor at half resolution (9.8 MB per 640x640 frame) stays
+// in LDS: a block computes the convolution for the 15 x 17 patch under its 7 x 8 pooled positions (1.14x the plain layer's
+// arithmetic), one lane per patch position as above, then takes the maxima.  Cells beyond the convolution's output do not
+// take part in a window (maxpool_kernel, elementwise.hip): they are -inf in the patch.  max is exact: bit-identical to
+// first_conv_px_kernel -> maxpool_kernel.
+namespace {
+constexpr int QY = 7, QX = 8, QPH = 2 * QY + 1, QPW = 2 * QX + 1, QSLOT = QPH * QPW;      // 255 patch positions
+static_assert(QSLOT <= 256, "one lane per patch position");
+}
+struct FrontPoolDims { int B, H, W, act0, tiles_y, tiles_x; };
+// COUT: physical channels of the convolution's output -- 24, or 32 inside the network, whose tensors carry 8 zero pad channels
+template <int COUT>
+__global__ __launch_bounds__(256, 2) void front_pool_kernel(const uint8_t *__restrict__ a_img, const float *__restrict__ a_w0,
+                                                             const float *__restrict__ a_m0, const float *__restrict__ a_s0,
+                                                             const float *__restrict__ a_b0, float *__restrict__ a_out,
+                                                             const FrontPoolDims a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[QSLOT * 128];      // patch rows of 128 B: 6 chunks used, chunk c at slot c ^ (row & 7)
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W, OH = H >> 1, OW = W >> 1, PH2 = OH >> 1, PW2 = OW >> 1;
+    const int tiles_img = a.tiles_y * a.tiles_x, total = a.B * tiles_img;
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_img, 0, (int)((long long)a.B * H * W * 3), 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_out, 0, (int)((long long)a.B * PH2 * PW2 * COUT * 4), 0x00020000);
+    const int ppy = tid / QPW, ppx = tid - ppy * QPW;
+    unsigned raw[9];
+    auto fetch = [&](int t) {
+        const int b = t / tiles_img, r = t - b * tiles_img, ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        int fy = 2 * QY * ty + ppy, fx = 2 * QX * tx + ppx;
+        fy = fy >= OH ? OH - 1 : fy;
+        fx = fx >= OW ? OW - 1 : fx;
+        frame_fetch(irsrc, tid < QSLOT, b, H, W, fy, fx, raw);
+    };
+    int t = blockIdx.x;
+    if (t < total) fetch(t);
+    for (; t < total; t += (int)gridDim.x) {
+        const int b = t / tiles_img, rt = t - b * tiles_img, ty = rt / a.tiles_x, tx = rt - ty * a.tiles_x;
+        {   // ---- phase 1: the convolution at this lane's patch position
+            const int fy = 2 * QY * ty + ppy, fx = 2 * QX * tx + ppx;
+            const bool inside = tid < QSLOT && fy < OH && fx < OW;
+            const int cy = fy >= OH ? OH - 1 : fy, cx = fx >= OW ? OW - 1 : fx;
+            float x[27];
+            frame_unpack(raw, b, H, W, cy, cx, x);
+            if (t + (int)gridDim.x < total) fetch(t + (int)gridDim.x);
+            unsigned char *prow = lds + tid * 128;
+#pragma unroll 1
+            for (int ch = 0; ch < COUT; ch += 8) {          // wave-uniform; 8 accumulators per pass over the 27 taps
+                float acc[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 27; ++k) {
+                    const float *wr = a_w0 + k * COUT + ch;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(x[k], wr[i], acc[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float tq = (acc[i] - a_m0[ch + i]) * a_s0[ch + i];
+                    float v = tq + a_b0[ch + i];
+                    if (a.act0 >= 1) v = v > 0.0f ? v : 0.0f;
+                    if (a.act0 == 2) v = v < 6.0f ? v : 6.0f;
+                    acc[i] = inside ? v : -__builtin_inff();
+                }
+                if (tid < QSLOT) {
+#pragma unroll
+                    for (int i = 0; i < 8; i += 4)
+                        *(v4f *)(prow + ((((ch + i) >> 2) ^ (tid & 7)) << 4)) = (v4f){acc[i], acc[i + 1], acc[i + 2], acc[i + 3]};
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: 56 pooled positions x COUT / 4 channel quads: a thread = (quad tid & 7, position tid >> 3 [+ 32])
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            const int c4 = tid & 7, p = (tid >> 3) + 32 * rnd;
+            if (c4 < COUT / 4 && p < QY * QX) {
+                const int py = p / QX, qx = p - py * QX;
+                const int oy = QY * ty + py, ox = QX * tx + qx;
+                v4f m = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int slot = (2 * py + ky) * QPW + 2 * qx + kx;
+                        const v4f xv = *(const v4f *)(lds + slot * 128 + ((c4 ^ (slot & 7)) << 4));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) m[e] = xv[e] > m[e] ? xv[e] : m[e];
+                    }
+                const unsigned o = (oy < PH2 && ox < PW2) ? (unsigned)((((b * PH2 + oy) * PW2 + ox) * COUT + c4 * 4) * 4) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, m), orsrc, (int)o, 0, 0);
+            }
+        }
+        __syncthreads();                 // the patch is free for the next tile
+    }
+}
+
+bool front_pool_supports(int B, int H, int W, int C0)
+{
+    if ((C0 != 24 && C0 != 32) || B < 1 || H < 4 || W < 4 || (H & 3) || (W & 3)) return false;
+    return (long long)B * H * W * 3 < (1LL << 31);
+}
+
+hipError_t launch_front_pool(const uint8_t *img, int B, int H, int W, const float *w0, int C0, const float *m0, const float *s0, const float *b0,
+                             int act0, float *out, hipStream_t s)
+{
+    if (!img || !w0 || !m0 || !s0 || !b0 || !out || !front_pool_supports(B, H, W, C0)) return hipErrorInvalidValue;
+    FrontPoolDims d = {B, H, W, act0, (H / 4 + QY - 1) / QY, (W / 4 + QX - 1) / QX};
+    const long long total = (long long)B * d.tiles_y * d.tiles_x;
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    const int grid = (int)(total < 4096 ? total : 4096);
+    if (C0 == 24) hipLaunchKernelGGL(front_pool_kernel<24>, dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d);
+    else hipLaunchKernelGGL(front_pool_kernel<32>, dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d);
+    return hipGetLastError();
 }
 
 bool front_supports(int B, int H, int W, int C0, int K, int Cout)

@@ -530,6 +530,10 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         bool sn_fuse = SSD_FUSE_SHUFFLE_DEFAULT;
         if (ssd_opt(h, OPT_FUSE_DW, -1) >= 0) sn_fuse = ssd_opt(h, OPT_FUSE_DW, -1) != 0;
         const int h4 = h2 / 2, w4 = w2 / 2;
+        // first convolution + max pool as ONE launch (front.hip) when the frames arrive at the network's input size; option
+        // front_fuse = 0 / 1 pins it
+        bool sn_front = srcH == H && srcW == W && rnh == H && rnw == W && h->first.mean && front_pool_supports(B, H, W, fc);
+        { const int pin = ssd_opt(h, OPT_FRONT_FUSE, -1); if (pin >= 0) sn_front = sn_front && pin != 0; }
         // ---- Two half-batch chains on the plan's two streams, as MobileNet's backbone above: the backbone is ~45 short kernels
         // far from any bound (fused units 0.07-0.21 of the HBM rate, 1x1 layers of 2-8 K-steps), one chain's load / store
         // phases sit under the other's arithmetic; FPN and heads stay full-batch launches.  Each stage is ONE allocation
@@ -585,7 +589,19 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                     float *F, *MP;
                     SSDCHK(falloc(&F, (long long)nb * h2 * w2 * fc));
                     SSDCHK(falloc(&MP, (long long)nb * h4 * w4 * fc));
-                    {
+                    if (sn_front) {
+                        // first convolution + max pool as one launch (front.hip): the half-resolution tensor stays in LDS
+                        Op op;
+                        op.cls = 3;
+                        op.flops = 2.0 * 27 * (double)nb * h2 * w2 * 24;
+                        op.bytes = (double)nb * H * W * 3 + (double)nb * h4 * w4 * 24 * 4.0;
+                        ssd_handle *hh = h;
+                        const DwW f = h->first;
+                        const int act = h->firstAct;
+                        const size_t off = img_off + (size_t)b0 * srcH * srcW * 3;
+                        op.run = [=](hipStream_t s) { return launch_front_pool(hh->cur_images + off, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, MP, s); };
+                        ops.push_back(op);
+                    } else {
                         Op op;
                         op.cls = 3;
                         op.flops = 2.0 * 27 * (double)nb * h2 * w2 * 24;
@@ -675,7 +691,17 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         float *F, *MP;
         SSDCHK(falloc(&F, (long long)B * h2 * w2 * fc));
         SSDCHK(falloc(&MP, (long long)B * h4 * w4 * fc));
-        {
+        if (sn_front) {
+            Op op;
+            op.cls = 3;
+            op.flops = 2.0 * 27 * (double)B * h2 * w2 * 24;
+            op.bytes = (double)B * H * W * 3 + (double)B * h4 * w4 * 24 * 4.0;
+            ssd_handle *hh = h;
+            const DwW f = h->first;
+            const int act = h->firstAct;
+            op.run = [=](hipStream_t s) { return launch_front_pool(hh->cur_images + img_off, B, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, MP, s); };
+            pl.ops.push_back(op);
+        } else {
             Op op;
             op.cls = 3;
             op.flops = 2.0 * 27 * (double)B * h2 * w2 * 24;

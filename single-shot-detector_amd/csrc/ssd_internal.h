@@ -183,6 +183,12 @@ bool front_supports(int B, int H, int W, int C0, int K, int Cout);
 int front_tile_y();
 int front_tile_x();
 hipError_t launch_front(const FrontArgs &q, hipStream_t s);
+// ShuffleNet's first convolution (3 -> C0 physical channels: 24, or 32 with the network's zero pad channels; batch norm,
+// activation) + 3x3 stride-2 max pool in one launch (front.hip): img [B,H,W,3] uint8 at the network's input size (H, W
+// multiples of 4), w0 [27][C0] -> out [B,H/4,W/4,C0]
+bool front_pool_supports(int B, int H, int W, int C0);
+hipError_t launch_front_pool(const uint8_t *img, int B, int H, int W, const float *w0, int C0, const float *m0, const float *s0, const float *b0,
+                             int act0, float *out, hipStream_t s);
 
 // elementwise / memory-bound kernels -----------------------------------------------------
 // source image [B,srcH,srcW,3] is NN-resized to [nh,nw], zero padded to [H,W] (even), normalised and convolved

@@ -394,6 +394,40 @@ extern "C" int ssd_front_block(const uint8_t *images_dev, int32_t B, int32_t H, 
     return rc;
 }
 
+// ShuffleNet's first two layers as the one launch the layer plan uses for them (front.hip): ssd_first_conv (3 -> 24) followed
+// by ssd_maxpool3x3s2, the half-resolution tensor kept in LDS.
+extern "C" int ssd_first_conv_maxpool(const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, const float *w_host, int32_t Cout,
+                                      const float *bn_mean, const float *bn_sf, const float *bn_beta, int32_t act, float *out_dev,
+                                      void *stream)
+{
+    if (!images_dev || !w_host || !bn_mean || !bn_sf || !bn_beta || !out_dev || act < 0 || act > 2)
+        return ssd_fail(SSD_ERR_INVALID, "ssd_first_conv_maxpool: bad arguments");
+    if (Cout != 24 || !front_pool_supports(B, H, W, Cout))
+        return ssd_fail(SSD_ERR_INVALID, "ssd_first_conv_maxpool: shape not supported (24 output channels, H and W multiples of 4, frames below 2 GiB)");
+    hipStream_t s = (hipStream_t)stream;
+    DevPool pool;
+    auto body = [&]() -> int {
+        const int Cp = 24;
+        std::vector<int> map = phys_map(Cout, Cp);
+        std::vector<float> wt((size_t)27 * Cp, 0.f), m, sf, be;
+        for (int t = 0; t < 27; ++t)
+            for (int p = 0; p < Cp; ++p) wt[(size_t)t * Cp + p] = w_host[(size_t)t * Cout + map[p]];
+        for (int p : map) { m.push_back(bn_mean[p]); sf.push_back(bn_sf[p]); be.push_back(bn_beta[p]); }
+        float *dw_, *dm, *ds, *db, *tout;
+        SSDCHK(pool.upload(&dw_, wt)); SSDCHK(pool.upload(&dm, m)); SSDCHK(pool.upload(&ds, sf)); SSDCHK(pool.upload(&db, be));
+        const long long rout = (long long)B * (H / 4) * (W / 4);
+        SSDCHK(pool.alloc((void **)&tout, (size_t)rout * Cp * 4));
+        HIPCHK(launch_front_pool(images_dev, B, H, W, dw_, Cp, dm, ds, db, act, tout, s));
+        HIPCHK(launch_permute_channels(tout, rout, Cout, Cp, 0, out_dev, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return SSD_OK;
+    };
+    int rc = body();
+    (void)hipStreamSynchronize(s);
+    pool.free_all();
+    return rc;
+}
+
 extern "C" int ssd_maxpool3x3s2(const float *in_dev, int32_t B, int32_t H, int32_t W, int32_t C, float *out_dev, void *stream)
 {
     if (!in_dev || !out_dev || B < 1 || C < 1 || (C & 3) || (H & 1) || (W & 1) || H < 2 || W < 2)

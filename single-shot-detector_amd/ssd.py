@@ -161,6 +161,23 @@ def front_block(images, w0, bn0, act0, dw_w, dw_bn, dw_act, pw_w, pw_bn, pw_act)
     return out
 
 
+def first_conv_maxpool(images, w, bn, act=None):
+    """ShuffleNet's first convolution + 3x3 stride-2 max pool as the one launch the layer plan uses (front.hip;
+    shufflenet_v2.py:50-54).  Only 24 output channels, H and W multiples of 4."""
+    torch = _torch()
+    _check_dev(torch, images, torch.uint8, "images")
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    B, H, W, three = images.shape
+    if three != 3 or w.shape[:3] != (3, 3, 3):
+        raise ValueError("images must be [B,H,W,3] and weights [3,3,3,Cout]")
+    Cout = w.shape[3]
+    out = torch.empty((B, H // 4, W // 4, Cout), dtype=torch.float32, device=images.device)
+    keep = [_fp(v) for v in bn]
+    check(lib().ssd_first_conv_maxpool(_ptr(images), B, H, W, w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                       Cout, keep[0][1], keep[1][1], keep[2][1], ACT[act], _ptr(out), _stream(torch)))
+    return out
+
+
 def maxpool3x3s2(x):
     torch = _torch()
     _check_dev(torch, x, torch.float32, "x")

@@ -84,6 +84,11 @@ def test_forward_vs_oracle_small(cuda, ssd, oracle_graph, backbone, H, W, B):
         out2 = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(img).cuda())]
         for a, b in zip(out, out2):
             assert np.array_equal(a, b)
+    # the backbone's first layers as separate launches again (front.hip off): the same bits
+    eng.set_option("front_fuse", 0)
+    out3 = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(img).cuda())]
+    for a, b in zip(out, out3):
+        assert np.array_equal(a, b)
     eng.close()
 
 

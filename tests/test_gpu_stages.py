@@ -357,6 +357,36 @@ def test_front_block_unsupported_widths_fail_loudly(cuda, ssd):
                             np.zeros((1, 1, 32, 128), np.float32), bn(128), "relu")
 
 
+# front.hip, ShuffleNet: first convolution + max pool in one launch.  640x640 / 4 (tiles of 7 x 8 pooled positions: ragged last
+# tile row), a frame smaller than one tile, sizes with ragged tiles on both axes, more tiles than resident blocks, no activation
+# (negative values under the maximum)
+@pytest.mark.parametrize("B,H,W,act", [(1, 160, 160, "relu"), (2, 12, 20, "relu"), (3, 52, 76, None), (2, 640, 640, "relu"),
+                                       (9, 128, 96, "relu6")])
+def test_first_conv_maxpool(cuda, ssd, oracle_ops, B, H, W, act):
+    rng = np.random.default_rng(H * 5 + W)
+    img = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    w = (rng.standard_normal((3, 3, 3, 24)) * 0.3).astype(np.float32)
+    g, b, m, v = bn_params(rng, 24)
+    bn = (m, oracle_ops.bn_scale(g, v), b)
+    x = dev(cuda, img)
+    got = ssd.ssd.first_conv_maxpool(x, w, bn, act)
+    sep = ssd.ssd.maxpool3x3s2(ssd.ssd.first_conv(x, w, bn=bn, act=act))
+    assert cuda.equal(got, sep), int((got != sep).sum())
+    if B * H * W <= 3 * 160 * 160:
+        ref = oracle_ops.maxpool3x3s2(oracle_ops.bn_act(oracle_ops.conv2d(oracle_ops.preprocess(img), w, 2, "SAME"), g, b, m, v, act))
+        assert close(got.cpu().numpy(), ref, "first conv + max pool") == 1.0
+    for _ in range(3):
+        assert cuda.equal(got, ssd.ssd.first_conv_maxpool(x, w, bn, act))
+
+
+def test_first_conv_maxpool_unsupported_shapes_fail_loudly(cuda, ssd):
+    bn = lambda c: (np.zeros(c, np.float32), np.ones(c, np.float32), np.zeros(c, np.float32))
+    with pytest.raises(Exception):       # 32 channels
+        ssd.ssd.first_conv_maxpool(cuda.zeros((1, 16, 16, 3), dtype=cuda.uint8, device="cuda"), np.zeros((3, 3, 3, 32), np.float32), bn(32), "relu")
+    with pytest.raises(Exception):       # H not a multiple of 4
+        ssd.ssd.first_conv_maxpool(cuda.zeros((1, 18, 16, 3), dtype=cuda.uint8, device="cuda"), np.zeros((3, 3, 3, 24), np.float32), bn(24), "relu")
+
+
 def test_maxpool_and_shuffle(cuda, ssd, oracle_ops):
     rng = np.random.default_rng(11)
     x = rng.standard_normal((2, 16, 24, 24)).astype(np.float32)
