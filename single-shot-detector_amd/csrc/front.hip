@@ -404,7 +404,9 @@ hipError_t launch_front(const FrontArgs &q, hipStream_t s)
     if (q.tiles_y != (OH + TY - 1) / TY || q.tiles_x != (OW + TX - 1) / TX) return hipErrorInvalidValue;
     const long long total = (long long)q.B * q.tiles_y * q.tiles_x;
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
-    const int grid = (int)(total < 512 ? total : 512);      // two resident blocks per CU, a block walks tiles b, b + grid, ...
+    // two resident blocks per CU, a block walks tiles b, b + grid, ...  (one frame = 756 tiles, measured: grids of 256 / 384 /
+    // 512 / 756 blocks -> 34.2 / 32.8 / 28.8 / 32.1 us; 32 frames: 512 / 1024 / 2048 the same step time)
+    const int grid = (int)(total < 512 ? total : 512);
     const FrontDims d = {q.B, q.H, q.W, q.act0, q.dact, q.act, q.tiles_y, q.tiles_x};
     hipLaunchKernelGGL(front_kernel, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, q.img, q.w0, q.m0, q.s0, q.b0, q.dwpack, q.wt, q.mean, q.sf,
                        q.beta, q.out, d);
