@@ -184,6 +184,15 @@ int ssd_forward_records(ssd_handle *h, const uint8_t *images_dev, int32_t B, int
 int ssd_forward_host(ssd_handle *h, const uint8_t *images_host, int32_t B, int32_t H, int32_t W,
                      void *records, void *stream);
 
+/* inference/detector.py:33-58 (Detector.__call__) for ONE frame as one call: ssd_forward_host with B = 1, the wait for
+ * `stream`, and the score filter `scores > score_threshold` over the frame's num_boxes rows (order kept) from the record
+ * into the caller's host arrays boxes_out [capacity,4], labels_out / scores_out [capacity]; *n_out = rows kept.
+ * `record` must be HOST-VISIBLE device-accessible memory of ssd_record_words(h) words (pinned: hipHostMalloc / a pinned
+ * torch tensor): the last kernel writes the frame's record there and this call reads it. */
+int ssd_detect_host(ssd_handle *h, const uint8_t *image_host, int32_t H, int32_t W, float score_threshold,
+                    void *record, float *boxes_out, int32_t *labels_out, float *scores_out, int32_t capacity,
+                    int32_t *n_out, void *stream);
+
 /* Copy a retained intermediate of the last ssd_forward to the host in the reference's
  * logical NHWC channel order (synchronises).  Names: "c3","c4","c5" (backbone outputs),
  * "p3".."p7" (feature_extractor.py:71-76), "encoded_boxes" [B,N,4] and

@@ -17,7 +17,10 @@ for spec in sys.argv[1:]:
     for kv in opts.split(","):
         if kv:
             k, v = kv.split("=")
-            d.engine.set_option(k, int(v, 0))
+            if k == "one_call":                   # Detector.__call__ through ssd_detect_host (1) or detect_host + numpy filter (0)
+                d.engine.one_call_detect = bool(int(v))
+            else:
+                d.engine.set_option(k, int(v, 0))
     for _ in range(10):
         out = d(img, score_threshold=0.5)
     got = [np.asarray(t) for t in out]

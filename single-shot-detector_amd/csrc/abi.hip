@@ -353,6 +353,34 @@ extern "C" int ssd_forward_host(ssd_handle *h, const uint8_t *images_host, int32
     return forward_checked_locked(h, h->stage_dev, B, H, W, (float *)r, r + 5 * T, (float *)(r + 4 * T), r + 6 * T, 6 * T + 1, stream);
 }
 
+// inference/detector.py:33-58 as ONE call for one frame: ssd_forward_host, the wait for `stream`, and the score filter
+// (`scores > score_threshold` over the frame's num_boxes rows, order kept) from the record into the caller's arrays.
+extern "C" int ssd_detect_host(ssd_handle *h, const uint8_t *image_host, int32_t H, int32_t W, float score_threshold, void *record,
+                               float *boxes_out, int32_t *labels_out, float *scores_out, int32_t capacity, int32_t *n_out, void *stream)
+{
+    if (!h || !boxes_out || !labels_out || !scores_out || !n_out || capacity < 0) return ssd_fail(SSD_ERR_INVALID, "ssd_detect_host: bad arguments");
+    int rc = ssd_forward_host(h, image_host, 1, H, W, record, stream);
+    if (rc != SSD_OK) return rc;
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    const long long T = (long long)h->cfg.num_classes * h->cfg.max_boxes_per_class;
+    const int32_t *r = (const int32_t *)record;
+    const float *bx = (const float *)r, *sc = (const float *)(r + 4 * T);
+    const int32_t *lb = r + 5 * T;
+    int32_t n = r[6 * T];
+    if (n < 0 || n > T) return ssd_fail(SSD_ERR_STATE, "ssd_detect_host: the record's num_boxes is out of range (is `record` host-visible memory?)");
+    int32_t k = 0;
+    for (int32_t i = 0; i < n; ++i)
+        if (sc[i] > score_threshold) {
+            if (k >= capacity) return ssd_fail(SSD_ERR_INVALID, "ssd_detect_host: capacity too small");
+            memcpy(boxes_out + 4 * (size_t)k, bx + 4 * (size_t)i, 16);
+            labels_out[k] = lb[i];
+            scores_out[k] = sc[i];
+            ++k;
+        }
+    *n_out = k;
+    return SSD_OK;
+}
+
 extern "C" int ssd_get_tensor(ssd_handle *h, const char *name, float *dst, int64_t cap, int32_t *dims)
 {
     if (!h || !name || !dst || !dims) return ssd_fail(SSD_ERR_INVALID, "ssd_get_tensor: null argument");

@@ -112,6 +112,9 @@ class Detector:
         image = np.asarray(image)
         if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
             raise ValueError("image must be a uint8 array of shape [height, width, 3]")
+        if self.engine.precision == "f32" and self.engine.one_call_detect:
+            # one library call: upload, forward, wait and the filter below in C (ssd_detect_host)
+            return self.engine.detect_one(image, float(score_threshold))
         with self.engine.lock:      # the views below live in the engine's pinned result block until the next call
             boxes, labels, scores, n = self._detect_views(image[None])
             n = n[0]  # inference/detector.py:54-58

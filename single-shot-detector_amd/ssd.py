@@ -307,6 +307,7 @@ class Engine:
             self._h = None
             raise
         self.T = int(params["num_classes"]) * int(params["max_boxes_per_class"])
+        self.one_call_detect = True      # Detector.__call__ in mode f32 through ssd_detect_host (False: detect_host + numpy filter)
         self._static = {}
         self._copy_streams = None
         self.zero_copy_max_batch = 1     # detect_host: up to this many images the records are written straight into pinned host memory
@@ -466,6 +467,24 @@ class Engine:
                 slot["pin_out"].copy_(slot["block"], non_blocking=True)
             torch.cuda.current_stream().synchronize()
             return slot["host"]
+
+    def detect_one(self, image, score_threshold):
+        """inference/detector.py:33-58 for one host frame [H,W,3] as ONE library call (ssd_detect_host): staging copy + upload,
+        forward, the wait, and the score filter in C.  Returns fresh arrays boxes [n,4], labels [n], scores [n]."""
+        torch = _torch()
+        H, W, _ = image.shape
+        with self.lock:
+            slot = self._slot((1, H, W, 3))
+            src = np.ascontiguousarray(image)
+            sc = slot.get("one")
+            if sc is None:
+                T = self.T
+                sc = (np.empty((T, 4), np.float32), np.empty((T,), np.int32), np.empty((T,), np.float32), ctypes.c_int32(0))
+                sc = slot["one"] = sc + tuple(a.ctypes.data for a in sc[:3]) + (ctypes.byref(sc[3]), _ptr(slot["pin_out"]))
+            check(lib().ssd_detect_host(self._h, src.ctypes.data, H, W, score_threshold, sc[8], sc[4], sc[5], sc[6],
+                                        sc[0].shape[0], sc[7], _stream(torch)))
+            n = sc[3].value
+            return sc[0][:n].copy(), sc[1][:n].copy(), sc[2][:n].copy()
 
     def detect_stream(self, batches):
         """Host-fed steady-state serving: an iterable of host uint8 arrays [B,H,W,3] -> a generator of (boxes, labels,

@@ -107,6 +107,25 @@ def test_detector_call_reads_pinned_views_safely(cuda, ssd):
     assert not np.array_equal(ra[2], rb[2])
 
 
+def test_detector_one_call_path_equals_numpy_filter(cuda, ssd):
+    """Detector.__call__ in mode f32 is one library call (ssd_detect_host: upload, forward, wait, score filter in C); the
+    same frames through detect_host + the numpy filter of inference/detector.py:54-58 give the same arrays -- at several
+    thresholds, incl. one that keeps nothing and one that keeps everything."""
+    det = _detector(ssd)
+    rng = np.random.default_rng(17)
+    for shape in [(128, 128, 3), (100, 151, 3)]:
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        for thr in (0.0, 0.05, 0.3, 0.999999):
+            det.engine.one_call_detect = True
+            a = det(img, score_threshold=thr)
+            det.engine.one_call_detect = False
+            b = det(img, score_threshold=thr)
+            assert len(a) == 3 and all(x.dtype == y.dtype and np.array_equal(x, y) for x, y in zip(a, b)), (shape, thr)
+            assert a[0].shape == (len(a[2]), 4) and a[1].dtype == np.int32
+        assert len(det(img, score_threshold=0.999999)[2]) == 0
+    det.engine.one_call_detect = True
+
+
 @pytest.mark.parametrize("B", [1, 3, 6])
 def test_detect_host_outputs_written_straight_into_pinned_memory(cuda, ssd, B):
     """Up to Engine.zero_copy_max_batch images detect_host hands the PINNED result block to the forward as its output
