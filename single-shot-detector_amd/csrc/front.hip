@@ -318,29 +318,28 @@ __global__ __launch_bounds__(256, 2) void front_pool_kernel(const uint8_t *__res
             frame_unpack(raw, b, H, W, cy, cx, x);
             if (t + (int)gridDim.x < total) fetch(t + (int)gridDim.x);
             unsigned char *prow = lds + tid * 128;
-#pragma unroll 1
-            for (int ch = 0; ch < COUT; ch += 8) {          // wave-uniform; 8 accumulators per pass over the 27 taps
-                float acc[8];
+            {                                                // all COUT accumulators in one pass over the 27 taps
+                float acc[COUT];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+                for (int i = 0; i < COUT; ++i) acc[i] = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 27; ++k) {
-                    const float *wr = a_w0 + k * COUT + ch;
+                    const float *wr = a_w0 + k * COUT;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(x[k], wr[i], acc[i]);
+                    for (int i = 0; i < COUT; ++i) acc[i] = fmaf(x[k], wr[i], acc[i]);
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float tq = (acc[i] - a_m0[ch + i]) * a_s0[ch + i];
-                    float v = tq + a_b0[ch + i];
+                for (int i = 0; i < COUT; ++i) {
+                    const float tq = (acc[i] - a_m0[i]) * a_s0[i];
+                    float v = tq + a_b0[i];
                     if (a.act0 >= 1) v = v > 0.0f ? v : 0.0f;
                     if (a.act0 == 2) v = v < 6.0f ? v : 6.0f;
                     acc[i] = inside ? v : -__builtin_inff();
                 }
                 if (tid < QSLOT) {
 #pragma unroll
-                    for (int i = 0; i < 8; i += 4)
-                        *(v4f *)(prow + ((((ch + i) >> 2) ^ (tid & 7)) << 4)) = (v4f){acc[i], acc[i + 1], acc[i + 2], acc[i + 3]};
+                    for (int i = 0; i < COUT; i += 4)
+                        *(v4f *)(prow + (((i >> 2) ^ (tid & 7)) << 4)) = (v4f){acc[i], acc[i + 1], acc[i + 2], acc[i + 3]};
                 }
             }
         }
