@@ -66,6 +66,19 @@ def test_documented_ctypes_binding(cuda, ssd):
     assert int(r[6 * T]) == n
     assert np.array_equal(r[:4 * T].view(np.float32).reshape(T, 4), boxes[0].cpu().numpy())
     assert np.array_equal(r[4 * T:5 * T].view(np.float32), scores[0].cpu().numpy()) and np.array_equal(r[5 * T:6 * T], labels[0].cpu().numpy())
+    # ... and all of Detector.__call__ as one call (third form)
+    bo, lo, so = np.empty((T, 4), np.float32), np.empty(T, np.int32), np.empty(T, np.float32)
+    k = ctypes.c_int32()
+    check(lib.ssd_detect_host(h, ctypes.c_void_p(image.ctypes.data), ctypes.c_int32(image.shape[0]), ctypes.c_int32(image.shape[1]),
+                              ctypes.c_float(score_threshold), p(rec), ctypes.c_void_p(bo.ctypes.data), ctypes.c_void_p(lo.ctypes.data),
+                              ctypes.c_void_p(so.ctypes.data), ctypes.c_int32(T), ctypes.byref(k),
+                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    one = bo[:k.value], lo[:k.value], so[:k.value]
+    assert k.value == int(keep.sum()) and all(np.array_equal(a, b) for a, b in zip(one, got))
+    assert lib.ssd_detect_host(h, ctypes.c_void_p(image.ctypes.data), ctypes.c_int32(image.shape[0]), ctypes.c_int32(image.shape[1]),
+                               ctypes.c_float(0.0), p(rec), ctypes.c_void_p(bo.ctypes.data), ctypes.c_void_p(lo.ctypes.data),
+                               ctypes.c_void_p(so.ctypes.data), ctypes.c_int32(1), ctypes.byref(k),
+                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0 and b"capacity" in lib.ssd_last_error()
     # errors come back as codes + text, nothing throws across the ABI
     assert lib.ssd_forward(h, None, 1, 1, 1, None, None, None, None, None) != 0 and b"null" in lib.ssd_last_error()
     lib.ssd_destroy.argtypes = [ctypes.c_void_p]
