@@ -346,6 +346,35 @@ def test_front_block(cuda, ssd, oracle_ops, B, H, W, acts):
         assert cuda.equal(got, ssd.ssd.front_block(x, w0, bn0, acts[0], wd, bn1, acts[1], wp, bn2, acts[2]))
 
 
+def test_front_kernels_random_shapes(cuda, ssd, oracle_ops):
+    """front.hip on 60 random frame sizes (even H, W for the MobileNet block; multiples of 4 for ShuffleNet's convolution + max
+    pool), batch sizes and activation combinations -- tile grids ragged on either axis, frames smaller than a tile, grids beyond
+    the resident blocks: every output bit equals the separate launches'."""
+    rng = np.random.default_rng(2024)
+    acts = [None, "relu", "relu6"]
+    w0 = (rng.standard_normal((3, 3, 3, 32)) * 0.3).astype(np.float32)
+    wd = rng.standard_normal((3, 3, 32, 1)).astype(np.float32)
+    wp = (rng.standard_normal((1, 1, 32, 64)) * 0.25).astype(np.float32)
+    w24 = (rng.standard_normal((3, 3, 3, 24)) * 0.3).astype(np.float32)
+    bns = {c: tuple(np.ascontiguousarray(v) for v in (lambda g, b, m, v: (m, oracle_ops.bn_scale(g, v), b))(*bn_params(rng, c))) for c in (24, 32, 64)}
+    bn32b = tuple(np.ascontiguousarray(v) for v in (lambda g, b, m, v: (m, oracle_ops.bn_scale(g, v), b))(*bn_params(rng, 32)))
+    for case in range(60):
+        B = int(rng.integers(1, 4))
+        if case % 2 == 0:
+            H, W = 2 * int(rng.integers(1, 90)), 2 * int(rng.integers(1, 90))
+            a = [acts[int(rng.integers(0, 3))] for _ in range(3)]
+            x = dev(cuda, rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8))
+            got = ssd.ssd.front_block(x, w0, bns[32], a[0], wd, bn32b, a[1], wp, bns[64], a[2])
+            sep = ssd.ssd.dw_pw(ssd.ssd.first_conv(x, w0, bn=bns[32], act=a[0]), wd, 1, bn32b, a[1], wp, bns[64], a[2])
+        else:
+            H, W = 4 * int(rng.integers(1, 60)), 4 * int(rng.integers(1, 60))
+            a = [acts[int(rng.integers(0, 3))]]
+            x = dev(cuda, rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8))
+            got = ssd.ssd.first_conv_maxpool(x, w24, bns[24], a[0])
+            sep = ssd.ssd.maxpool3x3s2(ssd.ssd.first_conv(x, w24, bn=bns[24], act=a[0]))
+        assert cuda.equal(got, sep), (case, B, H, W, a, int((got != sep).sum()))
+
+
 def test_front_block_unsupported_widths_fail_loudly(cuda, ssd):
     img = cuda.zeros((1, 16, 16, 3), dtype=cuda.uint8, device="cuda")
     bn = lambda c: (np.zeros(c, np.float32), np.ones(c, np.float32), np.zeros(c, np.float32))
