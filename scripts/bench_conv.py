@@ -10,7 +10,7 @@ assert torch.cuda.is_available()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 ssd_amd._lib.use_diag()        # libssd_hip_diag.so: the -DSSD_DIAG build (include/ssd_hip_diag.h)
 L = ssd_amd.lib()
-TILES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "128x256", 4: "256x128", 5: "64x64", 6: "128x96",
+TILES = {8: "128x32 deep", 0: "128x128", 1: "128x64", 2: "128x32", 3: "128x256", 4: "256x128", 5: "64x64", 6: "128x96",
          20: "lat 1x1", 21: "lat 1x2", 22: "lat 2x1", 23: "lat 2x2", 24: "lat w2 1x1", 25: "lat w4 1x1", 26: "lat w4 2x1",
          27: "lat w4 1x2", 28: "lat il", 29: "lat il D8", 30: "lat il D16", 31: "lat il nm", 32: "lat il D8 nm", 33: "abl no lds", 34: "abl no lds,x", 35: "abl no lds,x,w", 36: "abl mfma only", 7: "64x64 deep", -1: "auto"}
 
@@ -23,6 +23,10 @@ def run(name, H, W, Cin, Cout, k, stride, tiles, pyramid=0, reps=10):
               (name, TILES[t], ms.value, gf.value / ms.value, gf.value / ms.value / 157.3 * 100), flush=True)
 
 
+if len(sys.argv) > 2 and sys.argv[2] == "box":       # the box head alone: 128x32 tiles with one / two register sets of operand loads
+    for rnd in range(3):
+        run("boxes 3x3 256->24 5 levels", 80, 112, 256, 24, 3, 1, [2, 8], pyramid=1)
+    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "lat1":      # the one-wave latency form alone: prefetch depth x tile order
     for rnd in range(2):
         for shape in (("fpn p6 3x3 s2 1024->256 20x28", 20, 28, 1024, 256, 3, 2), ("fpn p7 3x3 s2 256->256 10x14", 10, 14, 256, 256, 3, 2),

@@ -741,7 +741,7 @@ int igemm_tile_bn(int tile)
     case IGEMM_128x128: case IGEMM_256x128: return 128;
     case IGEMM_128x64: case IGEMM_64x64: case IGEMM_64x64D: case 18: return 64;
     case IGEMM_128x96: return 96;
-    case IGEMM_128x32: return 32;
+    case IGEMM_128x32: case 8: return 32;
     default: return 128;   // diagnostic variants of 128x128
     }
 }
@@ -815,6 +815,7 @@ hipError_t launch_igemm(int tile, const IgemmArgs &a, int total_tiles_m, hipStre
     case 12: return launch_t<2, 2, 2, 2, 3>(a, total_tiles_m, s);
     case 17: return launch_t<2, 2, 2, 2, 7>(a, total_tiles_m, s);
     case 18: return launch_t<2, 2, 1, 1, 7>(a, total_tiles_m, s);      // phase stamps of the 64x64 tile
+    case 8: return launch_t<4, 1, 1, 1, 8>(a, total_tiles_m, s);       // 128x32 with the two register sets (loads three K-steps ahead)
 #endif
     }
     return hipErrorInvalidValue;
