@@ -1,4 +1,6 @@
-"""ShuffleNet-shaped depthwise + 1x1 pairs on dwpw_stream.hip in its DENSE form (one contiguous output tensor), with the in-kernel\nphase cycle totals of the diag build: what the units of a stage cost without their destination maps.\nusage (GPU box): python scripts/experiments/sn_dwpw_probe.py"""
+"""ShuffleNet-shaped depthwise + 1x1 pairs on dwpw_stream.hip in its DENSE form (one contiguous output tensor), with the
+in-kernel phase cycle totals of the diag build: what the units of a stage cost without their destination maps.
+usage (GPU box): python scripts/experiments/sn_dwpw_probe.py"""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
