@@ -110,7 +110,8 @@ int ssd_get_precision(ssd_handle *h);
  *   "lat_one"         30 | 20 | 28..32: the one-wave tile the plan gives its tiny launches (fpn p6, lateral5)  (30)
  *   "front_fuse"      -1 auto | 0 | 1: the backbone's first layers as one launch (front.hip): MobileNet's first
  *                     convolution + Conv2d_1, ShuffleNet's first convolution + max pool                   (-1)
- *   "igemm_lat"       1 | 0: small exact-fp32 launches on the latency form (v_mfma_f32_16x16x4_f32)      (1)
+ *   "igemm_lat"       1 | 0: small exact-fp32 launches on the latency form (v_mfma_f32_16x16x4_f32) | 2: ... and 1x1 launches
+ *                     up to 1 280 tiles | 3: as 1 without fpn p6 / p7 of the serving batches                  (1)
  *   "igemm_deep64"    -1 auto | 0 | 1: 64x64 tiles with operand loads three K-steps ahead                (-1)
  *   "streams"         0 auto | 1: every kernel of a forward on one stream, in plan order | 2: the internal streams at the
  *                     highest priority (a hardware-queue pool of their own)                  (0)

@@ -27,6 +27,11 @@ if len(sys.argv) > 2 and sys.argv[2] == "box":       # the box head alone: 128x3
     for rnd in range(3):
         run("boxes 3x3 256->24 5 levels", 80, 112, 256, 24, 3, 1, [2, 8], pyramid=1)
     sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "p67":       # fpn p6 / p7 at a serving batch: 64x64 tiles against the block forms of the latency kernel
+    for rnd in range(2):
+        for shape in (("fpn p6 3x3 s2 1024->256 20x28", 20, 28, 1024, 256, 3, 2), ("fpn p7 3x3 s2 256->256 10x14", 10, 14, 256, 256, 3, 2)):
+            run(*shape, [5, 7, 24, 25, 26, 27, 20])
+    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "lat1":      # the one-wave latency form alone: prefetch depth x tile order
     for rnd in range(2):
         for shape in (("fpn p6 3x3 s2 1024->256 20x28", 20, 28, 1024, 256, 3, 2), ("fpn p7 3x3 s2 256->256 10x14", 10, 14, 256, 256, 3, 2),

@@ -132,7 +132,13 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
             // profiles/r03_tower_phases_b1.log).  The four-wave block form of igemm_lat.hip, 16 x 64 per block: 16x16 granularity,
             // 4.4 waves per SIMD.  Alone 22 -> 18 us per launch (profiles/r03_conv_latency_form.log); batch-1 forward
             // 1.735 -> 1.690 ms, batch 2 3.10 -> 3.06 ms (profiles/r03_batch1_option_ab.log).
-            else if (a.wt_lat && cw.CoutPad % 64 == 0 && cw.taps == 1 && cw.CinP >= 256 && b64 <= (ssd_opt(h, OPT_IGEMM_LAT, 1) >= 2 ? 1280 : 640))
+            else if (a.wt_lat && cw.CoutPad % 64 == 0 && cw.taps == 1 && cw.CinP >= 256 && b64 <= (ssd_opt(h, OPT_IGEMM_LAT, 1) == 2 ? 1280 : 640))
+                tile = IGEMM_LAT_W4_1x1;
+            // fpn p6 / p7 (3x3 stride 2 on c5 / p6) at the batches where their launches are fewer than two 64x64 tiles per CU and more
+            // than the one-wave form takes: the four-wave form.  Alone at 32 images (scripts/bench_conv.py 32 p67): p6 0.288 -> 0.228 ms,
+            // p7 0.040 -> 0.028 ms; the 32-image step 39.03 / 39.06 -> 38.97 / 39.01 ms, same box.  Option igemm_lat = 3 keeps them on
+            // the 64x64 tiles.
+            else if (a.wt_lat && cw.CoutPad % 64 == 0 && cw.taps == 9 && stride == 2 && b64 <= 512 && ssd_opt(h, OPT_IGEMM_LAT, 1) != 3)
                 tile = IGEMM_LAT_W4_1x1;
             // (The box head -- 3x3, 24 of 32 columns, 96 tiles of 128x32 at batch 1 -- is NOT such a launch: 1 492 / 746 waves of
             //  16x16 / 16x32 took 73 / 66 us against the 128x32 tiles' 41 us, profiles/r03_conv_latency_form.log.)
