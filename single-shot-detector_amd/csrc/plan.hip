@@ -140,6 +140,11 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
             // the 64x64 tiles.
             else if (a.wt_lat && cw.CoutPad % 64 == 0 && cw.taps == 9 && stride == 2 && b64 <= 512 && ssd_opt(h, OPT_IGEMM_LAT, 1) != 3)
                 tile = IGEMM_LAT_W4_1x1;
+            // ... and the other single-level 3x3 launches of a small serving batch (fpn p4 / p5 from 4 images on: up to 1 280 tiles
+            // of 64x64): 8 images 10.19 / 10.20 -> 10.13 / 10.14 ms per step, 32 images (p5 only) no difference, same box.  Not the
+            // multi-level launches (towers, the grouped fpn launch of batch 1-2: +110 us per forward on this form).
+            else if (a.wt_lat && cw.CoutPad % 64 == 0 && cw.taps == 9 && lv.size() == 1 && B >= 4 && b64 <= 1280 && ssd_opt(h, OPT_IGEMM_LAT, 1) != 3)
+                tile = IGEMM_LAT_W4_1x1;
             // (The box head -- 3x3, 24 of 32 columns, 96 tiles of 128x32 at batch 1 -- is NOT such a launch: 1 492 / 746 waves of
             //  16x16 / 16x32 took 73 / 66 us against the 128x32 tiles' 41 us, profiles/r03_conv_latency_form.log.)
         }

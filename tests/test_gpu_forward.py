@@ -196,14 +196,15 @@ def test_small_batch_plan_variants_are_bit_identical(cuda, ssd, oracle_graph, H,
 
 
 def test_fpn_stride2_convs_on_the_block_form_are_bit_identical(cuda, ssd):
-    """fpn p6 / p7 (3x3 stride 2) at serving batches run on the four-wave block form of igemm_lat.hip (plan.hip; 8 frames of
-    640x896: 72 and 20 tiles of 64x64); option igemm_lat = 3 keeps them on the 64x64 tiles: the same bits in p6, p7 and every output."""
+    """fpn p6 / p7 (3x3 stride 2) and, at small serving batches, p4 / p5 run on the four-wave block form of igemm_lat.hip (plan.hip;
+    8 frames of 640x896: 1 120, 280, 72 and 20 tiles of 64x64); option igemm_lat = 3 keeps them on the 64x64 tiles: the same bits
+    in p4 ... p7 and every output."""
     params = ssd.load_config(os.path.join(HERE, "golden", "config_mobilenet.json"))
     Wt = ssd.synthetic_weights(params, seed=3, logits_bias=-5.0)
     img = cuda.from_numpy(np.random.default_rng(8).integers(0, 256, (8, 640, 896, 3), dtype=np.uint8)).cuda()
     eng = ssd.Engine(params, Wt)
     a = [t.cpu().numpy() for t in eng.forward(img)]
-    ta = {n: eng.get_tensor(n) for n in ("p6", "p7", "class_predictions", "encoded_boxes")}
+    ta = {n: eng.get_tensor(n) for n in ("p4", "p5", "p6", "p7", "class_predictions", "encoded_boxes")}
     eng.set_option("igemm_lat", 3)
     b = [t.cpu().numpy() for t in eng.forward(img)]
     tb = {n: eng.get_tensor(n) for n in ta}
