@@ -112,9 +112,18 @@ class Detector:
         image = np.asarray(image)
         if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
             raise ValueError("image must be a uint8 array of shape [height, width, 3]")
-        if self.engine.precision == "f32" and self.engine.one_call_detect:
+        if self.engine.one_call_detect:
             # one library call: upload, forward, wait and the filter below in C (ssd_detect_host)
-            return self.engine.detect_one(image, float(score_threshold))
+            out = self.engine.detect_one(image, float(score_threshold))
+            if self.engine.precision == "f16x3" and self.engine.status() & 1:
+                # an activation exceeded +-65504 and was clamped (ssd_hip.h ssd_status): these results are not
+                # trustworthy -- this detector continues in the exact mode
+                import warnings
+                warnings.warn("single-shot-detector_amd: activation outside the fp16 range in precision mode "
+                              "f16x3; switching this Detector to f32")
+                self.engine.set_precision("f32")
+                out = self.engine.detect_one(image, float(score_threshold))
+            return out
         with self.engine.lock:      # the views below live in the engine's pinned result block until the next call
             boxes, labels, scores, n = self._detect_views(image[None])
             n = n[0]  # inference/detector.py:54-58

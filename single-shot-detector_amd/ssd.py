@@ -307,7 +307,7 @@ class Engine:
             self._h = None
             raise
         self.T = int(params["num_classes"]) * int(params["max_boxes_per_class"])
-        self.one_call_detect = True      # Detector.__call__ in mode f32 through ssd_detect_host (False: detect_host + numpy filter)
+        self.one_call_detect = True      # Detector.__call__ through ssd_detect_host (False: detect_host + numpy filter)
         self._static = {}
         self._copy_streams = None
         self.zero_copy_max_batch = 1     # detect_host: up to this many images the records are written straight into pinned host memory
