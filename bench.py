@@ -392,6 +392,7 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
     if not args.no_other_precision and not stub:
         engine.set_precision(other)
         n_other = max(3, args.steps // 2)
+        out = [t.clone() for t in out]       # (collective path: detect_sharded's results are views of its receive buffers)
         dt_o, out_o, prof_o = timed.run(engine, step, n_other, 2)
         status_other = status_all_ranks()
         # agreement of the two modes on this run's frames (mode f32 is bit-identical to the CPU oracle, tests/)

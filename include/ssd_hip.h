@@ -189,7 +189,8 @@ int ssd_forward_host(ssd_handle *h, const uint8_t *images_host, int32_t B, int32
  * `stream`, and the score filter `scores > score_threshold` over the frame's num_boxes rows (order kept) from the record
  * into the caller's host arrays boxes_out [capacity,4], labels_out / scores_out [capacity]; *n_out = rows kept.
  * `record` must be HOST-VISIBLE device-accessible memory of ssd_record_words(h) words (pinned: hipHostMalloc / a pinned
- * torch tensor): the last kernel writes the frame's record there and this call reads it. */
+ * torch tensor): the last kernel writes the frame's record there and this call reads it.  A pointer that is not pinned or
+ * managed host memory (device memory, pageable memory) is refused with SSD_ERR_INVALID -- checked once per pointer. */
 int ssd_detect_host(ssd_handle *h, const uint8_t *image_host, int32_t H, int32_t W, float score_threshold,
                     void *record, float *boxes_out, int32_t *labels_out, float *scores_out, int32_t capacity,
                     int32_t *n_out, void *stream);

@@ -44,6 +44,20 @@ int nms_fast_max(const ssd_handle *h)
     return v < 0 ? 0 : (v == 0 ? -1 : v);
 }
 
+// The handle's own ordering events (sub-batch start, graph replay in / out, previous forward) with the flags the handle's
+// options ask for; called by ssd_create and again when option event_fence changes on the handle (device idle, plans freed).
+static int make_handle_events(ssd_handle *h)
+{
+    hipEvent_t *evs[4] = {&h->ev_start, &h->ev_gin, &h->ev_gout, &h->ev_last};
+    const unsigned evf = ssd_sync_event_flags(h);
+    for (hipEvent_t *e : evs) {
+        if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+        HIPCHK(hipEventCreateWithFlags(e, evf));
+    }
+    h->have_last = false;           // (ev_last is new: nothing is recorded in it; the device is idle)
+    return SSD_OK;
+}
+
 extern "C" int ssd_set_option(ssd_handle *h, const char *key, int32_t value)
 {
     const int k = ssd_opt_index(key);
@@ -59,6 +73,7 @@ extern "C" int ssd_set_option(ssd_handle *h, const char *key, int32_t value)
     HIPCHK(hipDeviceSynchronize());
     free_plans(h);                  // the layer plan depends on the options
     h->opts.v[k] = value;
+    if (k == OPT_EVENT_FENCE) SSDCHK(make_handle_events(h));      // the handle's own ordering events follow the option too
     return SSD_OK;
 }
 
@@ -84,11 +99,8 @@ extern "C" int ssd_create(const ssd_config *cfg, ssd_handle **out)
     HIPCHK(hipSetDevice(cfg->device));
     ssd_handle *h = new ssd_handle();
     h->cfg = *cfg;
-    const unsigned evf = ssd_sync_event_flags(nullptr);
-    if (hipEventCreateWithFlags(&h->ev_start, evf) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_gin, evf) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_gout, evf) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_last, evf) != hipSuccess) {
+    if (make_handle_events(h) != SSD_OK) {
+        for (hipEvent_t e : {h->ev_start, h->ev_gin, h->ev_gout, h->ev_last}) if (e) (void)hipEventDestroy(e);
         delete h;
         return ssd_fail(SSD_ERR_HIP, "ssd_create: cannot create events");
     }
@@ -202,9 +214,22 @@ static int forward_locked(ssd_handle *h, const uint8_t *images_dev, int32_t B, i
     // one arena per handle: a forward on another stream than the previous one waits for it.  The event is recorded HERE, at the
     // current tail of the previous stream (everything the previous forward enqueued there precedes it), not at the end of
     // every forward: a record behind the last kernel is one more packet the caller's synchronisation waits for.
+    // Single-stream steady state (the usual caller): nothing is ever recorded.  The FIRST time a forward arrives on another
+    // stream the event is recorded lazily at the tail of the previous stream -- unless that stream is being captured by the
+    // caller or is gone (then the device is drained instead) -- and from then on the handle is `multi_stream`: every forward
+    // records ev_last right behind its own last kernel (forward_checked_locked), so a later forward on another stream never
+    // touches a stream handle it does not own any more and never waits for unrelated work queued there afterwards.
     if (h->have_last && h->last_stream != s) {
-        if (hipEventRecord(h->ev_last, h->last_stream) == hipSuccess) HIPCHK(hipStreamWaitEvent(s, h->ev_last, 0));
-        else { (void)hipGetLastError(); HIPCHK(hipDeviceSynchronize()); }      // (the caller destroyed that stream)
+        if (!h->multi_stream) {
+            h->multi_stream = true;
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            const bool known = hipStreamIsCapturing(h->last_stream, &cs) == hipSuccess;
+            if (known && cs == hipStreamCaptureStatusNone && hipEventRecord(h->ev_last, h->last_stream) == hipSuccess)
+                HIPCHK(hipStreamWaitEvent(s, h->ev_last, 0));
+            else { (void)hipGetLastError(); HIPCHK(hipDeviceSynchronize()); }      // (captured, destroyed or unknown stream)
+        } else {
+            HIPCHK(hipStreamWaitEvent(s, h->ev_last, 0));
+        }
         h->have_last = false;
     }
     // hipGraph replay (launch-bound regime: batch 1 is ~35 short kernels on a few streams).  A
@@ -269,6 +294,7 @@ static int forward_checked_locked(ssd_handle *h, const uint8_t *images_dev, int3
         if (cs == hipStreamCaptureStatusNone) {
             h->last_stream = s;
             h->have_last = true;
+            if (h->multi_stream) HIPCHK(hipEventRecord(h->ev_last, s));       // (a handle that has seen two streams: eager record)
         }
     }
     return rc;
@@ -358,7 +384,24 @@ extern "C" int ssd_forward_host(ssd_handle *h, const uint8_t *images_host, int32
 extern "C" int ssd_detect_host(ssd_handle *h, const uint8_t *image_host, int32_t H, int32_t W, float score_threshold, void *record,
                                float *boxes_out, int32_t *labels_out, float *scores_out, int32_t capacity, int32_t *n_out, void *stream)
 {
-    if (!h || !boxes_out || !labels_out || !scores_out || !n_out || capacity < 0) return ssd_fail(SSD_ERR_INVALID, "ssd_detect_host: bad arguments");
+    if (!h || !record || !boxes_out || !labels_out || !scores_out || !n_out || capacity < 0) return ssd_fail(SSD_ERR_INVALID, "ssd_detect_host: bad arguments");
+    {   // `record` is written by the GPU and read HERE, on the host: it must be pinned (or managed) host memory.  Checked once per
+        // pointer (hipPointerGetAttributes costs microseconds; a serving loop reuses its block), so a device pointer comes back
+        // as an error code instead of a fault inside the library.
+        std::lock_guard<std::mutex> g(h->mu);
+        if (h->detect_rec_ok != record) {
+            HIPCHK(hipSetDevice(h->cfg.device));
+            hipPointerAttribute_t at;
+            memset(&at, 0, sizeof(at));
+            const hipError_t pe = hipPointerGetAttributes(&at, record);
+            if (pe != hipSuccess) (void)hipGetLastError();
+            const bool host_visible = pe == hipSuccess && (at.type == hipMemoryTypeHost || at.type == hipMemoryTypeManaged || at.isManaged);
+            if (!host_visible)
+                return ssd_fail(SSD_ERR_INVALID, "ssd_detect_host: `record` must be pinned (hipHostMalloc / hipHostRegister) or managed host memory -- "
+                                                 "a device pointer or pageable memory cannot be written by the GPU and read by this call");
+            h->detect_rec_ok = record;
+        }
+    }
     int rc = ssd_forward_host(h, image_host, 1, H, W, record, stream);
     if (rc != SSD_OK) return rc;
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));

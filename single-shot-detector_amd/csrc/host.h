@@ -254,7 +254,9 @@ struct ssd_handle {
     // the arena is one per handle: a forward enqueued on another stream than the previous one waits for it
     hipStream_t last_stream = nullptr;
     bool have_last = false;
+    bool multi_stream = false;          // forwards have arrived on more than one stream: ev_last is recorded behind every forward
     hipEvent_t ev_last = nullptr;
+    const void *detect_rec_ok = nullptr;     // ssd_detect_host: the record pointer last verified to be host-visible memory
     // ssd_forward_host: pinned staging + device image, grown on demand; the stream whose copy last read the staging buffer
     uint8_t *stage_pin = nullptr, *stage_dev = nullptr;
     size_t stage_bytes = 0;

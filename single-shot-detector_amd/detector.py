@@ -113,16 +113,19 @@ class Detector:
         if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
             raise ValueError("image must be a uint8 array of shape [height, width, 3]")
         if self.engine.one_call_detect:
-            # one library call: upload, forward, wait and the filter below in C (ssd_detect_host)
-            out = self.engine.detect_one(image, float(score_threshold))
-            if self.engine.precision == "f16x3" and self.engine.status() & 1:
-                # an activation exceeded +-65504 and was clamped (ssd_hip.h ssd_status): these results are not
-                # trustworthy -- this detector continues in the exact mode
-                import warnings
-                warnings.warn("single-shot-detector_amd: activation outside the fp16 range in precision mode "
-                              "f16x3; switching this Detector to f32")
-                self.engine.set_precision("f32")
+            # one library call: upload, forward, wait and the filter below in C (ssd_detect_host).  The engine's lock (an RLock)
+            # is held across the call AND the read-and-clear of the status word: with two threads on one Detector in mode
+            # f16x3, thread A's status() must not consume the overflow bit that thread B's forward raised.
+            with self.engine.lock:
                 out = self.engine.detect_one(image, float(score_threshold))
+                if self.engine.precision == "f16x3" and self.engine.status() & 1:
+                    # an activation exceeded +-65504 and was clamped (ssd_hip.h ssd_status): these results are not
+                    # trustworthy -- this detector continues in the exact mode
+                    import warnings
+                    warnings.warn("single-shot-detector_amd: activation outside the fp16 range in precision mode "
+                                  "f16x3; switching this Detector to f32")
+                    self.engine.set_precision("f32")
+                    out = self.engine.detect_one(image, float(score_threshold))
             return out
         with self.engine.lock:      # the views below live in the engine's pinned result block until the next call
             boxes, labels, scores, n = self._detect_views(image[None])

@@ -121,7 +121,16 @@ def detect_sharded(engine, images_local, group=None, total=None, force=False):
     The engine writes its records straight into this rank's slice of the all-gather's receive buffer (ssd_forward_records),
     the collective runs in place on it and the four results are views of the buffer: no pack / unpack launches, no stream
     users beside RCCL's.  Uneven shards: every rank's slice is the largest shard's size; the rows beyond a rank's own
-    shard are dropped by one concatenation of row ranges."""
+    shard are dropped by one concatenation of row ranges.
+
+    Lifetime of the results: on the collective path they are VIEWS of a receive buffer this module keeps per (engine,
+    world, shard size) -- TWO buffers used alternately, so the results of step k stay intact during step k + 1 (the usual
+    "consume the previous step while the next one runs" loop) and are overwritten by step k + 2.  Clone what must live
+    longer.  Without a process group (or a group of one rank and no `force`) the results are fresh tensors.
+
+    A failed collective propagates: after an RCCL error the communicator is aborted and a retry on the same process group
+    can hang every rank, so nothing is retried here.  Whether the send buffer may sit inside the receive buffer is decided
+    once from the backend's name ('nccl' = RCCL: in place; anything else: one copy of this rank's slice)."""
     use = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
     if not hasattr(engine, "record_words"):                # a stand-in engine (launcher tests): the generic path
         boxes, labels, scores, num = engine.forward(images_local)
@@ -134,19 +143,16 @@ def detect_sharded(engine, images_local, group=None, total=None, force=False):
     if n > per:
         raise ValueError("shard of %d images exceeds ceil(%d / %d)" % (n, total, world))
     key = (id(engine), world, per, str(images_local.device))
-    buf = _gather_buffers.get(key)
-    if buf is None:
+    slot = _gather_buffers.get(key)
+    if slot is None:
         _gather_buffers.clear()
-        buf = _gather_buffers[key] = torch.zeros((world, per, engine.record_words), dtype=torch.int32, device=images_local.device)
+        slot = _gather_buffers[key] = {"bufs": [torch.zeros((world, per, engine.record_words), dtype=torch.int32, device=images_local.device)
+                                                for _ in range(2)], "turn": 0}
+    buf = slot["bufs"][slot["turn"]]
+    slot["turn"] ^= 1
     engine.forward(images_local, records=buf[rank, :n])
     inplace = dist.get_backend(group) == "nccl"
-    try:
-        got = gather_records(buf[rank] if inplace else buf[rank].clone(), group, out=buf.view(world * per, -1))
-    except RuntimeError:
-        if not inplace:
-            raise
-        # a process-group build that refuses a send buffer inside the receive buffer: one copy, then the same collective
-        got = gather_records(buf[rank].clone(), group, out=buf.view(world * per, -1))
+    got = gather_records(buf[rank] if inplace else buf[rank].clone(), group, out=buf.view(world * per, -1))
     if per == n and (total is None or total % world == 0):
         return unpack_detections(got)
     g3 = got.view(world, per, -1)

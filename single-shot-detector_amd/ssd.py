@@ -373,6 +373,9 @@ class Engine:
             records = self.new_records(B, images.device)
         if records.dtype != torch.int32 or tuple(records.shape) != (B, self.record_words) or not records.is_contiguous():
             raise ValueError("records must be a contiguous int32 tensor [B, %d]" % self.record_words)
+        if not (records.is_cuda or records.is_pinned()):
+            # the GPU writes through this pointer: pageable host memory would fault inside the kernel
+            raise ValueError("records must live in device memory or in pinned host memory")
         with self.lock:
             check(lib().ssd_forward_records(self._h, _ptr(images), B, H, W, _ptr(records), _stream(torch)))
         return self.record_views(records)

@@ -33,6 +33,23 @@ def test_self_launch_world2_gloo(extra, total, shards):
     assert res["precision"] == "f32" and res["dtype"] == "f32"          # the reference's arithmetic is the headline
 
 
+def test_self_launch_world8_gloo_uneven_global_batch():
+    """The driver's 8-GPU run (BASELINE config 5) is the first time eight ranks meet on hardware; the launcher, the shard
+    table and the padded all-gather meet them here first: world size 8 on gloo, a global batch of 250 that 8 does not
+    divide (shards of 32, 32, 31 x 6)."""
+    res = run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--global-batch", "250"])
+    assert res["n_gpus"] == 8 and res["ranks_seen"] == list(range(8))
+    exp, lo = [], 0
+    for r in range(8):
+        n = 32 if r < 2 else 31
+        exp.append([lo, lo + n])
+        lo += n
+    assert res["config"]["global_batch"] == 250 and res["config"]["shards"] == exp and lo == 250
+    assert res["value"] > 0 and abs(res["value"] - 250 * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"]
+    even = run(["--gpus", "8", "--steps", "1", "--warmup", "0", "--batch", "4"])
+    assert even["config"]["global_batch"] == 32 and even["config"]["shards"][7] == [28, 32] and even["ranks_seen"] == list(range(8))
+
+
 def test_single_rank_needs_no_launcher():
     res = run(["--steps", "1", "--warmup", "0", "--batch", "2"])
     assert res["n_gpus"] == 1 and res["ranks_seen"] == [0] and res["config"]["global_batch"] == 2

@@ -97,7 +97,18 @@ def _worker_sharded(rank, world, port, q):
     for r in range(world):
         for a, b in zip(out, _records(r, 3, T)):
             ok &= bool(torch.equal(a[r * 3:(r + 1) * 3], b))
-    # uneven shards: 5 = 3 + 2, twice (the buffer is reused)
+    # lifetime of the results (views of one of TWO alternating receive buffers): step k survives step k + 1 ...
+    keep = [t.clone() for t in out]
+    ptr = out[0].data_ptr()
+    eng.rank = rank + 10                                # the next steps' records differ from step k's
+    out_b = ssd_amd.detect_sharded(eng, torch.zeros((3, 8, 8, 3), dtype=torch.uint8), total=6)
+    ok &= all(bool(torch.equal(a, b)) for a, b in zip(out, keep)) and out_b[0].data_ptr() != ptr
+    ok &= not torch.equal(out_b[0], keep[0])
+    # ... and is overwritten by step k + 2 (documented: clone what must live longer)
+    out_c = ssd_amd.detect_sharded(eng, torch.zeros((3, 8, 8, 3), dtype=torch.uint8), total=6)
+    ok &= out_c[0].data_ptr() == ptr and bool(torch.equal(out[0], out_c[0]))
+    eng.rank = rank
+    # uneven shards: 5 = 3 + 2, twice (the buffers are reused)
     for _ in range(2):
         lo, hi = ssd_amd.shard_range(5, rank, world)
         out5 = ssd_amd.detect_sharded(eng, torch.zeros((hi - lo, 8, 8, 3), dtype=torch.uint8), total=5)

@@ -228,7 +228,7 @@ def test_forward_vs_oracle_full_size(cuda, ssd, oracle_graph, cfg, H, W):
     eng = ssd.Engine(params, Wt)
     out = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(img).cuda())]
     assert out[0].shape == (1, 2000, 4) and out[1].dtype == np.int32 and out[3].dtype == np.int32
-    stage_check(eng, keep, STAGES, "full")
+    assert stage_check(eng, keep, STAGES, "full") == 1.0, "full-size stages within tolerance but not bit-identical to the oracle"
     compare_outputs(out, ref, "full size")
     assert ref["num_boxes"][0] > 50, ref["num_boxes"]
     eng.close()
@@ -345,10 +345,12 @@ def test_missing_weight_fails_loudly(cuda, ssd):
         ssd.Engine(params, Wt)
 
 
-def test_batch_independence_full_batch(cuda, ssd):
+def test_batch_independence_full_batch(cuda, ssd, oracle_graph):
     """BASELINE config 5 shard size (32 images / GPU) at 640x896: every image of a batch
     gives exactly the result of its own batch-1 run, and permuting the batch permutes the
-    outputs (the path has no cross-image term)."""
+    outputs (the path has no cross-image term).  Two images of the batch -- one per backbone
+    chain of the serving plan (128x128 tiles, two half-batch chains) -- are also compared with
+    the oracle directly: outputs and every retained stage, bit for bit."""
     params = ssd.load_config(os.path.join(HERE, "golden", "config_mobilenet.json"))
     Wt = ssd.synthetic_weights(params, seed=0, logits_bias=-4.0)
     eng = ssd.Engine(params, Wt)
@@ -364,6 +366,20 @@ def test_batch_independence_full_batch(cuda, ssd):
     for a, b in zip(full, one):
         assert np.array_equal(a[17:18], b)
     assert full[3].min() > 0
+    # the serving plan against the oracle itself (not only against its own batch-1 run): the batch is forwarded again (the
+    # batch-1 run above re-planned the arena) and images 3 (first chain) and 29 (second chain) are checked
+    full2 = [t.cpu().numpy() for t in eng.forward(d)]
+    for a, b in zip(full, full2):
+        assert np.array_equal(a, b)
+    stages = {n: eng.get_tensor(n) for n in STAGES}
+    for i in (3, 29):
+        keep = {}
+        ref = oracle_graph.forward(imgs[i:i + 1], Wt, params, keep)
+        for a, k in zip(full2, ("boxes", "labels", "scores", "num_boxes")):
+            assert np.array_equal(a[i:i + 1], ref[k]), (i, k)
+        for n in STAGES:
+            got = stages[n][i:i + 1]
+            assert np.array_equal(got, keep[n].reshape(got.shape)), (i, n)
     eng.close()
 
 

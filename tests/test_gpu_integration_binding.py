@@ -79,6 +79,14 @@ def test_documented_ctypes_binding(cuda, ssd):
                                ctypes.c_float(0.0), p(rec), ctypes.c_void_p(bo.ctypes.data), ctypes.c_void_p(lo.ctypes.data),
                                ctypes.c_void_p(so.ctypes.data), ctypes.c_int32(1), ctypes.byref(k),
                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0 and b"capacity" in lib.ssd_last_error()
+    # a record block the host cannot read (device memory) or the GPU cannot write (pageable memory): an error code, no fault
+    dev_rec = torch.empty((1, RW), dtype=torch.int32, device="cuda")
+    page_rec = np.empty((1, RW), np.int32)
+    for bad in (p(dev_rec), ctypes.c_void_p(page_rec.ctypes.data)):
+        assert lib.ssd_detect_host(h, ctypes.c_void_p(image.ctypes.data), ctypes.c_int32(image.shape[0]), ctypes.c_int32(image.shape[1]),
+                                   ctypes.c_float(0.0), bad, ctypes.c_void_p(bo.ctypes.data), ctypes.c_void_p(lo.ctypes.data),
+                                   ctypes.c_void_p(so.ctypes.data), ctypes.c_int32(T), ctypes.byref(k),
+                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0 and b"pinned" in lib.ssd_last_error()
     # errors come back as codes + text, nothing throws across the ABI
     assert lib.ssd_forward(h, None, 1, 1, 1, None, None, None, None, None) != 0 and b"null" in lib.ssd_last_error()
     lib.ssd_destroy.argtypes = [ctypes.c_void_p]
