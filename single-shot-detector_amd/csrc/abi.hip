@@ -443,7 +443,7 @@ extern "C" int ssd_get_tensor(ssd_handle *h, const char *name, float *dst, int64
         HIPCHK(hipMemcpy(tmp.data(), r.dev, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
         for (long long q = 0; q < rows; ++q)
             for (int c = 0; c < r.C; ++c) {
-                const int pc = r.permuted ? ssd_phys_of_logical(c) : c;
+                const int pc = !r.permuted ? c : (r.split > 0 ? twopart_phys(c, r.split, r.Cp / 2) : ssd_phys_of_logical(c));
                 if (r.fmt) {          // split-fp16 row: per octet 8 halves h, 8 halves l
                     const _Float16 *row = (const _Float16 *)&tmp[q * r.Cp];
                     dst[done + q * r.C + c] = (float)row[(pc >> 3) * 16 + (pc & 7)] + (float)row[(pc >> 3) * 16 + 8 + (pc & 7)];
@@ -475,7 +475,7 @@ extern "C" int ssd_get_tensor_dev(ssd_handle *h, const char *name, float *dst_de
         const Retained &r = it->second;
         const long long rows = (long long)r.B * r.H * r.W;
         if (cap < done + rows * r.C) return ssd_fail(SSD_ERR_INVALID, "ssd_get_tensor_dev: destination too small");
-        if (r.permuted) HIPCHK(launch_permute_channels(r.dev, rows, r.C, r.Cp, r.fmt ? 2 : 0, dst_dev + done, (hipStream_t)stream));
+        if (r.permuted) HIPCHK(launch_permute_channels(r.dev, rows, r.C, r.Cp, r.fmt ? 2 : 0, dst_dev + done, (hipStream_t)stream, r.fmt ? 0 : r.split));
         else HIPCHK(hipMemcpyAsync(dst_dev + done, r.dev, (size_t)rows * r.C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
         done += rows * r.C;
         Btot += r.B;

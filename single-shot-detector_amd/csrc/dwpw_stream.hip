@@ -21,18 +21,16 @@
 //               fma(x, w, acc) are the same bits), so an accumulator tile has the output channel on its rows
 //               (registers) and the position on its columns (lanes): a lane holds runs of 4 consecutive channels of
 //               ONE position -- 16-byte stores straight from the accumulators, no LDS transpose.
-//   epilogue    batch norm + activation per channel (parameters from LDS), then either 16-B stores into a dense
-//               [M][Cout] tensor, or (OMAP) one dword per channel through a per-channel destination map (byte offset
-//               + one of two row strides): ShuffleNet's concat_shuffle_split (shufflenet_v2.py:94-115) and the stage
-//               concat (:89) folded into the stores -- every produced channel is written once, where its consumer
-//               reads it.
+//   epilogue    batch norm + activation per channel (parameters from LDS), then 16-B stores into dense rows
+//               [M][out_rs] (out_rs >= Cout: a ShuffleNet stage's last unit writes its channels straight into the first
+//               half of the stage output's rows).  ShuffleNet's concat_shuffle_split (shufflenet_v2.py:94-115) is not
+//               here: producers store dense, the consumer's loads gather (sn_pw.hip).
 #include "ssd_internal.h"
 #include <cstdio>
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
-typedef int v4i __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
 #define WAIT_VM_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
@@ -51,7 +49,7 @@ static __device__ __forceinline__ void wait_vmcnt(int n)
     }
 }
 
-template <int STRIDE, int WN, bool OMAP>
+template <int STRIDE, int WN>
 __global__ __launch_bounds__(256, (STRIDE == 1 && WN == 1) ? 3 : 2) void dwpw_stream_kernel(const DwPwSArgs a)
 {
     constexpr int TY = STRIDE == 1 ? 8 : 4, TX = 8, BM = TY * TX;
@@ -63,7 +61,7 @@ __global__ __launch_bounds__(256, (STRIDE == 1 && WN == 1) ? 3 : 2) void dwpw_st
     constexpr int NBW = BN / 32;                     // B-slice DMA instructions per wave (BN rows x 128 B over 4 waves)
     constexpr int PATCH_BYTES = NPI * 1024, W_BYTES = 2048, A_BYTES = BM * 128, B_BYTES = BN * 128, P_BYTES = BN * 16;
     constexpr int OFF_W = 2 * PATCH_BYTES, OFF_A = OFF_W + W_BYTES, OFF_B = OFF_A + A_BYTES, OFF_P = OFF_B + 2 * B_BYTES;
-    constexpr int NSTORE = OMAP ? WN * 16 : WN * 4;  // epilogue stores per wave and tile
+    constexpr int NSTORE = WN * 4;                   // epilogue stores per wave and tile
     constexpr unsigned OOB = 0x80000000u;
     static_assert(OFF_P + P_BYTES <= 80 * 1024, "two blocks per CU");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // the ONE shared array of this kernel
@@ -171,18 +169,16 @@ __global__ __launch_bounds__(256, (STRIDE == 1 && WN == 1) ? 3 : 2) void dwpw_st
         }
     };
 
-    // ---- epilogue parameters of the block's BN channels -> LDS (the block keeps its n-tile): mean | sf | beta | destination.
+    // ---- epilogue parameters of the block's BN channels -> LDS (the block keeps its n-tile): mean | sf | beta.
     // Ordinary loads and LDS writes, all retired before the DMA pipeline starts.
     {
         float *pp = (float *)(lds + OFF_P);
-        int *po = (int *)(lds + OFF_P + 3 * BN * 4);
         for (int c = tid; c < BN; c += 256) {
             const int n = tile_n * BN + c;
             const bool ok = n < a.Cout;
             pp[c] = ok ? a.mean[n] : 0.0f;
             pp[BN + c] = ok ? a.sf[n] : 0.0f;
             pp[2 * BN + c] = ok ? a.beta[n] : 0.0f;
-            if constexpr (OMAP) po[c] = ok ? a.omap[n] : -1;      // byte offset of the channel in row 0 | row-stride selector, or -1
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -340,23 +336,9 @@ __global__ __launch_bounds__(256, (STRIDE == 1 && WN == 1) ? 3 : 2) void dwpw_st
                         v[e] = x;
                         acc[j][4 * m + e] = 0.0f;
                     }
-                    if constexpr (OMAP) {
-                        const v4i d = *(const v4i *)(lds + OFF_P + 3 * BN * 4 + cl * 4);
-                        const v4u vu = __builtin_bit_cast(v4u, v);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            // (locals, not vector elements, as builtin arguments: see the note in dma_b)
-                            const int de = d[e];
-                            const unsigned val = vu[e];
-                            const int rs = (de & 1) ? a.rs1 : a.rs0;
-                            const unsigned o = (ok && de >= 0) ? (unsigned)(pos * rs + (de & ~3)) : OOB;
-                            __builtin_amdgcn_raw_buffer_store_b32(val, orsrc, (int)o, 0, 0);
-                        }
-                    } else {
-                        const int n = tile_n * BN + cl;
-                        const unsigned o = (ok && n < a.Cout) ? (unsigned)((pos * a.Cout + n) * 4) : OOB;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), orsrc, (int)o, 0, 0);
-                    }
+                    const int n = tile_n * BN + cl;
+                    const unsigned o = (ok && n < a.Cout) ? (unsigned)((pos * a.out_rs + n) * 4) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), orsrc, (int)o, 0, 0);
                 }
             }
         }
@@ -374,7 +356,7 @@ __global__ __launch_bounds__(256, (STRIDE == 1 && WN == 1) ? 3 : 2) void dwpw_st
 int dwpws_tile_m(int stride) { return stride == 1 ? 64 : 32; }
 int dwpws_tile_n(int stride, int CoutP) { return stride == 1 && CoutP <= 64 ? 64 : 128; }
 
-template <int STRIDE, int WN, bool OMAP>
+template <int STRIDE, int WN>
 static hipError_t launch_s(const DwPwSArgs &a, hipStream_t s)
 {
     constexpr int TY = STRIDE == 1 ? 8 : 4, TX = 8;
@@ -383,7 +365,7 @@ static hipError_t launch_s(const DwPwSArgs &a, hipStream_t s)
     constexpr int lds_bytes = 2 * NPI * 1024 + 2048 + TY * TX * 128 + 2 * BN * 128 + BN * 16;
     constexpr int PER_CU = (STRIDE == 1 && WN == 1) ? 3 : 2;        // resident blocks per CU (LDS)
     static std::atomic<unsigned> attr_done{0};
-    auto k = dwpw_stream_kernel<STRIDE, WN, OMAP>;
+    auto k = dwpw_stream_kernel<STRIDE, WN>;
     {
         hipError_t e = ssd_allow_lds((const void *)k, lds_bytes, attr_done);
         if (e != hipSuccess) return e;
@@ -393,7 +375,7 @@ static hipError_t launch_s(const DwPwSArgs &a, hipStream_t s)
         static bool said = false;
         int nb = 0;
         if (!said && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 256, lds_bytes) == hipSuccess) {
-            fprintf(stderr, "[diag] dwpw_stream_kernel<%d,%d,%d>: %d bytes of LDS, occupancy API: %d blocks per CU\n", STRIDE, WN, (int)OMAP, lds_bytes, nb);
+            fprintf(stderr, "[diag] dwpw_stream_kernel<%d,%d>: %d bytes of LDS, occupancy API: %d blocks per CU\n", STRIDE, WN, lds_bytes, nb);
             said = true;
         }
     }
@@ -419,13 +401,8 @@ hipError_t launch_dwpw_stream(int stride, const DwPwSArgs &a, hipStream_t s)
     if (a.tiles_y != (a.OH + TY - 1) / TY || a.tiles_x != (a.OW + 7) / 8 || a.m_tiles != a.B * a.tiles_y * a.tiles_x) return hipErrorInvalidValue;
     // 32-bit byte offsets inside the buffer resources
     if ((long long)a.B * a.H * a.W * a.K * 4 >= (1LL << 31) || (long long)a.wt_rows * a.K * 4 >= (1LL << 31) || a.out_bytes <= 0) return hipErrorInvalidValue;
-    if (!a.omap && (long long)a.B * a.OH * a.OW * a.Cout * 4 > (long long)a.out_bytes) return hipErrorInvalidValue;
-    if (a.omap && (a.rs0 <= 0 || a.rs1 <= 0 || (a.rs0 & 3) || (a.rs1 & 3) ||
-                   (long long)a.B * a.OH * a.OW * (a.rs0 > a.rs1 ? a.rs0 : a.rs1) >= (1LL << 31))) return hipErrorInvalidValue;
-    if (a.omap) {
-        if (stride == 1) return BN == 64 ? launch_s<1, 1, true>(a, s) : launch_s<1, 2, true>(a, s);
-        return launch_s<2, 1, true>(a, s);
-    }
-    if (stride == 1) return BN == 64 ? launch_s<1, 1, false>(a, s) : launch_s<1, 2, false>(a, s);
-    return launch_s<2, 1, false>(a, s);
+    if (a.out_rs < a.Cout || (long long)a.B * a.OH * a.OW * a.out_rs * 4 >= (1LL << 31)) return hipErrorInvalidValue;
+    if (((long long)a.B * a.OH * a.OW - 1) * a.out_rs * 4 + (long long)a.Cout * 4 > (long long)a.out_bytes) return hipErrorInvalidValue;
+    if (stride == 1) return BN == 64 ? launch_s<1, 1>(a, s) : launch_s<1, 2>(a, s);
+    return launch_s<2, 1>(a, s);
 }

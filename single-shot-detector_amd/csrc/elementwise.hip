@@ -535,12 +535,46 @@ hipError_t launch_gather_channels(const float *x, int xs, const float *y, int ys
     return hipGetLastError();
 }
 
+// Table-driven row gather from several dense tensors of ONE allocation with one row stride (the y half of a ShuffleNet stage
+// output, shufflenet_v2.py:89: channels that earlier units left untouched): out[r][c] = base[r * rs + src[c]] (byte
+// offsets; src[c] < 0: 0) for c < Cw, four channels per thread, 16-byte stores.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const unsigned char *__restrict__ base, const int *__restrict__ src, int rs,
+                                                           long long rows, int Cw, float *__restrict__ out, int ors)
+{
+    const int C4 = Cw >> 2;
+    const long long total = rows * C4;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4) * 4;
+        const long long r = idx / C4;
+        const int4 sv = *(const int4 *)(src + c);
+        const unsigned char *row = base + r * rs;
+        float4 v;
+        v.x = sv.x >= 0 ? *(const float *)(row + sv.x) : 0.0f;
+        v.y = sv.y >= 0 ? *(const float *)(row + sv.y) : 0.0f;
+        v.z = sv.z >= 0 ? *(const float *)(row + sv.z) : 0.0f;
+        v.w = sv.w >= 0 ? *(const float *)(row + sv.w) : 0.0f;
+        *(float4 *)(out + r * ors + c) = v;
+    }
+}
+
+hipError_t launch_gather_rows(const float *base, const int *src, int rs, long long rows, int Cw, float *out, int ors, hipStream_t s)
+{
+    if (!base || !src || !out || Cw < 4 || (Cw & 3) || (ors & 3) || (rs & 3) || rows < 1 || (reinterpret_cast<uintptr_t>(out) & 15)) return hipErrorInvalidValue;
+    const long long total = rows * (Cw / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned char *)base, src, rs, rows, Cw, out, ors);
+    return hipGetLastError();
+}
+
 // to_phys = 1: in [rows][C] logical -> out [rows][Cpad] physical (pad channels zero)
 // to_phys = 0: in [rows][Cpad] physical -> out [rows][C] logical
 // to_phys = 2 / 3: the same with the physical side in split-fp16 (S16) rows: per octet of 8 physical
 //   channels 8 halves h then 8 halves l, value = h + l (igemm.hip)
+// split > 0 (to_phys = 0 only): a two-part physical row [first `split` logical channels in their own standard layout over
+// Cpad / 2 | the rest likewise] -- a ShuffleNet stage output (plan.hip)
 __global__ __launch_bounds__(256) void permute_kernel(const float *__restrict__ in, long long rows, int C, int Cpad,
-                                                       int to_phys, float *__restrict__ out)
+                                                       int to_phys, float *__restrict__ out, int split)
 {
     const int Cw = (to_phys & 1) ? Cpad : C;
     const long long total = rows * Cw;
@@ -552,7 +586,7 @@ __global__ __launch_bounds__(256) void permute_kernel(const float *__restrict__ 
             const int l = logical_of_phys(j);
             out[idx] = l < C ? in[r * C + l] : 0.0f;
         } else if (to_phys == 0) {
-            out[idx] = in[r * Cpad + phys_of_logical(j)];
+            out[idx] = in[r * Cpad + ((split > 0 && j >= split) ? (Cpad >> 1) + phys_of_logical(j - split) : phys_of_logical(j))];
         } else if (to_phys == 3) {
             const int l = logical_of_phys(j);
             float x = l < C ? in[r * C + l] : 0.0f;
@@ -571,12 +605,13 @@ __global__ __launch_bounds__(256) void permute_kernel(const float *__restrict__ 
 }
 
 hipError_t launch_permute_channels(const float *in, long long rows, int C, int Cpad, int to_phys, float *out,
-                                   hipStream_t s)
+                                   hipStream_t s, int split)
 {
+    if (split && to_phys != 0) return hipErrorInvalidValue;
     const long long total = rows * ((to_phys & 1) ? Cpad : C);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(permute_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, rows, C, Cpad, to_phys, out);
+    hipLaunchKernelGGL(permute_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, rows, C, Cpad, to_phys, out, split);
     return hipGetLastError();
 }

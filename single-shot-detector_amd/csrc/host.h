@@ -106,6 +106,9 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // physical position p -> logical channel (or -1 for a pad channel)
 std::vector<int> phys_map(int C, int Cp);
 std::vector<int> ident_map(int C, int Cp);
+// a ShuffleNet stage output [x half | y half] (D logical channels each, each half in its own standard layout over Dp)
+std::vector<int> twopart_map(int D, int Dp);
+static inline int twopart_phys(int c, int D, int Dp) { return c < D ? ssd_phys_of_logical(c) : Dp + ssd_phys_of_logical(c - D); }
 
 struct BnHost { std::vector<float> mean, sf, beta; };
 
@@ -176,7 +179,9 @@ Op make_dw_op(const DwW &d, const float *in, int B, int H, int W, int stride, in
               int *flags = nullptr);
 bool dwpws_eligible(const DwW &d, const ConvW &cw, int B, int H, int W, int stride);
 Op make_dwpws_op(const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact, int act,
-                 float *out, const int *omap = nullptr, long long out_bytes = 0, int rs0 = 0, int rs1 = 0);
+                 float *out, int out_rs = 0 /* floats between output rows; 0: cw.CoutP */);
+// sn_pw.hip: 1x1 + batch norm + activation on rows gathered through `src` (device table, CinP entries) from `base`
+Op make_pw_gather_op(const ConvW &cw, const float *base, long long base_bytes, const int *src, int rs, long long M, int act, float *out);
 int dwpw_lat_ct(const struct ssd_handle *h, const DwW &d, const ConvW &cw, int B, int H, int W, int stride);   // 0: not this kernel's
 // front.hip: first convolution + Conv2d_1 in one launch; the frame pointer is the handle's cur_images + img_off at run time
 Op make_front_op(struct ssd_handle *h, size_t img_off, const DwW &f, int act0, const DwW &d, const ConvW &cw, int B, int H, int W, int dact, int act, float *out);
@@ -193,7 +198,9 @@ extern const int A_STRIDES[5];
 extern const int MB_STRIDE[13];          // mobilenet_v1.py:52-58 (weights.hip)
 
 // ----------------------------------------------------------------------------- handle
-struct Retained { const float *dev; int B, H, W, C, Cp; bool permuted; int fmt = 0; /* 1: split-fp16 rows */ };
+struct Retained { const float *dev; int B, H, W, C, Cp; bool permuted; int fmt = 0; /* 1: split-fp16 rows */
+                  int split = 0; /* > 0: two-part rows (a ShuffleNet stage output): the first `split` logical channels in their own
+                                    standard layout over Cp / 2 physical channels, the rest likewise behind them */ };
 
 struct EvPair { hipEvent_t a, b; int cls; int fwd; };
 
@@ -244,6 +251,7 @@ struct ssd_handle {
     ConvW tgroup[4];                    // tower layer i of BOTH nets behind one pointer each (kernel, 2 x 5 batch norms): one launch per layer
     std::vector<int *> tabs;            // shufflenet gather tables (device)
     int c_ch[3] = {0, 0, 0};            // logical channels of c3, c4, c5
+    int c_split[3] = {0, 0, 0};         // > 0: c3 / c4 is a ShuffleNet stage output in two-part rows [x half | y half], this many channels each
     int precision = SSD_PRECISION_F32;  // ssd_set_precision
     int *flags_dev = nullptr;           // status word (bit 0: an S16 tensor was clamped to the fp16 range)
     // plans

@@ -240,8 +240,8 @@ Op make_dw_op(const DwW &d, const float *in, int B, int H, int W, int stride, in
     return op;
 }
 
-// depthwise + pointwise on the streaming kernel (dwpw_stream.hip): any K % 32 == 0, any image size.  omap / out_bytes:
-// per-channel destination map (ShuffleNet: concat_shuffle_split folded into the stores), else a dense [M][CoutP] output.
+// depthwise + pointwise on the streaming kernel (dwpw_stream.hip): any K % 32 == 0, any image size; dense output rows
+// [M][out_rs] (out_rs: a ShuffleNet stage's last unit writes into the x half of the stage output's rows)
 bool dwpws_eligible(const DwW &d, const ConvW &cw, int B, int H, int W, int stride)
 {
     const int OH = H / stride, OW = W / stride;
@@ -252,22 +252,21 @@ bool dwpws_eligible(const DwW &d, const ConvW &cw, int B, int H, int W, int stri
 }
 
 Op make_dwpws_op(const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact, int act,
-                 float *out, const int *omap, long long out_bytes, int rs0, int rs1)
+                 float *out, int out_rs)
 {
     DwPwSArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = in; a.dwpack = d.pack; a.wt = cw.wt; a.mean = cw.mean; a.sf = cw.sf; a.beta = cw.beta; a.out = out; a.omap = omap;
+    a.in = in; a.dwpack = d.pack; a.wt = cw.wt; a.mean = cw.mean; a.sf = cw.sf; a.beta = cw.beta; a.out = out;
     a.B = B; a.H = H; a.W = W; a.K = d.Cp; a.OH = H / stride; a.OW = W / stride;
     a.Cout = cw.CoutP; a.wt_rows = cw.CoutPad;
+    a.out_rs = out_rs > 0 ? out_rs : cw.CoutP;
     a.pad = stride == 1 ? 1 : 0;
     a.dact = dact; a.act = act;
     const int TY = stride == 1 ? 8 : 4, BN = dwpws_tile_n(stride, cw.CoutP);
     a.tiles_y = (a.OH + TY - 1) / TY; a.tiles_x = (a.OW + 7) / 8;
     a.m_tiles = B * a.tiles_y * a.tiles_x;
     a.n_tiles = (cw.CoutP + BN - 1) / BN;
-    const long long dense = (long long)B * a.OH * a.OW * cw.CoutP * 4;
-    a.out_bytes = (int)(omap ? out_bytes : dense);
-    a.rs0 = rs0; a.rs1 = rs1;
+    a.out_bytes = (int)(((long long)B * a.OH * a.OW - 1) * a.out_rs * 4 + (long long)cw.CoutP * 4);
     a.ts = g_dbg_ts;
 #ifdef SSD_DIAG
     if (const char *e = getenv("SSD_DWPWS_ABL")) a.abl = atoi(e);
@@ -278,6 +277,27 @@ Op make_dwpws_op(const DwW &d, const ConvW &cw, const float *in, int B, int H, i
     op.flops = (2.0 * 9 * cw.Cin_l + 2.0 * cw.Cin_l * cw.Cout_l) * M;
     op.bytes = ((double)B * H * W * cw.Cin_l + M * cw.Cout_l) * 4.0 + (double)cw.Cin_l * cw.Cout_l * 4.0;
     op.run = [a, stride](hipStream_t s) { return launch_dwpw_stream(stride, a, s); };
+    return op;
+}
+
+// ShuffleNet's conv1x1_before on gathered rows (sn_pw.hip): `src` (device, cw.CinP entries) names the column of `base` that
+// holds input channel k of row 0; M rows of `rs` bytes each
+Op make_pw_gather_op(const ConvW &cw, const float *base, long long base_bytes, const int *src, int rs, long long M, int act, float *out)
+{
+    PwGArgs a;
+    memset(&a, 0, sizeof(a));
+    a.base = base; a.base_bytes = (int)base_bytes; a.src = src; a.rs = rs;
+    a.wt = cw.wt; a.mean = cw.mean; a.sf = cw.sf; a.beta = cw.beta;
+    a.out = out; a.out_rs = cw.CoutP; a.out_bytes = (int)(M * cw.CoutP * 4);
+    a.M = (int)M; a.K = cw.CinP; a.Cout = cw.CoutP; a.wt_rows = cw.CoutPad; a.act = act;
+    a.m_tiles = (int)((M + 63) / 64);
+    const int BN = pw_gather_tile_n(cw.CoutP);
+    a.n_tiles = (cw.CoutP + BN - 1) / BN;
+    Op op;
+    op.cls = 1;
+    op.flops = 2.0 * (double)M * cw.Cin_l * cw.Cout_l;
+    op.bytes = (double)M * (cw.Cin_l + cw.Cout_l) * 4.0 + (double)cw.Cin_l * cw.Cout_l * 4.0;
+    op.run = [a](hipStream_t s) { return launch_pw_gather(a, s); };
     return op;
 }
 
@@ -545,18 +565,28 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         // front_fuse = 0 / 1 pins it
         bool sn_front = srcH == H && srcW == W && rnh == H && rnw == W && h->first.mean && front_pool_supports(B, H, W, fc);
         { const int pin = ssd_opt(h, OPT_FRONT_FUSE, -1); if (pin >= 0) sn_front = sn_front && pin != 0; }
-        // ---- Two half-batch chains on the plan's two streams, as MobileNet's backbone above: the backbone is ~45 short kernels
-        // far from any bound (fused units 0.07-0.21 of the HBM rate, 1x1 layers of 2-8 K-steps), one chain's load / store
-        // phases sit under the other's arithmetic; FPN and heads stay full-batch launches.  Each stage is ONE allocation
-        // [X' buffers of chain 0 | X' buffers of chain 1 | stage output S of the whole batch]: a chain's destination maps
-        // address its own X' region and its images' rows of S.  Option backbone_split = 1 keeps one chain.
+        // ---- One or two half-batch chains (two from 4 images on, on the plan's two streams, as MobileNet's backbone above: the
+        // backbone is ~45 short kernels far from any bound, one chain's load / store phases sit under the other's arithmetic);
+        // FPN and heads stay full-batch launches.  Option backbone_split = 1 keeps one chain.
+        //
+        // concat_shuffle_split (shufflenet_v2.py:94-115) and the stage concat (:89) run as NO kernel of their own:
+        //   * every producer of a stage -- unit_1's two branches, unit j's conv1x1_after -- stores its D channels DENSE, one
+        //     contiguous run per position, into a tensor of its own (16-byte stores from dwpw_stream.hip's accumulators, every
+        //     line written whole by one launch);
+        //   * unit j's conv1x1_before GATHERS its input row (sn_pw.hip): the host traces input channel k through the interleave-
+        //     and-split of the reference back to (producer tensor, column) and gives the kernel that table; the k order -- and
+        //     with it bit-identity with the oracle -- is untouched;
+        //   * the stage output is kept in two-part rows [x half | y half] (weights.hip packs its consumers for that): the last
+        //     unit stores its channels straight into the x half, the y half (channels no later unit touched) is one row gather.
+        // Each stage is ONE allocation [producer tensors of chain 0 | ... of chain 1 | stage output S of the whole batch] under
+        // one buffer resource.
         bool chained = false;
         {
             int nhalf = B >= 4 ? 2 : 1;
             { const int v = ssd_opt(h, OPT_BACKBONE_SPLIT, 0); if (v >= 1 && v <= 2 && v <= B) nhalf = v; }
-            bool ok = sn_fuse && nhalf == 2;
-            const int nb_of[2] = {B / 2, B - B / 2};
-            struct StageGeo { int ch, cw, oh, ow, D, Dp, Cc, n_units, ipw, idw; long long xbytes[2], xoff[2], soff, total; };
+            bool ok = sn_fuse;
+            const int nb_of[2] = {nhalf == 2 ? B / 2 : B, nhalf == 2 ? B - B / 2 : 0};
+            struct StageGeo { int ch, cw, oh, ow, D, Dp, n_units, ipw, idw; long long tbytes[2], toff[2], soff, total; };
             StageGeo geo[3];
             {
                 int ch = h4, cw = w4, ipw = 0, idw = 0;
@@ -564,20 +594,24 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                     StageGeo &g = geo[st];
                     g.ch = ch; g.cw = cw; g.oh = ch / 2; g.ow = cw / 2; g.ipw = ipw; g.idw = idw; g.n_units = units[st];
                     const ConvW &after = h->pw[ipw + 1], &after2 = h->pw[ipw + 2];
-                    g.Dp = after.CoutP; g.D = after.Cout_l; g.Cc = round_up(2 * g.D, 32);
+                    g.Dp = after.CoutP; g.D = after.Cout_l;
                     long long off = 0;
-                    for (int hf = 0; hf < 2; ++hf) {
-                        g.xbytes[hf] = (long long)nb_of[hf] * g.oh * g.ow * g.Dp * 4;
-                        g.xoff[hf] = off;
-                        off += g.xbytes[hf] * (g.n_units - 1);
+                    for (int hf = 0; hf < nhalf; ++hf) {
+                        g.tbytes[hf] = (long long)nb_of[hf] * g.oh * g.ow * g.Dp * 4;       // one producer tensor of this chain
+                        g.toff[hf] = off;
+                        off += g.tbytes[hf] * g.n_units;                                  // x1, y1, o_2 .. o_{n-1}
                     }
                     g.soff = off;
-                    g.total = off + (long long)B * g.oh * g.ow * g.Cc * 4;
-                    ok = g.total < (1LL << 31) && (g.D & 1) == 0;
-                    for (int hf = 0; ok && hf < 2; ++hf) {
+                    g.total = off + (long long)B * g.oh * g.ow * 2 * g.Dp * 4;
+                    ok = g.total < (1LL << 31) && g.n_units >= 2 && after2.CoutP == g.Dp && after2.Cout_l == g.D;
+                    for (int hf = 0; ok && hf < nhalf; ++hf) {
                         ok = dwpws_eligible(h->dw[idw], after, nb_of[hf], ch, cw, 2) && dwpws_eligible(h->dw[idw + 1], after2, nb_of[hf], ch, cw, 2);
-                        for (int j = 2; ok && j <= g.n_units; ++j)
-                            ok = dwpws_eligible(h->dw[idw + j], h->pw[ipw + 3 + 2 * (j - 2) + 1], nb_of[hf], g.oh, g.ow, 1);
+                        for (int j = 2; ok && j <= g.n_units; ++j) {
+                            const ConvW &b2 = h->pw[ipw + 3 + 2 * (j - 2)], &a2 = h->pw[ipw + 3 + 2 * (j - 2) + 1];
+                            ok = dwpws_eligible(h->dw[idw + j], a2, nb_of[hf], g.oh, g.ow, 1) && a2.CoutP == g.Dp && b2.CinP == g.Dp && b2.taps == 1 &&
+                                 b2.mean && !b2.bias &&
+                                 pw_gather_supports(b2.CinP, b2.CoutP, (long long)nb_of[hf] * g.oh * g.ow, g.Dp * 4, g.total, (long long)nb_of[hf] * g.oh * g.ow * b2.CoutP * 4);
+                        }
                     }
                     ipw += 3 + 2 * (g.n_units - 1); idw += 2 + (g.n_units - 1);
                     ch = g.oh; cw = g.ow;
@@ -586,50 +620,42 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             if (ok) {
                 chained = true;
                 float *stage[3];
-                for (int st = 0; st < 3; ++st) {
-                    SSDCHK(falloc(&stage[st], geo[st].total / 4));
-                    HIPCHK(hipMemset(stage[st], 0, (size_t)geo[st].total));       // pad channels are never written: they stay zero
-                }
+                for (int st = 0; st < 3; ++st) SSDCHK(falloc(&stage[st], geo[st].total / 4));
                 const StageGeo &g2 = geo[2];
                 const ConvW &c5w = h->pw[g2.ipw + 3 + 2 * (g2.n_units - 1)];
                 SSDCHK(falloc(&C5, (long long)B * g2.oh * g2.ow * c5w.CoutP));
                 std::vector<Op> half_ops[2];
-                for (int hf = 0; hf < 2; ++hf) {
+                for (int hf = 0; hf < nhalf; ++hf) {
                     const int b0 = hf == 0 ? 0 : nb_of[0], nb = nb_of[hf];
                     std::vector<Op> &ops = half_ops[hf];
-                    float *F, *MP;
-                    SSDCHK(falloc(&F, (long long)nb * h2 * w2 * fc));
+                    float *F = nullptr, *MP;
                     SSDCHK(falloc(&MP, (long long)nb * h4 * w4 * fc));
-                    if (sn_front) {
-                        // first convolution + max pool as one launch (front.hip): the half-resolution tensor stays in LDS
-                        Op op;
-                        op.cls = 3;
-                        op.flops = 2.0 * 27 * (double)nb * h2 * w2 * 24;
-                        op.bytes = (double)nb * H * W * 3 + (double)nb * h4 * w4 * 24 * 4.0;
+                    {
                         ssd_handle *hh = h;
                         const DwW f = h->first;
                         const int act = h->firstAct;
                         const size_t off = img_off + (size_t)b0 * srcH * srcW * 3;
-                        op.run = [=](hipStream_t s) { return launch_front_pool(hh->cur_images + off, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, MP, s); };
-                        ops.push_back(op);
-                    } else {
                         Op op;
                         op.cls = 3;
                         op.flops = 2.0 * 27 * (double)nb * h2 * w2 * 24;
-                        op.bytes = (double)nb * H * W * 3 + (double)nb * h2 * w2 * 24 * 4.0;
-                        ssd_handle *hh = h;
-                        const DwW f = h->first;
-                        const int act = h->firstAct;
-                        const size_t off = img_off + (size_t)b0 * srcH * srcW * 3;
-                        op.run = [=](hipStream_t s) {
-                            return launch_first_conv(hh->cur_images + off, nb, srcH, srcW, rnh, rnw, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s);
-                        };
-                        ops.push_back(op);
-                        Op mp;
-                        mp.cls = 5; mp.flops = 0;
-                        mp.bytes = ((double)nb * h2 * w2 + (double)nb * h4 * w4) * 24 * 4.0;
-                        mp.run = [=](hipStream_t s) { return launch_maxpool(F, nb, h2, w2, fc, MP, s); };
-                        ops.push_back(mp);
+                        if (sn_front) {
+                            // first convolution + max pool as one launch (front.hip): the half-resolution tensor stays in LDS
+                            op.bytes = (double)nb * H * W * 3 + (double)nb * h4 * w4 * 24 * 4.0;
+                            op.run = [=](hipStream_t s) { return launch_front_pool(hh->cur_images + off, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, MP, s); };
+                            ops.push_back(op);
+                        } else {
+                            SSDCHK(falloc(&F, (long long)nb * h2 * w2 * fc));
+                            op.bytes = (double)nb * H * W * 3 + (double)nb * h2 * w2 * 24 * 4.0;
+                            op.run = [=](hipStream_t s) {
+                                return launch_first_conv(hh->cur_images + off, nb, srcH, srcW, rnh, rnw, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s);
+                            };
+                            ops.push_back(op);
+                            Op mp;
+                            mp.cls = 5; mp.flops = 0;
+                            mp.bytes = ((double)nb * h2 * w2 + (double)nb * h4 * w4) * 24 * 4.0;
+                            mp.run = [=](hipStream_t s) { return launch_maxpool(F, nb, h2, w2, fc, MP, s); };
+                            ops.push_back(mp);
+                        }
                     }
                     const float *cur = MP;
                     for (int st = 0; st < 3; ++st) {
@@ -641,42 +667,51 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                         float *t1, *U;
                         SSDCHK(falloc(&t1, (long long)nb * g.ch * g.cw * before.CoutP));
                         SSDCHK(falloc(&U, rows * Dp));
-                        const int rs0 = Dp * 4, rs1 = g.Cc * 4;
+                        float *sb = stage[st];
+                        // producer p's tensor of this chain (0: unit_1's second branch = x, 1: its main branch = y, j: unit j's output)
+                        auto tensor_off = [&](int p) { return g.toff[hf] + (long long)p * g.tbytes[hf]; };
                         // the chain's rows of S start b0 images into the stage output
-                        const long long s_chain = g.soff + (long long)b0 * g.oh * g.ow * rs1;
+                        float *S_chain = sb + g.soff / 4 + (long long)b0 * g.oh * g.ow * 2 * Dp;
                         struct Src { int prod, col; };
                         std::vector<Src> x(D), y(D);
                         for (int d = 0; d < D; ++d) { x[d] = Src{0, d}; y[d] = Src{1, d}; }
-                        std::vector<std::vector<int>> omap(n_units + 1, std::vector<int>(Dp, -1));
-                        auto place = [&](const Src &v, long long off, int physcol, int sel) {
-                            omap[v.prod][ssd_phys_of_logical(v.col)] = (int)(off + (long long)physcol * 4) | sel;
+                        auto table = [&](const std::vector<Src> &v) {      // physical channel p of a D-channel row -> byte offset of its source
+                            std::vector<int> t(Dp, -1);
+                            for (int d = 0; d < D; ++d) t[ssd_phys_of_logical(d)] = (int)(tensor_off(v[d].prod) + (long long)ssd_phys_of_logical(v[d].col) * 4);
+                            return t;
                         };
+                        std::vector<const int *> src_dev(n_units + 1, nullptr);
                         for (int j = 2; j <= n_units; ++j) {
                             std::vector<Src> z(2 * D);
                             for (int d = 0; d < D; ++d) { z[2 * d] = x[d]; z[2 * d + 1] = y[d]; }
-                            for (int k = 0; k < D; ++k) place(z[k], g.xoff[hf] + (long long)(j - 2) * g.xbytes[hf], ssd_phys_of_logical(k), 0);
+                            std::vector<Src> xin(z.begin(), z.begin() + D);
+                            int *dv;
+                            SSDCHK(ap.upload(&dv, table(xin)));
+                            src_dev[j] = dv;
                             for (int d = 0; d < D; ++d) { x[d] = Src{j, d}; y[d] = z[D + d]; }
                         }
-                        for (int c = 0; c < 2 * D; ++c) place(c < D ? x[c] : y[c - D], s_chain, ssd_phys_of_logical(c), 1);
-                        std::vector<const int *> omap_dev(n_units + 1, nullptr);
-                        for (int p = 0; p <= n_units; ++p) {
-                            int *dv;
-                            SSDCHK(ap.upload(&dv, omap[p]));
-                            omap_dev[p] = dv;
-                        }
-                        float *sb = stage[st];
+                        int *ysrc;
+                        SSDCHK(ap.upload(&ysrc, table(y)));          // the stage output's y half (x = unit n's own channels)
                         ops.push_back(make_conv_op(h, before, cur, t1, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU,
                                                    {dense_level(g.ch, g.cw, g.ch, g.cw, before.CoutP)}, true));
-                        ops.push_back(make_dwpws_op(d1, after, t1, nb, g.ch, g.cw, 2, SSD_ACT_NONE, SSD_ACT_RELU, sb, omap_dev[1], g.total, rs0, rs1));
-                        ops.push_back(make_dwpws_op(d2, after2, cur, nb, g.ch, g.cw, 2, SSD_ACT_NONE, SSD_ACT_RELU, sb, omap_dev[0], g.total, rs0, rs1));
+                        ops.push_back(make_dwpws_op(d1, after, t1, nb, g.ch, g.cw, 2, SSD_ACT_NONE, SSD_ACT_RELU, sb + tensor_off(1) / 4));
+                        ops.push_back(make_dwpws_op(d2, after2, cur, nb, g.ch, g.cw, 2, SSD_ACT_NONE, SSD_ACT_RELU, sb + tensor_off(0) / 4));
                         for (int j = 2; j <= n_units; ++j) {
                             const ConvW &b2 = h->pw[g.ipw + 3 + 2 * (j - 2)], &a2 = h->pw[g.ipw + 3 + 2 * (j - 2) + 1];
                             const DwW &dd = h->dw[g.idw + j];
-                            const float *xin = sb + (g.xoff[hf] + (long long)(j - 2) * g.xbytes[hf]) / 4;
-                            ops.push_back(make_conv_op(h, b2, xin, U, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU, {dense_level(g.oh, g.ow, g.oh, g.ow, Dp)}, true));
-                            ops.push_back(make_dwpws_op(dd, a2, U, nb, g.oh, g.ow, 1, SSD_ACT_NONE, SSD_ACT_RELU, sb, omap_dev[j], g.total, rs0, rs1));
+                            ops.push_back(make_pw_gather_op(b2, sb, g.total, src_dev[j], Dp * 4, rows, SSD_ACT_RELU, U));
+                            if (j < n_units) ops.push_back(make_dwpws_op(dd, a2, U, nb, g.oh, g.ow, 1, SSD_ACT_NONE, SSD_ACT_RELU, sb + tensor_off(j) / 4));
+                            else ops.push_back(make_dwpws_op(dd, a2, U, nb, g.oh, g.ow, 1, SSD_ACT_NONE, SSD_ACT_RELU, S_chain, 2 * Dp));
                         }
-                        cur = sb + s_chain / 4;
+                        {
+                            Op gop;
+                            gop.cls = 5; gop.flops = 0; gop.bytes = 2.0 * rows * D * 4.0;
+                            const int rs = Dp * 4, ors = 2 * Dp;
+                            float *ydst = S_chain + Dp;
+                            gop.run = [=](hipStream_t s) { return launch_gather_rows(sb, ysrc, rs, rows, Dp, ydst, ors, s); };
+                            ops.push_back(gop);
+                        }
+                        cur = S_chain;
                     }
                     ops.push_back(make_conv_op(h, c5w, cur, C5 + (long long)b0 * g2.oh * g2.ow * c5w.CoutP, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU,
                                                {dense_level(g2.oh, g2.ow, g2.oh, g2.ow, c5w.CoutP)}, true, 0, X16, 0, FL));
@@ -684,11 +719,11 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 for (int st = 0; st < 2; ++st) {
                     float *S = stage[st] + geo[st].soff / 4;
                     if (st == 0) C3 = S; else C4 = S;
-                    pl.retained[st == 0 ? "c3" : "c4"] = Retained{S, B, geo[st].oh, geo[st].ow, 2 * geo[st].D, geo[st].Cc, true};
+                    pl.retained[st == 0 ? "c3" : "c4"] = Retained{S, B, geo[st].oh, geo[st].ow, 2 * geo[st].D, 2 * geo[st].Dp, true, 0, geo[st].D};
                 }
                 pl.retained["c5"] = Retained{C5, B, g2.oh, g2.ow, c5w.Cout_l, c5w.CoutP, true, X16};
                 for (size_t i = 0; i < std::max(half_ops[0].size(), half_ops[1].size()); ++i)
-                    for (int hf = 0; hf < 2; ++hf)
+                    for (int hf = 0; hf < nhalf; ++hf)
                         if (i < half_ops[hf].size()) {
                             Op op = half_ops[hf][i];
                             op.stream = hf;
@@ -739,70 +774,6 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             const ConvW &before = h->pw[ipw], &after = h->pw[ipw + 1], &after2 = h->pw[ipw + 2];
             const DwW &d1 = h->dw[idw], &d2 = h->dw[idw + 1];
             const int Dp = after.CoutP, D = after.Cout_l;
-            // ---- concat_shuffle_split (shufflenet_v2.py:94-115) and the stage concat (:89) FOLDED into the stores of the
-            // convolutions that produce the channels: every 1x1 of the stage runs on the streaming depthwise+pointwise
-            // kernel, whose epilogue stores channel by channel through a destination map.  A channel is traced from its
-            // producer (unit_1's two branches, or unit j's conv1x1_after) through the shuffles to the ONE place that
-            // consumes it -- input channel k of a later unit's conv1x1_before (buffer X'_u, standard physical position
-            // of k, so that convolution's k order is untouched and the result stays bit-identical), or channel c of the
-            // stage output -- and is written there directly.  No shuffle, split or concat kernel runs.
-            {
-                const int n_units = units[st], Cc = round_up(2 * D, 32);
-                const long long xbytes = rows * Dp * 4, sbytes = rows * Cc * 4;
-                const long long total = xbytes * (n_units - 1) + sbytes;
-                bool ok = sn_fuse && total < (1LL << 31) && (D & 1) == 0 &&
-                          dwpws_eligible(d1, after, B, ch, cwid, 2) && dwpws_eligible(d2, after2, B, ch, cwid, 2);
-                for (int j = 2; ok && j <= n_units; ++j)
-                    ok = dwpws_eligible(h->dw[idw + j], h->pw[ipw + 3 + 2 * (j - 2) + 1], B, oh, ow, 1);
-                if (ok) {
-                    float *stage, *t1, *U;
-                    SSDCHK(falloc(&stage, total / 4));
-                    HIPCHK(hipMemset(stage, 0, (size_t)total));       // pad channels are never written: they stay zero
-                    SSDCHK(falloc(&t1, (long long)B * ch * cwid * before.CoutP));
-                    SSDCHK(falloc(&U, rows * Dp));
-                    // buffer u (2..n) at (u - 2) * xbytes, the stage output at (n - 1) * xbytes
-                    struct Src { int prod, col; };
-                    std::vector<Src> x(D), y(D);
-                    for (int d = 0; d < D; ++d) { x[d] = Src{0, d}; y[d] = Src{1, d}; }      // producer 0: second branch (x), 1: main branch (y)
-                    std::vector<std::vector<int>> omap(n_units + 1, std::vector<int>(Dp, -1));
-                    auto place = [&](const Src &v, long long off, int physcol, int sel) {
-                        omap[v.prod][ssd_phys_of_logical(v.col)] = (int)(off + (long long)physcol * 4) | sel;
-                    };
-                    for (int j = 2; j <= n_units; ++j) {
-                        std::vector<Src> z(2 * D);
-                        for (int d = 0; d < D; ++d) { z[2 * d] = x[d]; z[2 * d + 1] = y[d]; }
-                        for (int k = 0; k < D; ++k) place(z[k], (long long)(j - 2) * xbytes, ssd_phys_of_logical(k), 0);
-                        for (int d = 0; d < D; ++d) { x[d] = Src{j, d}; y[d] = z[D + d]; }
-                    }
-                    const long long soff = (long long)(n_units - 1) * xbytes;
-                    for (int c = 0; c < 2 * D; ++c) place(c < D ? x[c] : y[c - D], soff, ssd_phys_of_logical(c), 1);
-                    std::vector<const int *> omap_dev(n_units + 1, nullptr);
-                    for (int p = 0; p <= n_units; ++p) {
-                        int *dv;
-                        SSDCHK(ap.upload(&dv, omap[p]));
-                        omap_dev[p] = dv;
-                    }
-                    const int rs0 = Dp * 4, rs1 = Cc * 4;
-                    pl.ops.push_back(make_conv_op(h, before, cur, t1, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
-                                                  {dense_level(ch, cwid, ch, cwid, before.CoutP)}, true));
-                    pl.ops.push_back(make_dwpws_op(d1, after, t1, B, ch, cwid, 2, SSD_ACT_NONE, SSD_ACT_RELU, stage, omap_dev[1], total, rs0, rs1));
-                    pl.ops.push_back(make_dwpws_op(d2, after2, cur, B, ch, cwid, 2, SSD_ACT_NONE, SSD_ACT_RELU, stage, omap_dev[0], total, rs0, rs1));
-                    for (int j = 2; j <= n_units; ++j) {
-                        const ConvW &b2 = h->pw[ipw + 3 + 2 * (j - 2)], &a2 = h->pw[ipw + 3 + 2 * (j - 2) + 1];
-                        const DwW &dd = h->dw[idw + j];
-                        const float *xin = stage + (long long)(j - 2) * (xbytes / 4);
-                        pl.ops.push_back(make_conv_op(h, b2, xin, U, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU, {dense_level(oh, ow, oh, ow, Dp)}, true));
-                        pl.ops.push_back(make_dwpws_op(dd, a2, U, B, oh, ow, 1, SSD_ACT_NONE, SSD_ACT_RELU, stage, omap_dev[j], total, rs0, rs1));
-                    }
-                    float *S = stage + soff / 4;
-                    if (st == 0) { C3 = S; pl.retained["c3"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
-                    if (st == 1) { C4 = S; pl.retained["c4"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
-                    ipw += 3 + 2 * (n_units - 1); idw += 2 + (n_units - 1);
-                    cur = S;
-                    ch = oh; cwid = ow;
-                    continue;
-                }
-            }
             ipw += 3; idw += 2;
             float *t1, *t2, *t3, *Xa, *Xb, *Ya, *Yb, *U, *V;
             SSDCHK(falloc(&t1, (long long)B * ch * cwid * before.CoutP));
@@ -840,8 +811,8 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 float *oldy = y;
                 y = ys; ys = oldy;
             }
-            // concat([x, y]) -> stage output
-            const int Cc = round_up(2 * D, 32);
+            // concat([x, y]) -> stage output in two-part rows [x half | y half] (weights.hip)
+            const int Cc = 2 * Dp;
             float *S;
             SSDCHK(falloc(&S, rows * Cc));
             {
@@ -851,8 +822,8 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 g.run = [=](hipStream_t s) { return launch_gather_channels(cx, Dp, cy, Dp, rows, tabc, Cc, S, s); };
                 pl.ops.push_back(g);
             }
-            if (st == 0) { C3 = S; pl.retained["c3"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
-            if (st == 1) { C4 = S; pl.retained["c4"] = Retained{S, B, oh, ow, 2 * D, Cc, true}; }
+            if (st == 0) { C3 = S; pl.retained["c3"] = Retained{S, B, oh, ow, 2 * D, Cc, true, 0, D}; }
+            if (st == 1) { C4 = S; pl.retained["c4"] = Retained{S, B, oh, ow, 2 * D, Cc, true, 0, D}; }
             cur = S;
             ch = oh; cwid = ow;
         }

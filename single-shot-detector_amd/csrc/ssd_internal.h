@@ -137,11 +137,8 @@ struct DwPwSArgs {
     const float *dwpack;                   // [K/32][12][32]: per slice 9 taps, mean, sf, beta of the depthwise layer
     const float *wt;                       // [wt_rows][K] pointwise weights (igemm B layout, taps = 1), wt_rows >= Cout
     const float *mean, *sf, *beta;         // [>= Cout] pointwise batch norm
-    float *out;                            // base of the destination(s)
-    const int *omap;                       // nullable: per physical output channel n < Cout the byte offset of that channel in
-                                           // row 0 relative to `out` (a multiple of 4) | row-stride selector in bit 0 (rs0 / rs1),
-                                           // or -1 = not stored.  Null: dense [M][Cout] output.
-    int rs0, rs1;                          // omap: the two row strides in bytes
+    float *out;                            // dense rows [M][out_rs]; channels [0, Cout) of a row are written
+    int out_rs;                            // floats between consecutive output rows (>= Cout)
     int B, H, W, K, OH, OW, Cout, wt_rows; // Cout: physical output channels (incl. pad channels inside octets)
     int pad;                               // depthwise pad_beg (1 for stride 1, 0 for stride 2 on even sizes)
     int dact, act;                         // activation after the depthwise / the pointwise batch norm
@@ -153,6 +150,25 @@ struct DwPwSArgs {
 int dwpws_tile_m(int stride);
 int dwpws_tile_n(int stride, int CoutP);
 hipError_t launch_dwpw_stream(int stride, const DwPwSArgs &a, hipStream_t s);
+
+// 1x1 convolution whose input rows are gathered from several dense producer tensors (sn_pw.hip: ShuffleNet's
+// conv1x1_before with concat_shuffle_split folded into its loads) ------------------------------------------------------
+struct PwGArgs {
+    const float *base;                     // one allocation that holds every source row
+    int base_bytes;                        // its extent (< 2 GiB): the buffer range of the gather
+    const int *src;                        // [K] device table: byte offset (a multiple of 4, relative to `base`) of physical input
+                                           // channel k in row 0 of its producer tensor, or -1 = a zero channel
+    int rs;                                // bytes between consecutive rows (positions) of every producer tensor
+    const float *wt;                       // [wt_rows][K] weights (igemm B layout, taps = 1), wt_rows >= Cout
+    const float *mean, *sf, *beta;         // [>= Cout] batch norm
+    float *out;                            // dense rows [M][out_rs]; channels [0, Cout) of a row are written
+    int out_rs, out_bytes;                 // floats between rows; extent of the destination from `out`
+    int M, K, Cout, wt_rows, act;          // rows, physical input channels (K % 32 == 0), physical output channels (% 4 == 0)
+    int m_tiles, n_tiles;                  // ceil(M / 64), ceil(Cout / pw_gather_tile_n(Cout))
+};
+int pw_gather_tile_n(int CoutP);
+bool pw_gather_supports(int K, int CoutP, long long M, int rs, long long base_bytes, long long out_bytes);
+hipError_t launch_pw_gather(const PwGArgs &a, hipStream_t s);
 
 // depthwise -> pointwise in the latency form (dwpw_lat.hip, batch 1-2): the four-wave block of igemm_lat.hip whose position
 // operand is produced by the depthwise arithmetic instead of loaded --------------------------------------------------
@@ -209,7 +225,9 @@ hipError_t launch_gather_channels(const float *x, int xs, const float *y, int ys
 // to_phys: 0 physical fp32 -> logical, 1 logical -> physical fp32,
 //          2 physical S16 -> logical fp32, 3 logical fp32 -> physical S16
 hipError_t launch_permute_channels(const float *in, long long rows, int C, int Cpad, int to_phys, float *out,
-                                   hipStream_t s);
+                                   hipStream_t s, int split = 0 /* to_phys = 0: two-part physical rows, first part `split` logical channels */);
+// out[r][c] = base[r * rs + src[c]] (byte offsets, src[c] < 0: 0), c < Cw: rows gathered from several dense tensors of one allocation
+hipError_t launch_gather_rows(const float *base, const int *src, int rs, long long rows, int Cw, float *out, int ors, hipStream_t s);
 
 // post-processing ------------------------------------------------------------------------
 struct PostArgs {

@@ -24,6 +24,17 @@ std::vector<int> ident_map(int C, int Cp)
     return m;
 }
 
+std::vector<int> twopart_map(int D, int Dp)
+{
+    std::vector<int> m(2 * Dp, -1);
+    for (int part = 0; part < 2; ++part)
+        for (int p = 0; p < Dp; ++p) {
+            const int l = ssd_logical_of_phys(p);
+            if (l < D) m[part * Dp + p] = part * D + l;
+        }
+    return m;
+}
+
 // batch_norm_relu (layer_utils.py:5-12): sf = gamma * rsqrt(var + 1e-3)
 static void bn_pack(const float *gamma, const float *beta, const float *mean, const float *var,
                     const std::vector<int> &outmap, BnHost &o)
@@ -171,12 +182,13 @@ static int get_bn(ssd_handle *h, const std::string &scope, int C, const std::vec
 }
 
 // dense conv + optional BN, standard physical maps on both sides
+// (in_split > 0: the input is a ShuffleNet stage output in two-part rows, in_split channels per half)
 static int load_conv(ssd_handle *h, const std::string &wname, const std::string &bnscope, int k, int Cin, int Cout,
-                     ConvW &cw, bool out_identity = false)
+                     ConvW &cw, bool out_identity = false, int in_split = 0)
 {
     const Tensor *w = getvar(h, wname, {k, k, Cin, Cout});
     if (!w) return SSD_ERR_WEIGHT;
-    std::vector<int> inmap = phys_map(Cin, round_up(Cin, 32));
+    std::vector<int> inmap = in_split > 0 ? twopart_map(in_split, round_up(in_split, 32)) : phys_map(Cin, round_up(Cin, 32));
     std::vector<int> outmap = out_identity ? ident_map(Cout, Cout) : phys_map(Cout, round_up(Cout, 32));
     SSDCHK(pack_conv(h, h->wpool, w->data.data(), k, Cin, Cout, inmap, outmap, cw));
     if (!bnscope.empty()) {
@@ -187,12 +199,12 @@ static int load_conv(ssd_handle *h, const std::string &wname, const std::string 
     return SSD_OK;
 }
 
-static int load_dw(ssd_handle *h, const std::string &scope, const std::string &bnname, int C, DwW &d)
+static int load_dw(ssd_handle *h, const std::string &scope, const std::string &bnname, int C, DwW &d, int in_split = 0)
 {
     const Tensor *w = getvar(h, scope + "/depthwise_weights", {3, 3, C, 1});
     if (!w) return SSD_ERR_WEIGHT;
-    d.Cp = round_up(C, 32);
-    std::vector<int> map = phys_map(C, d.Cp);
+    d.Cp = in_split > 0 ? 2 * round_up(in_split, 32) : round_up(C, 32);
+    std::vector<int> map = in_split > 0 ? twopart_map(in_split, round_up(in_split, 32)) : phys_map(C, d.Cp);
     std::vector<float> t((size_t)9 * d.Cp, 0.0f);
     for (int tap = 0; tap < 9; ++tap)
         for (int p = 0; p < d.Cp; ++p)
@@ -275,21 +287,26 @@ static int finalize_shufflenet(ssd_handle *h)
     SSDCHK(load_first(h, "ShuffleNetV2/Conv1", "batch_norm", 24));
     h->firstAct = SSD_ACT_RELU;
     const int units[3] = {4, 8, 4};
-    int cin = 24, out = D0;
+    // A stage's output is kept in TWO-PART rows [x half | y half], each half (D channels) in its own standard layout over Dp
+    // physical channels: the last unit's conv1x1_after then stores its channels as one dense run per position (plan.hip), and
+    // the stage's consumers -- the next stage's unit_1 (conv1x1_before, second_branch depthwise + conv1x1_after), the FPN
+    // lateral, Conv5 -- get their weights packed for that layout here.  Their k-ordered accumulation still visits the
+    // logical channels in ascending order (the pad channels of the x half, zeros, sit between 2 D - 1's halves).
+    int cin = 24, out = D0, split = 0;          // split: channels per half of this stage's input rows (0: standard rows)
     for (int st = 0; st < 3; ++st) {
         const int D = out / 2;
         char base[64];
         snprintf(base, sizeof base, "ShuffleNetV2/Stage%d", st + 2);
         std::string u1 = std::string(base) + "/unit_1";
         ConvW cw; DwW d;
-        SSDCHK(load_conv(h, u1 + "/conv1x1_before/weights", u1 + "/conv1x1_before/batch_norm", 1, cin, cin, cw)); h->pw.push_back(cw);
+        SSDCHK(load_conv(h, u1 + "/conv1x1_before/weights", u1 + "/conv1x1_before/batch_norm", 1, cin, cin, cw, false, split)); h->pw.push_back(cw);
         SSDCHK(load_dw(h, u1 + "/depthwise", "batch_norm", cin, d)); h->dw.push_back(d);
         cw = ConvW();
         SSDCHK(load_conv(h, u1 + "/conv1x1_after/weights", u1 + "/conv1x1_after/batch_norm", 1, cin, D, cw)); h->pw.push_back(cw);
         d = DwW();
-        SSDCHK(load_dw(h, u1 + "/second_branch/depthwise", "batch_norm", cin, d)); h->dw.push_back(d);
+        SSDCHK(load_dw(h, u1 + "/second_branch/depthwise", "batch_norm", cin, d, split)); h->dw.push_back(d);
         cw = ConvW();
-        SSDCHK(load_conv(h, u1 + "/second_branch/conv1x1_after/weights", u1 + "/second_branch/conv1x1_after/batch_norm", 1, cin, D, cw)); h->pw.push_back(cw);
+        SSDCHK(load_conv(h, u1 + "/second_branch/conv1x1_after/weights", u1 + "/second_branch/conv1x1_after/batch_norm", 1, cin, D, cw, false, split)); h->pw.push_back(cw);
         for (int j = 2; j <= units[st]; ++j) {
             std::string u = std::string(base) + "/unit_" + std::to_string(j);
             cw = ConvW();
@@ -300,7 +317,7 @@ static int finalize_shufflenet(ssd_handle *h)
             SSDCHK(load_conv(h, u + "/conv1x1_after/weights", u + "/conv1x1_after/batch_norm", 1, D, D, cw)); h->pw.push_back(cw);
         }
         // gather tables for this stage: shuffle (two outputs) and final concat
-        const int Dp = round_up(D, 32), Cc = round_up(2 * D, 32);
+        const int Dp = round_up(D, 32), Cc = 2 * Dp;
         std::vector<int> tx(2 * Dp, -1), ty(2 * Dp, -1), tc(2 * Cc, -1);
         for (int p = 0; p < Dp; ++p) {
             const int j = ssd_logical_of_phys(p);
@@ -309,23 +326,23 @@ static int finalize_shufflenet(ssd_handle *h)
             tx[2 * p] = zx & 1; tx[2 * p + 1] = ssd_phys_of_logical(zx >> 1);
             ty[2 * p] = zy & 1; ty[2 * p + 1] = ssd_phys_of_logical(zy >> 1);
         }
-        for (int p = 0; p < Cc; ++p) {
-            const int j = ssd_logical_of_phys(p);
-            if (j >= 2 * D) continue;
-            tc[2 * p] = j < D ? 0 : 1;
-            tc[2 * p + 1] = ssd_phys_of_logical(j < D ? j : j - D);
+        for (int p = 0; p < Cc; ++p) {          // two-part rows: the concat copies the halves side by side
+            if (ssd_logical_of_phys(p % Dp) >= D) continue;
+            tc[2 * p] = p / Dp;
+            tc[2 * p + 1] = p % Dp;
         }
         int *dx, *dy, *dc;
         SSDCHK(h->wpool.upload(&dx, tx)); SSDCHK(h->wpool.upload(&dy, ty)); SSDCHK(h->wpool.upload(&dc, tc));
         h->tabs.push_back(dx); h->tabs.push_back(dy); h->tabs.push_back(dc);
         cin = out;
-        if (st == 0) h->c_ch[0] = out;
-        if (st == 1) h->c_ch[1] = out;
+        split = D;
+        if (st == 0) { h->c_ch[0] = out; h->c_split[0] = D; }
+        if (st == 1) { h->c_ch[1] = out; h->c_split[1] = D; }
         out *= 2;
     }
     const int fin = h->cfg.depth_multiplier == 2.0f ? 2048 : 1024;
     ConvW cw;
-    SSDCHK(load_conv(h, "ShuffleNetV2/Conv5/weights", "ShuffleNetV2/Conv5/batch_norm", 1, cin, fin, cw));
+    SSDCHK(load_conv(h, "ShuffleNetV2/Conv5/weights", "ShuffleNetV2/Conv5/batch_norm", 1, cin, fin, cw, false, split));
     h->pw.push_back(cw);
     h->c_ch[2] = fin;
     return SSD_OK;
@@ -337,7 +354,7 @@ static int finalize_fpn_heads(ssd_handle *h)
     for (int i = 0; i < 3; ++i) {
         char n[48];
         snprintf(n, sizeof n, "fpn/lateral%d/kernel", i + 3);
-        SSDCHK(load_conv(h, n, "", 1, h->c_ch[i], 256, h->lat[i]));
+        SSDCHK(load_conv(h, n, "", 1, h->c_ch[i], 256, h->lat[i], false, h->c_split[i]));
     }
     for (int i = 0; i < 5; ++i) {
         char n[48], b[48];
