@@ -229,6 +229,95 @@ class Timed:
         return dt, out, prof
 
 
+def _sysfs_probe(device):
+    """(read_mhz, read_watts) callables on the HIP device's sysfs files (shader clock level marked '*' in pp_dpm_sclk, socket
+    power in W), or None where the file is not readable by this user."""
+    import glob
+    import re
+    try:
+        pr = torch.cuda.get_device_properties(device)
+        base = "/sys/bus/pci/devices/%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        return None, None
+
+    def first(pattern):
+        for q in sorted(glob.glob(pattern)):
+            try:
+                open(q).read()
+                return q
+            except OSError:
+                pass
+        return None
+    sclk = first(base + "/pp_dpm_sclk")
+    power = first(base + "/hwmon/hwmon*/power1_average") or first(base + "/hwmon/hwmon*/power1_input")
+
+    def mhz():
+        m = re.search(r"(\d+)Mhz \*", open(sclk).read())
+        return int(m.group(1)) if m else None
+
+    def watts():
+        return int(open(power).read()) / 1e6
+    return (mhz if sclk else None), (watts if power else None)
+
+
+def sustained_leg(step, images_per_step, device, seconds, window=5.0):
+    """Back-to-back steps for `seconds` of wall clock (the headline's 20 steps are 0.8 s of GPU work on a 1.2 kW part with
+    DVFS give-back): img/s over the first and the last `window` seconds from per-step events on the compute stream, shader
+    clock / socket power (sysfs, 10 samples per second) over the same two windows."""
+    import threading
+    read_mhz, read_w = _sysfs_probe(device)
+    samples, stop = [], [False]
+
+    def sampler():
+        while not stop[0]:
+            t = time.perf_counter()
+            try:
+                samples.append((t, read_mhz() if read_mhz else None, read_w() if read_w else None))
+            except (OSError, ValueError):
+                pass
+            time.sleep(0.1)
+    torch.cuda.synchronize(device)
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    evs = [torch.cuda.Event(enable_timing=True)]
+    evs[0].record()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        step()
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        evs.append(e)
+        if len(evs) > 8:
+            evs[-8].synchronize()            # bounded queue: the host stays at most 8 steps ahead
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    stop[0] = True
+    th.join()
+    ts = [0.0] + [evs[0].elapsed_time(e) * 1e-3 for e in evs[1:]]          # seconds since the first event, per finished step
+    total_s, n = ts[-1], len(ts) - 1
+
+    def rate(lo, hi):
+        k = [i for i in range(1, len(ts)) if lo < ts[i] <= hi]
+        if len(k) < 2:
+            return None
+        return images_per_step * (k[-1] - k[0]) / (ts[k[-1]] - ts[k[0]])
+
+    def med(vals):
+        v = sorted(x for x in vals if x is not None)
+        return v[len(v) // 2] if v else None
+
+    def sysfs(lo, hi):
+        w = [sm for sm in samples if lo <= sm[0] - t0 <= hi]
+        return {"sclk_mhz_median": med(x[1] for x in w), "power_w_median": med(x[2] for x in w), "samples": len(w)}
+    first, last = rate(0.0, window), rate(total_s - window, total_s)
+    return {"seconds": total_s, "steps": n, "img_s": images_per_step * n / total_s,
+            "img_s_first_%ds" % window: first, "img_s_last_%ds" % window: last,
+            "ratio_last_to_first": (last / first) if first and last else None,
+            "sysfs_first_%ds" % window: sysfs(0.0, window), "sysfs_last_%ds" % window: sysfs(t1 - t0 - window, t1 - t0),
+            "note": "same step as `value`, enqueued back to back (host at most 8 steps ahead), no profiling; `value` stays the "
+                    "K-step number of the contract"}
+
+
 def shufflenet_leg(local, timed, steps, warmup, batch):
     """BASELINE config 4: ShuffleNet-v2 + FPN (config_shufflenet.json), 640x640, batch 64, one GPU."""
     Wt = ssd_amd.synthetic_weights(PARAMS_SHUFFLE, seed=0, logits_bias=LOGITS_BIAS["shufflenet"])
@@ -287,6 +376,8 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-shufflenet", action="store_true", help="skip the config-4 object (N = 1 only anyway)")
     ap.add_argument("--no-other-precision", action="store_true")
+    ap.add_argument("--sustained-seconds", type=float, default=30.0,
+                    help="length of the sustained-rate leg (N = 1 only; 0 skips it): back-to-back steps, img/s of the first and last 5 s")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
                     help="a kernel / schedule selector of the library for this run (ssd_set_option, include/ssd_hip.h; A/B runs: "
                          "scripts/ab_opt.sh); none changes a result bit in mode f32")
@@ -385,6 +476,9 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
         return v
 
     status_value = status_all_ranks()
+    sustained = None
+    if world == 1 and not use_dist and not stub and args.sustained_seconds > 0:
+        sustained = sustained_leg(step, total, dev, args.sustained_seconds)
 
     # the same workload in the other precision mode, same process, same frames (shorter run)
     other = "f32" if args.precision == "f16x3" else "f16x3"
@@ -463,6 +557,8 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
                                              "the compute of batch k"}
             # 1.113 ms/img at the per-layer roofline of the exact-fp32 arithmetic
             res["whole_net_roofline_frac"] = ROOFLINE_MS[net] * (hi - lo) / ms_step if args.precision == "f32" else None
+            if sustained:
+                res["sustained"] = sustained
             if other_res:
                 res["other_precision"] = other_res
             if not args.no_latency:

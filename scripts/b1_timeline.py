@@ -16,7 +16,7 @@ if len(ends) < back + 1:
     sys.exit("not enough forwards in the trace")
 hi = ends[-back]
 lo = ends[-back - 1] + 1
-while lo < hi and "first_conv" not in rows[lo][2] and "front_kernel" not in rows[lo][2]:
+while lo < hi and "first_conv" not in rows[lo][2] and "front_kernel" not in rows[lo][2] and "front_pool" not in rows[lo][2]:
     lo += 1
 fw = rows[lo:hi + 1]
 t0 = fw[0][0]
