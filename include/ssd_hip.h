@@ -98,44 +98,40 @@ const char *ssd_last_error(void);
  * takes its mode from the environment variable SSD_PRECISION ("f32" | "f16x3"), default f32. */
 int ssd_set_precision(ssd_handle *h, int32_t mode /* SSD_PRECISION_* */);
 int ssd_get_precision(ssd_handle *h);
-/* Tuning / test switches.  None changes a result bit in mode F32 (each selects among kernels or schedules that are
- * bit-identical by construction and by test); the library reads NO environment variable for them (SSD_PRECISION above is
- * the only one it reads).  `h` == NULL sets the process-wide value, which the handle-less stage entry points below use and
- * which a handle falls back to for an option it has not been given itself; with a handle the call synchronises and drops
- * the cached layer plan.  Keys (value; default):
- *   "igemm_tile"      0 auto | 128 | 64 pin the tile of the 128x128-class launches | 20..32 pin a tile of the latency form
- *                     wherever that form applies: 20..23 one wave per block (1x1, 1x2, 2x1, 2x2 sixteen-wide units), 24..27
- *                     two / four waves per block sharing the positions through LDS, 28..32 the one-accumulator wave with its
- *                     K-step interleaved (4 / 8 / 16 K-steps of operands in flight; 31, 32: channel-tile-major order) (0)
- *   "lat_one"         30 | 20 | 28..32: the one-wave tile the plan gives its tiny launches (fpn p6, lateral5)  (30)
+/* Options.  None changes a result bit in mode F32 (each selects among kernels or schedules that are bit-identical by
+ * construction and by test); the library reads NO environment variable for them (SSD_PRECISION above is the only one it
+ * reads).  `h` == NULL sets the process-wide value, which the handle-less stage entry points below use and which a handle
+ * falls back to for an option it has not been given itself; with a handle the call synchronises and drops the cached layer
+ * plan.  Keys (value; default).
+ * Selectors a caller may want:
+ *   "streams"         0 auto | 1: every kernel of a forward on the caller's stream, in plan order            (0)
+ *   "h2d_chunks"      2 | 1..16: pieces of ssd_forward_host's staging copy + upload                           (2)
  *   "front_fuse"      -1 auto | 0 | 1: the backbone's first layers as one launch (front.hip): MobileNet's first
- *                     convolution + Conv2d_1, ShuffleNet's first convolution + max pool                   (-1)
+ *                     convolution + Conv2d_1, ShuffleNet's first convolution + max pool                       (-1)
+ *   "fuse_dw"         -1 default | bit mask of depthwise+pointwise pairs that run as one launch (MobileNet: bit i =
+ *                     Conv2d_{i+1}; ShuffleNet: non-zero = every unit)                                        (-1)
+ *   "backbone_split"  0 auto | 1 .. 4 (ShuffleNet: 1 | 2): backbone chains (two half-batch chains on two streams from 4 images on) (0)
+ *   "event_fence"     0 | 1: the library's stream-ordering events with the default flags (system-scope fence per record) (0)
+ * Test hooks -- they pin a kernel variant or a plan shape so that the parity tests see every shape on it:
+ *   "igemm_tile"      0 auto | 128 | 64 pin the tile of the 128x128-class launches | 20..27 pin a tile of the latency form
+ *                     wherever that form applies: 20..23 one wave per block (1x1, 1x2, 2x1, 2x2 sixteen-wide units), 24..27
+ *                     two / four waves per block sharing the positions through LDS                            (0)
  *   "igemm_lat"       1 | 0: small exact-fp32 launches on the latency form (v_mfma_f32_16x16x4_f32) | 2: ... and 1x1 launches
  *                     up to 1 280 tiles | 3: as 1 without fpn p6 / p7 of the serving batches                  (1)
- *   "igemm_deep64"    -1 auto | 0 | 1: 64x64 tiles with operand loads three K-steps ahead                (-1)
- *   "streams"         0 auto | 1: every kernel of a forward on one stream, in plan order | 2: the internal streams at the
- *                     highest priority (a hardware-queue pool of their own)                  (0)
- *   "fpn_group"       -1 auto | 0 | 1: fpn p3 + p4 + p5 as one grouped launch (batch 1, F32)             (-1)
- *   "tower_group"     0 | 1: layer i of the box and the class tower as one launch over 2 x 5 levels      (0)
- *   "head_serial"     -1 auto | 0 | 1: the box head behind the class logits instead of beside them       (-1)
- *   "side_priority"   0 | 1 | 2: the streams of fpn p6 / p7 at the lowest / highest dispatch priority    (0)
- *   "fpn_p6_first"    3: fpn p6 (-> p7) on the caller's stream, the lateral chain beside them (batch <= 2) | 0: p6 -> p7 on the
- *                     third stream | 1 | 2: ... and the grouped fpn launch waits for p6 / for p7 | 4: p7 beside the grouped launch (3)
- *   "fpn_p7_group"    1 | 0: fpn p7 as a fourth level of the grouped p3 + p4 + p5 launch (batch <= 2, F32)   (1)
+ *   "igemm_deep64"    -1 auto | 0 | 1: 64x64 tiles with operand loads three K-steps ahead                     (-1)
+ *   "igemm16"         -1 auto | 0 | 1: F16X3 launches on the 256x256-tile kernel                              (-1)
+ *   "igemm_96"        1 | 0: 128x96 tiles for widths 96 divides and 128 does not (read by ssd_finalize)       (1)
+ *   "lateral_split"   1 | 0: F16X3 laterals split fp32 rows while staging them                                (1)
+ *   "fpn_group"       -1 auto | 0 | 1: fpn p3 + p4 + p5 as one grouped launch (batch <= 2, F32)               (-1)
+ *   "fpn_p7_group"    1 | 0: fpn p7 as a fourth level of that launch                                          (1)
  *   "fpn_early_lat"   -1 auto | 0 | 1: lateral3 / lateral4 early, their top-down sums as one elementwise launch (batch <= 2) (-1)
- *   "dwpw_lat"        0 | 1 | 2 | 4: MobileNet Conv2d_5..13 depthwise + pointwise pairs as one latency-form launch (dwpw_lat.hip) (0)
- *   "event_fence"     0 | 1: the library's stream-ordering events with the default flags (system-scope fence per record) (0)
- *   "igemm16"         -1 auto | 0 | 1: F16X3 launches on the 256x256-tile kernel                         (-1)
- *   "igemm_96"        1 | 0: 128x96 tiles for widths 96 divides and 128 does not (read by ssd_finalize)  (1)
- *   "lateral_split"   1 | 0: F16X3 laterals split fp32 rows while staging them                           (1)
- *   "backbone_split"  0 auto | 1..4: MobileNet backbone chains                                           (0)
- *   "nsub"            0 auto | 1..8: staggered sub-batch plans                                            (0)
- *   "level_split"     0 | 1 | 2: head towers of levels 6-7 as launches of their own (batch <= 2): every layer / the first (0)
- *   "nms_fast_max"    -1 default | n >= 0: candidate lists up to n stay in one wave's registers          (-1)
- *   "h2d_chunks"      2 | 1..16: pieces of ssd_forward_host's staging copy + upload                       (2)
- *   "fuse_dw"         -1 default | bit mask of depthwise+pointwise pairs that run as one launch          (-1)
- *   "graph"           0 | 1: hipGraph replay of a repeating forward                                      (0)
- *   "debug_sync"      0 | 1: announce every op on stderr, run it alone, wait for it, print its time      (0)
+ *   "nsub"            0 auto | 1..8: at least this many consecutive sub-batch plans (the split a batch whose tensors would
+ *                     pass 2 GiB takes)                                                                        (0)
+ *   "nms_fast_max"    -1 default | n >= 0: candidate lists up to n stay in one wave's registers               (-1)
+ *   "debug_sync"      0 | 1: announce every op on stderr, run it alone, wait for it, print its time           (0)
+ * (Rounds 1-4 carried more switches -- schedule experiments that measured equal or slower: tower_group, head_serial,
+ *  side_priority, level_split, fpn_p6_first, lat_one, dwpw_lat, graph, staggered sub-batch plans.  They are out of the library;
+ *  scripts/experiments/README.md has what each measured and the commit that holds its source.)
  * ssd_get_option returns the value in effect (handle, else process), INT32_MIN when neither was set. */
 int ssd_set_option(ssd_handle *h, const char *key, int32_t value);
 int ssd_get_option(ssd_handle *h, const char *key, int32_t *value);

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SOURCES = ["abi.hip", "weights.hip", "plan.hip", "stages.hip", "igemm.hip", "igemm_lat.hip", "igemm16.hip", "dwpw_stream.hip", "sn_pw.hip", "dwpw_lat.hip", "front.hip",
+_SOURCES = ["abi.hip", "weights.hip", "plan.hip", "stages.hip", "igemm.hip", "igemm_lat.hip", "igemm16.hip", "dwpw_stream.hip", "sn_pw.hip", "front.hip",
             "elementwise.hip", "postprocess.hip"]
 _LIB_PATH = os.path.join(_CSRC, "libssd_hip.so")
 _DIAG_PATH = os.path.join(_CSRC, "libssd_hip_diag.so")       # -DSSD_DIAG build, scripts/ only

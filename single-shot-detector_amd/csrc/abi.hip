@@ -16,8 +16,9 @@ extern "C" const char *ssd_last_error(void) { return g_err.c_str(); }
 // ----------------------------------------------------------------------------- options
 static Options g_opts;                 // process-wide values (ssd_set_option with a NULL handle)
 static std::mutex g_opts_mu;
-static const char *const OPT_NAMES[OPT_COUNT] = {"igemm_tile", "igemm16", "igemm_96", "lateral_split", "backbone_split", "nsub",
-                                                 "level_split", "nms_fast_max", "debug_sync", "fuse_dw", "graph", "igemm_lat", "igemm_deep64", "streams", "fpn_group", "head_serial", "side_priority", "tower_group", "fpn_p6_first", "dwpw_lat", "fpn_early_lat", "h2d_chunks", "fpn_p7_group", "event_fence", "lat_one", "front_fuse"};
+static const char *const OPT_NAMES[OPT_COUNT] = {"streams", "h2d_chunks", "front_fuse", "fuse_dw", "backbone_split", "event_fence",
+                                                 "igemm_tile", "igemm16", "igemm_96", "igemm_lat", "igemm_deep64", "lateral_split", "fpn_group", "fpn_p7_group",
+                                                 "fpn_early_lat", "nsub", "nms_fast_max", "debug_sync"};
 int ssd_opt_index(const char *key)
 {
     for (int i = 0; i < OPT_COUNT; ++i)
@@ -44,16 +45,12 @@ int nms_fast_max(const ssd_handle *h)
     return v < 0 ? 0 : (v == 0 ? -1 : v);
 }
 
-// The handle's own ordering events (sub-batch start, graph replay in / out, previous forward) with the flags the handle's
-// options ask for; called by ssd_create and again when option event_fence changes on the handle (device idle, plans freed).
+// The handle's own ordering event (previous forward on another stream) with the flags the handle's options ask for; called by
+// ssd_create and again when option event_fence changes on the handle (device idle, plans freed).
 static int make_handle_events(ssd_handle *h)
 {
-    hipEvent_t *evs[4] = {&h->ev_start, &h->ev_gin, &h->ev_gout, &h->ev_last};
-    const unsigned evf = ssd_sync_event_flags(h);
-    for (hipEvent_t *e : evs) {
-        if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
-        HIPCHK(hipEventCreateWithFlags(e, evf));
-    }
+    if (h->ev_last) { (void)hipEventDestroy(h->ev_last); h->ev_last = nullptr; }
+    HIPCHK(hipEventCreateWithFlags(&h->ev_last, ssd_sync_event_flags(h)));
     h->have_last = false;           // (ev_last is new: nothing is recorded in it; the device is idle)
     return SSD_OK;
 }
@@ -100,7 +97,7 @@ extern "C" int ssd_create(const ssd_config *cfg, ssd_handle **out)
     ssd_handle *h = new ssd_handle();
     h->cfg = *cfg;
     if (make_handle_events(h) != SSD_OK) {
-        for (hipEvent_t e : {h->ev_start, h->ev_gin, h->ev_gout, h->ev_last}) if (e) (void)hipEventDestroy(e);
+        if (h->ev_last) (void)hipEventDestroy(h->ev_last);
         delete h;
         return ssd_fail(SSD_ERR_HIP, "ssd_create: cannot create events");
     }
@@ -158,11 +155,7 @@ extern "C" void ssd_destroy(ssd_handle *h)
     for (auto r : h->ref_evs) (void)hipEventDestroy(r);
     for (auto r : h->ev_pool) (void)hipEventDestroy(r);
     free_plans(h);
-    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
-    if (h->ev_gin) (void)hipEventDestroy(h->ev_gin);
-    if (h->ev_gout) (void)hipEventDestroy(h->ev_gout);
     if (h->ev_last) (void)hipEventDestroy(h->ev_last);
-    if (h->gstream) (void)hipStreamDestroy(h->gstream);
     if (h->stage_pin) (void)hipHostFree(h->stage_pin);
     if (h->stage_dev) (void)hipFree(h->stage_dev);
     if (h->flags_dev) (void)hipFree(h->flags_dev);
@@ -232,45 +225,9 @@ static int forward_locked(ssd_handle *h, const uint8_t *images_dev, int32_t B, i
         }
         h->have_last = false;
     }
-    // hipGraph replay (launch-bound regime: batch 1 is ~35 short kernels on a few streams).  A
-    // forward whose pointers, shape and stream repeat is captured on the handle's own stream at
-    // its second occurrence and replayed from then on; profiling or option graph = 0 keep it eager.
-    // Measured (batch 1, 640x896): replay 2.49 ms vs eager 2.33 ms p50 -- the forward is GPU-bound
-    // (host enqueue 0.9 ms < 2.3 ms of kernels), so replay is OFF unless option graph = 1.
-    const bool use_graph = ssd_opt(h, OPT_GRAPH, 0) != 0 && !h->capture_broken;
-    if (!use_graph || h->profiling || h->plans.size() != 1)
-        return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, out_stride, s);
-    if (!h->gstream) HIPCHK(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));    // (only a handle that replays graphs has one)
-    GraphKey key{images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, B, H, W, out_stride};
-    hipGraphExec_t exec = nullptr;
-    for (auto &g : h->graphs)
-        if (g.first == key) exec = g.second;
-    if (!exec) {
-        if (!(h->last_key == key)) {             // first sighting: run eagerly (lazy one-time inits happen here)
-            h->last_key = key;
-            return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, out_stride, s);
-        }
-        hipGraph_t graph = nullptr;
-        HIPCHK(hipStreamBeginCapture(h->gstream, hipStreamCaptureModeRelaxed));
-        int rc = enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, out_stride, h->gstream);
-        hipError_t ce = hipStreamEndCapture(h->gstream, &graph);
-        if (rc != SSD_OK || ce != hipSuccess || !graph) {
-            if (graph) (void)hipGraphDestroy(graph);
-            (void)hipGetLastError();
-            h->capture_broken = true;            // capture unsupported here: stay eager from now on
-            return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, out_stride, s);
-        }
-        HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(graph);
-        if (h->graphs.size() >= 4) { (void)hipGraphExecDestroy(h->graphs.front().second); h->graphs.erase(h->graphs.begin()); }
-        h->graphs.push_back({key, exec});
-    }
-    HIPCHK(hipEventRecord(h->ev_gin, s));
-    HIPCHK(hipStreamWaitEvent(h->gstream, h->ev_gin, 0));
-    HIPCHK(hipGraphLaunch(exec, h->gstream));
-    HIPCHK(hipEventRecord(h->ev_gout, h->gstream));
-    HIPCHK(hipStreamWaitEvent(s, h->ev_gout, 0));
-    return SSD_OK;
+    // (hipGraph replay of a repeating forward was measured in rounds 1-2 -- batch 1: replay 2.49 ms against eager 2.33, the forward
+    //  is GPU-bound -- and is not part of the library.)
+    return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, out_stride, s);
 }
 
 // (the caller holds h->mu)

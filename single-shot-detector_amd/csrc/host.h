@@ -33,35 +33,28 @@ int ssd_fail(int code, const std::string &msg);        // records the text for s
 // Tuning / test switches behind ssd_set_option (include/ssd_hip.h lists them).  None is read from the
 // environment; a handle's own value wins over the process-wide one (handle == NULL), which wins over the default.
 enum SsdOpt {
-    OPT_IGEMM_TILE = 0,     // 0 auto | 128 | 64: pins the 128x128-vs-64x64 choice of the implicit-GEMM kernel | 20 .. 23: a wave tile of igemm_lat.hip
-    OPT_IGEMM16,            // -1 auto | 0 | 1: f16x3 launches on the 256x256-tile kernel
-    OPT_IGEMM_96,           // 1 (default) | 0: 128x96 tiles for widths 96 divides and 128 does not
-    OPT_LATERAL_SPLIT,      // 1 (default) | 0: f16x3 laterals split fp32 rows while staging them
-    OPT_BACKBONE_SPLIT,     // 0 auto | 1..4: MobileNet backbone chains
-    OPT_NSUB,               // 0 auto | 1..8: staggered sub-batch plans
-    OPT_LEVEL_SPLIT,        // 0 (default) | 1: head towers of levels 6-7 as launches of their own (batch <= 2)
-    OPT_NMS_FAST_MAX,       // -1 default | n >= 0: candidate lists up to n run in one wave's registers
-    OPT_DEBUG_SYNC,         // 0 | 1: announce every op, run it alone, wait for it (fault localisation)
-    OPT_FUSE_DW,            // -1 default | mask: depthwise+pointwise pairs that run as one launch
-    OPT_GRAPH,              // 0 (default) | 1: hipGraph replay of a repeating forward
-    OPT_IGEMM_LAT,          // 1 (default) | 0: tiny exact-fp32 launches on the latency form (igemm_lat.hip)
-    OPT_IGEMM_DEEP64,       // -1 auto | 0 | 1: 64x64 tiles with loads three K-steps ahead
-    OPT_STREAMS,            // 0 auto | 1: every op of a plan on one stream (measurement aid)
-    OPT_FPN_GROUP,          // -1 auto | 0 | 1: fpn p3 + p4 + p5 as one grouped launch (exact fp32)
-    OPT_HEAD_SERIAL,        // -1 auto | 0 | 1: the box head behind the class logits on one stream instead of beside them
-    OPT_SIDE_PRIORITY,      // 0 (default) | 1: the plan's third / fourth stream at the lowest dispatch priority
-    OPT_TOWER_GROUP,        // 0 (default) | 1: layer i of the box and the class tower as ONE launch over 2 x 5 levels (exact fp32)
-    OPT_FPN_P6_FIRST,       // 3 (default): fpn p6 -> p7 on the main stream, the laterals beside them | 0: p6 -> p7 on the third stream | 1 / 2: ... and the grouped launch waits for p6 / p7
-    OPT_DWPW_LAT,           // 0 (default) | 1 | 2 | 4: depthwise + pointwise pairs the streaming kernel leaves apart as ONE launch of dwpw_lat.hip
-                            // (measured = the pair's time, plan.hip); 1 = wherever it takes the shape, channel tiles per wave chosen per layer; 2 / 4 pin them
-    OPT_FPN_EARLY_LAT,      // -1 auto (batch <= 2, one backbone chain, exact fp32) | 0 | 1: lateral3 / lateral4 early beside the backbone's last
-                            // layers, their top-down sums as one elementwise launch behind lateral5
+    // selectors a caller may want
+    OPT_STREAMS = 0,        // 0 auto | 1: every op of a plan on the caller's stream (measurement aid; also the form a caller's own graph capture takes)
     OPT_H2D_CHUNKS,         // 2 (default) | 1 .. 16: pieces of ssd_forward_host's staging copy + upload (piece k uploads under the host copy of k + 1)
-    OPT_FPN_P7_GROUP,       // 1 (default) | 0: fpn p7 as a fourth level of the grouped p3 + p4 + p5 launch (batch <= 2, exact fp32)
+    OPT_FRONT_FUSE,         // -1 auto | 0 | 1: the backbone's first layers as one launch (front.hip)
+    OPT_FUSE_DW,            // -1 default | mask: depthwise+pointwise pairs that run as one launch
+    OPT_BACKBONE_SPLIT,     // 0 auto | 1 | 2: backbone chains (two half-batch chains from 4 images on)
     OPT_EVENT_FENCE,        // 0 (default): the library's ordering events carry no system-scope fence (hipEventDisableSystemFence: they order
                             // streams of ONE device) | 1: default event flags (a cache writeback per record: ~8-12 us per cross-stream edge)
-    OPT_LAT_ONE,            // 20 | 28 .. 32: the one-wave tile of igemm_lat.hip the plan gives its tiny launches (fpn p6 / p7 / lateral5 at batch 1-2)
-    OPT_FRONT_FUSE,         // -1 auto | 0 | 1: MobileNet's first convolution + Conv2d_1 (depthwise + pointwise) as one launch (front.hip)
+    // test hooks: pin a kernel variant / a plan shape so that the parity tests see every shape on it (none changes a result bit in mode f32)
+    OPT_IGEMM_TILE,         // 0 auto | 128 | 64: pins the 128x128-vs-64x64 choice of the implicit-GEMM kernel | 20 .. 27: a wave tile of igemm_lat.hip
+    OPT_IGEMM16,            // -1 auto | 0 | 1: f16x3 launches on the 256x256-tile kernel
+    OPT_IGEMM_96,           // 1 (default) | 0: 128x96 tiles for widths 96 divides and 128 does not
+    OPT_IGEMM_LAT,          // 1 (default) | 0: tiny exact-fp32 launches on the latency form (igemm_lat.hip)
+    OPT_IGEMM_DEEP64,       // -1 auto | 0 | 1: 64x64 tiles with loads three K-steps ahead
+    OPT_LATERAL_SPLIT,      // 1 (default) | 0: f16x3 laterals split fp32 rows while staging them
+    OPT_FPN_GROUP,          // -1 auto | 0 | 1: fpn p3 + p4 + p5 as one grouped launch (exact fp32, batch <= 2)
+    OPT_FPN_P7_GROUP,       // 1 (default) | 0: fpn p7 as a fourth level of that launch
+    OPT_FPN_EARLY_LAT,      // -1 auto (batch <= 2, one backbone chain, exact fp32) | 0 | 1: lateral3 / lateral4 early beside the backbone's last
+                            // layers, their top-down sums as one elementwise launch behind lateral5
+    OPT_NSUB,               // 0 auto | 1..8: at least this many consecutive sub-batch plans (the split a > 2 GiB batch takes)
+    OPT_NMS_FAST_MAX,       // -1 default | n >= 0: candidate lists up to n run in one wave's registers
+    OPT_DEBUG_SYNC,         // 0 | 1: announce every op, run it alone, wait for it (fault localisation)
     OPT_COUNT
 };
 #define SSD_OPT_UNSET INT_MIN
@@ -156,7 +149,6 @@ struct Op {
     int stream = 0;     // 0: the plan's main stream, 1: its second stream, 2 / 3: further chains
     std::vector<int> deps;          // indices of ops (on the other stream) that must have finished
     hipEvent_t done = nullptr;      // recorded after the op when another op depends on it
-    bool fpn_end = false;           // last op of backbone + FPN (sub-batch stagger point)
     double flops, bytes;
     std::function<hipError_t(hipStream_t)> run;
 };
@@ -182,10 +174,8 @@ Op make_dwpws_op(const DwW &d, const ConvW &cw, const float *in, int B, int H, i
                  float *out, int out_rs = 0 /* floats between output rows; 0: cw.CoutP */);
 // sn_pw.hip: 1x1 + batch norm + activation on rows gathered through `src` (device table, CinP entries) from `base`
 Op make_pw_gather_op(const ConvW &cw, const float *base, long long base_bytes, const int *src, int rs, long long M, int act, float *out);
-int dwpw_lat_ct(const struct ssd_handle *h, const DwW &d, const ConvW &cw, int B, int H, int W, int stride);   // 0: not this kernel's
 // front.hip: first convolution + Conv2d_1 in one launch; the frame pointer is the handle's cur_images + img_off at run time
 Op make_front_op(struct ssd_handle *h, size_t img_off, const DwW &f, int act0, const DwW &d, const ConvW &cw, int B, int H, int W, int dact, int act, float *out);
-Op make_dwpw_lat_op(int ct, const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact, int act, float *out);
 LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long in_off = 0, long long out_off = 0,
                       int param_off = 0, long long res_off = 0);
 float conservative_logit_bound(float thr);
@@ -204,33 +194,18 @@ struct Retained { const float *dev; int B, H, W, C, Cp; bool permuted; int fmt =
 
 struct EvPair { hipEvent_t a, b; int cls; int fwd; };
 
-// The layer plan of one SUB-BATCH: ssd_forward splits a large batch into a few sub-batches and
-// staggers them over streams, so the HBM-bound backbone of sub-batch k+1 runs underneath the
-// MFMA-bound heads of sub-batch k (images are independent end to end).
+// The layer plan of one SUB-BATCH (normally the whole batch: consecutive sub-batch plans exist for batches whose tensors would
+// pass the 2 GiB that a launch addresses with 32-bit byte offsets).
 struct Plan {
     int B = 0, img0 = 0, N = 0;
     DevPool pool;                       // activations / workspace
     std::vector<Op> ops;
     PostArgs post;
     std::map<std::string, Retained> retained;
-    hipStream_t s_main = nullptr;       // null: the caller's stream (sub-batch 0)
-    hipStream_t s_aux = nullptr;        // class tower beside the box tower (box_predictor.py:47-59)
-    hipStream_t s_bb[2] = {nullptr, nullptr};   // further chains (Op::stream 2, 3)
-    bool own_streams = false;           // false: the streams are the process-wide ones (plan.hip make_plans), not destroyed with the plan
-    hipEvent_t ev_fpn = nullptr, ev_join = nullptr, ev_done = nullptr, ev_begin = nullptr;
-    hipEvent_t ev_join_bb[2] = {nullptr, nullptr};
+    hipStream_t s_aux = nullptr;        // Op::stream 1: class tower beside the box tower (box_predictor.py:47-59), second backbone chain
+    hipStream_t s_bb[2] = {nullptr, nullptr};   // Op::stream 2, 3 (fpn p6 -> p7; the batch-1 lateral chain); process-wide, not owned
+    hipEvent_t ev_join = nullptr, ev_begin = nullptr;
     bool need_begin = false;            // some chain starts on an internal stream without a dependency: it waits for ev_begin
-    bool tail_on[2] = {false, false};   // the plan's last ops on stream 2 / 3 are not awaited by any later op: join them before the post-processing
-    int last_aux = -1;                  // index of the last op on the second stream
-};
-
-struct GraphKey {
-    const void *img; void *boxes, *labels, *scores, *num; int B, H, W; long long out_stride = 0;
-    bool operator==(const GraphKey &o) const
-    {
-        return img == o.img && boxes == o.boxes && labels == o.labels && scores == o.scores && num == o.num && B == o.B && H == o.H && W == o.W &&
-               out_stride == o.out_stride;
-    }
 };
 
 struct ssd_handle {
@@ -248,8 +223,6 @@ struct ssd_handle {
     ConvW lat[3], pconv[5];             // fpn lateral3..5, p3..p7
     ConvW pgroup;                       // fpn p3 | p4 | p5 | p7 kernels and batch norms behind one pointer each: one grouped launch at batch 1
     ConvW tower[2][4], final_[2];       // [box, class]
-    ConvW tgroup[4];                    // tower layer i of BOTH nets behind one pointer each (kernel, 2 x 5 batch norms): one launch per layer
-    std::vector<int *> tabs;            // shufflenet gather tables (device)
     int c_ch[3] = {0, 0, 0};            // logical channels of c3, c4, c5
     int c_split[3] = {0, 0, 0};         // > 0: c3 / c4 is a ShuffleNet stage output in two-part rows [x half | y half], this many channels each
     int precision = SSD_PRECISION_F32;  // ssd_set_precision
@@ -257,7 +230,6 @@ struct ssd_handle {
     // plans
     int pB = 0, pH = 0, pW = 0;
     std::vector<Plan *> plans;
-    hipEvent_t ev_start = nullptr;
     const uint8_t *cur_images = nullptr;
     // the arena is one per handle: a forward enqueued on another stream than the previous one waits for it
     hipStream_t last_stream = nullptr;
@@ -270,12 +242,6 @@ struct ssd_handle {
     size_t stage_bytes = 0;
     hipStream_t stage_stream = nullptr;
     bool stage_busy = false;
-    // hipGraph replay
-    hipStream_t gstream = nullptr;
-    hipEvent_t ev_gin = nullptr, ev_gout = nullptr;
-    std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
-    GraphKey last_key{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-    bool capture_broken = false;        // a failed capture is not retried
     // profiling
     bool profiling = false;
     std::vector<EvPair> evs;

@@ -385,10 +385,11 @@ hipError_t launch_igemm_lat(int tile, const IgemmArgs &a, int total_tiles_m, hip
     if (a.n_major && (a.tiles_m != total_tiles_m || total_tiles_m < 1)) return hipErrorInvalidValue;
     switch (tile) {
     case IGEMM_LAT_1x1: return launch_l<1, 1, 4>(a, total_tiles_m, s);
+    case IGEMM_LAT_1x1_D16: return launch_l<1, 1, 16, 1, 1>(a, total_tiles_m, s);
+#ifdef SSD_DIAG   // libssd_hip_diag.so only: the other prefetch depths / tile orders of the interleaved K-step (measured, round 4), and
+                  // its timing ablations (results wrong)
     case IGEMM_LAT_1x1_IL: case IGEMM_LAT_1x1_NM: return launch_l<1, 1, 4, 1, 1>(a, total_tiles_m, s);
     case IGEMM_LAT_1x1_D8: case IGEMM_LAT_1x1_D8_NM: return launch_l<1, 1, 8, 1, 1>(a, total_tiles_m, s);
-    case IGEMM_LAT_1x1_D16: return launch_l<1, 1, 16, 1, 1>(a, total_tiles_m, s);
-#ifdef SSD_DIAG   // timing ablations of the interleaved K-step (results wrong): libssd_hip_diag.so only
     case 33: return launch_l<1, 1, 16, 1, 2>(a, total_tiles_m, s);
     case 34: return launch_l<1, 1, 16, 1, 3>(a, total_tiles_m, s);
     case 35: return launch_l<1, 1, 16, 1, 4>(a, total_tiles_m, s);

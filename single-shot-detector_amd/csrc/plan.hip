@@ -121,10 +121,8 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
             }
             if ((waves <= 320 || b64 <= 40) && a.wt_lat) {
                 // the one-accumulator wave with its K-step interleaved and 16 K-steps of operands in flight (igemm_lat.hip;
-                // batch-1 forward 1.652 -> 1.637 ms against the plain K-step, profiles/r04_batch1_option_ab.log); option
-                // lat_one = 20 | 28 .. 32 pins another form of the same tile
-                tile = ssd_opt(h, OPT_LAT_ONE, IGEMM_LAT_1x1_D16);
-                if (tile != IGEMM_LAT_1x1 && !(tile >= IGEMM_LAT_1x1_IL && tile <= IGEMM_LAT_1x1_D8_NM)) tile = IGEMM_LAT_1x1_D16;
+                // batch-1 forward 1.652 -> 1.637 ms against the plain K-step, profiles/r04_batch1_option_ab.log)
+                tile = IGEMM_LAT_1x1_D16;
             }
             // 1x1 launches of one or two 64x64 tiles per CU (batch 1-2: MobileNet pointwise Conv2d_5 .. 13, laterals 3 and 4): the
             // tiles do not divide over the 256 CUs -- 280 of a 512 -> 512 layer at 40x56: 24 CUs run two, the launch takes two
@@ -186,23 +184,12 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
 
 void free_plans(ssd_handle *h)
 {
-    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.second);
-    h->graphs.clear();
-    h->last_key = GraphKey{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     for (Plan *pl : h->plans) {
         for (Op &op : pl->ops)
             if (op.done) (void)hipEventDestroy(op.done);
         pl->pool.free_all();
-        if (pl->own_streams) {
-            if (pl->s_main) (void)hipStreamDestroy(pl->s_main);
-            if (pl->s_aux) (void)hipStreamDestroy(pl->s_aux);
-            for (int i = 0; i < 2; ++i) if (pl->s_bb[i]) (void)hipStreamDestroy(pl->s_bb[i]);
-        }
-        if (pl->ev_fpn) (void)hipEventDestroy(pl->ev_fpn);
         if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
-        if (pl->ev_done) (void)hipEventDestroy(pl->ev_done);
         if (pl->ev_begin) (void)hipEventDestroy(pl->ev_begin);
-        for (int i = 0; i < 2; ++i) if (pl->ev_join_bb[i]) (void)hipEventDestroy(pl->ev_join_bb[i]);
         delete pl;
     }
     h->plans.clear();
@@ -324,74 +311,6 @@ Op make_front_op(ssd_handle *h, size_t img_off, const DwW &f, int act0, const Dw
     return op;
 }
 
-// depthwise + pointwise on the latency-form kernel (dwpw_lat.hip): the pairs of a batch-1 / batch-2 forward that the streaming
-// kernel leaves apart (MobileNet Conv2d_5 .. 13).  Returns the channel tiles per wave (0: not this kernel's launch).
-//   ct   block = 16 positions x 64 ct channels; the block recomputes its positions' depthwise values once per channel tile of
-//        the layer, so wide blocks for wide layers -- as long as the launch keeps >= ~2 waves per SIMD
-static DwPwLArgs dwpw_lat_args(int ct, const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact, int act, float *out)
-{
-    DwPwLArgs q;
-    memset(&q, 0, sizeof(q));
-    IgemmArgs &a = q.g;
-    const int OH = H / stride, OW = W / stride;
-    a.in = in; a.wt = cw.wt; a.wt_lat = cw.wlat; a.out = out;
-    a.mean = cw.mean; a.sf = cw.sf; a.beta = cw.beta;
-    a.B = B; a.Cin = cw.CinP; a.Cout = cw.CoutP; a.CoutPad = cw.CoutPad; a.taps = 1; a.stride = 1; a.pad = 0; a.act = act;
-    a.nlevels = 1;
-    a.n_tiles_n = cw.CoutPad / (64 * (ct > 0 ? ct : 1));
-    a.dN = ssd_udiv_make((unsigned)a.n_tiles_n);
-    a.dense_out = 1;
-    a.acc_scale = 1.0f;
-    IgemmLevel &L = a.lv[0];
-    L.H = OH; L.W = OW; L.OH = OH; L.OW = OW; L.M = B * OH * OW;
-    L.out_rstride = cw.CoutP; L.out_bstride = (long long)OH * OW * cw.CoutP;
-    L.dP = ssd_udiv_make((unsigned)(OH * OW)); L.dOW = ssd_udiv_make((unsigned)OW);
-    L.stride = 1; L.pad = 0;
-    q.dw_pack = d.pack;
-    q.H = H; q.W = W; q.dstride = stride; q.dpad = stride == 1 ? 1 : 0; q.dact = dact;
-    return q;
-}
-
-int dwpw_lat_ct(const ssd_handle *h, const DwW &d, const ConvW &cw, int B, int H, int W, int stride)
-{
-    // Measured (profiles/r04_batch1_option_ab.log, r04_batch1_timeline_dwpw_lat*.txt), a 512 -> 512 layer at 40x56 against the
-    // 7.5 + 19 us of the pair it replaces: 35 us with the depthwise weights loaded per thread from global memory (21 sixteen-byte
-    // loads per thread and slice on the CU's one texture-address path, two rounds of blocks at 204 VGPRs), 26.5 with the layer's
-    // depthwise table in LDS (three blocks per CU), 26 with the iteration interleaved (sched_group_barrier): the pair's time,
-    // nine launches fewer, the batch-1 forward within +-5 us of the pairs (1.582 against 1.579 ms once the pairs' 1x1 kernel
-    // had lost its v_mov packing too).  What still separates it from ~18 us: 36 + 32 wave loads per block and slice (taps +
-    // 1x1 weights) against 1 024 MFMA cycles per wave -- dwpw_stream.hip's LDS-DMA patch staging would cut the 36 to 9.
-    // OFF unless asked for (option dwpw_lat >= 1); batch 2: 2.951 ms with the pairs, 2.978 fused.
-    const int opt = ssd_opt(h, OPT_DWPW_LAT, 0);
-    if (opt <= 0 || cw.taps != 1 || d.Cp != cw.CinP || !cw.mean || cw.bias || !cw.wlat || !d.pack) return 0;
-    if ((stride != 1 && stride != 2) || (stride == 2 && ((H | W) & 1))) return 0;
-    const long long M = (long long)B * (H / stride) * (W / stride);
-    int ct = 0;
-    if (opt == 2 || opt == 4) ct = opt;
-    else {
-        // auto: the launches of one or two 64x64 tiles per CU that make_conv_op gives the four-wave latency form (batch 1-2)
-        const long long b64 = ((M + 63) / 64) * ((cw.CoutPad + 63) / 64);
-        ct = cw.CoutPad % 128 == 0 ? 2 : 1;
-        const long long waves2 = ((M + 15) / 16) * (cw.CoutPad / 32);
-        if (ct == 2 && waves2 < 2048) ct = cw.CoutPad % 128 == 0 && waves2 >= 1024 ? 2 : 1;
-    }
-    while (ct > 1 && cw.CoutPad % (64 * ct)) ct >>= 1;
-    const DwPwLArgs q = dwpw_lat_args(ct, d, cw, nullptr, B, H, W, stride, 0, 0, nullptr);
-    return dwpw_lat_supports(q, ct) ? ct : 0;
-}
-
-Op make_dwpw_lat_op(int ct, const DwW &d, const ConvW &cw, const float *in, int B, int H, int W, int stride, int dact, int act, float *out)
-{
-    const DwPwLArgs q = dwpw_lat_args(ct, d, cw, in, B, H, W, stride, dact, act, out);
-    Op op;
-    op.cls = 6;
-    const double M = (double)B * (H / stride) * (W / stride);
-    op.flops = (2.0 * 9 * cw.Cin_l + 2.0 * cw.Cin_l * cw.Cout_l) * M;
-    op.bytes = ((double)B * H * W * cw.Cin_l + M * cw.Cout_l) * 4.0 + (double)cw.Cin_l * cw.Cout_l * 4.0;
-    op.run = [q, ct](hipStream_t s) { return launch_dwpw_lat(ct, q, s); };
-    return op;
-}
-
 LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long in_off, long long out_off, int param_off, long long res_off)
 {
     LevelDesc d;
@@ -403,18 +322,6 @@ LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long in_off,
     d.res_off = res_off;
     d.wt_off = 0;
     return d;
-}
-
-static void push_dw_pw(const ssd_handle *h, std::vector<Op> &ops, bool fuse, const DwW &d, const ConvW &cw, const float *in, float *mid,
-                       float *out, int B, int H, int W, int stride, int dact, int act, int Cl)
-{
-    const int OH = H / stride, OW = W / stride;
-    if (fuse && in != out && dwpws_eligible(d, cw, B, H, W, stride)) {
-        ops.push_back(make_dwpws_op(d, cw, in, B, H, W, stride, dact, act, out));
-        return;
-    }
-    ops.push_back(make_dw_op(d, in, B, H, W, stride, dact, mid, Cl));
-    ops.push_back(make_conv_op(h, cw, mid, out, nullptr, nullptr, B, 1, 0, act, {dense_level(OH, OW, OH, OW, cw.CoutP)}, true));
 }
 
 static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int img0)
@@ -520,9 +427,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 // f16x3: an unfused pair hands the depthwise result (exact fp32, in [0, 6]) to its pointwise
                 // convolution in split-fp16 rows, and the pointwise product runs as 3 x f16 MFMA
                 const int pw16 = X16 && !fuse && (h->dw[i].Cp % 32 == 0) ? 1 : 0;
-                // batch 1-2, exact fp32: the pair as ONE launch of the latency form (dwpw_lat.hip)
-                const int lct = (!fuse && !X16) ? dwpw_lat_ct(h, h->dw[i], cw, nb, ch, cwid, s) : 0;
-                if (!fuse && !lct) ops.push_back(make_dw_op(h->dw[i], cur, nb, ch, cwid, s, SSD_ACT_RELU6, dwo, h->pw[i].Cin_l, pw16, FL));
+                if (!fuse) ops.push_back(make_dw_op(h->dw[i], cur, nb, ch, cwid, s, SSD_ACT_RELU6, dwo, h->pw[i].Cin_l, pw16, FL));
                 const int dh = ch, dwid = cwid;
                 ch /= s; cwid /= s;
                 float *pwo;
@@ -530,12 +435,10 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                     float *full = i == 4 ? C3 : (i == 10 ? C4 : C5);
                     pwo = full + (long long)b0 * ch * cwid * cw.CoutP;
                 } else {
-                    pwo = (fuse || lct) ? dwo : ((dwo == X) ? Y : X);    // fused: input `cur` is live until the launch ends
+                    pwo = fuse ? dwo : ((dwo == X) ? Y : X);    // fused: input `cur` is live until the launch ends
                 }
                 if (fuse)
                     ops.push_back(make_dwpws_op(h->dw[i], cw, cur, nb, dh, dwid, s, SSD_ACT_RELU6, SSD_ACT_RELU6, pwo));
-                else if (lct)
-                    ops.push_back(make_dwpw_lat_op(lct, h->dw[i], cw, cur, nb, dh, dwid, s, SSD_ACT_RELU6, SSD_ACT_RELU6, pwo));
                 else   // c5 feeds only the FPN (lateral5, p6): in f16x3 mode it is written in split-fp16 rows
                     ops.push_back(make_conv_op(h, cw, dwo, pwo, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU6,
                                                {dense_level(ch, cwid, ch, cwid, cw.CoutP)}, true, pw16, (i == 12 && X16) ? 1 : 0, 0, h->flags_dev));
@@ -551,7 +454,6 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                     op.stream = hf;
                     pl.ops.push_back(op);
                     id_bb_last[hf] = (int)pl.ops.size() - 1;
-                    if (hf == 1) pl.last_aux = id_bb_last[hf];
                 }
     } else {
         // ---------------- ShuffleNet v2 (shufflenet_v2.py:50-69,79-137)
@@ -579,260 +481,167 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         //   * the stage output is kept in two-part rows [x half | y half] (weights.hip packs its consumers for that): the last
         //     unit stores its channels straight into the x half, the y half (channels no later unit touched) is one row gather.
         // Each stage is ONE allocation [producer tensors of chain 0 | ... of chain 1 | stage output S of the whole batch] under
-        // one buffer resource.
-        bool chained = false;
+        // one buffer resource (make_plans keeps it below 2 GiB).
+        int nhalf = B >= 4 ? 2 : 1;
+        { const int v = ssd_opt(h, OPT_BACKBONE_SPLIT, 0); if (v >= 1 && v <= 2 && v <= B) nhalf = v; }
+        const int nb_of[2] = {nhalf == 2 ? B / 2 : B, nhalf == 2 ? B - B / 2 : 0};
+        struct StageGeo { int ch, cw, oh, ow, D, Dp, n_units, ipw, idw; long long tbytes[2], toff[2], soff, total; };
+        StageGeo geo[3];
         {
-            int nhalf = B >= 4 ? 2 : 1;
-            { const int v = ssd_opt(h, OPT_BACKBONE_SPLIT, 0); if (v >= 1 && v <= 2 && v <= B) nhalf = v; }
-            bool ok = sn_fuse;
-            const int nb_of[2] = {nhalf == 2 ? B / 2 : B, nhalf == 2 ? B - B / 2 : 0};
-            struct StageGeo { int ch, cw, oh, ow, D, Dp, n_units, ipw, idw; long long tbytes[2], toff[2], soff, total; };
-            StageGeo geo[3];
-            {
-                int ch = h4, cw = w4, ipw = 0, idw = 0;
-                for (int st = 0; ok && st < 3; ++st) {
-                    StageGeo &g = geo[st];
-                    g.ch = ch; g.cw = cw; g.oh = ch / 2; g.ow = cw / 2; g.ipw = ipw; g.idw = idw; g.n_units = units[st];
-                    const ConvW &after = h->pw[ipw + 1], &after2 = h->pw[ipw + 2];
-                    g.Dp = after.CoutP; g.D = after.Cout_l;
-                    long long off = 0;
-                    for (int hf = 0; hf < nhalf; ++hf) {
-                        g.tbytes[hf] = (long long)nb_of[hf] * g.oh * g.ow * g.Dp * 4;       // one producer tensor of this chain
-                        g.toff[hf] = off;
-                        off += g.tbytes[hf] * g.n_units;                                  // x1, y1, o_2 .. o_{n-1}
-                    }
-                    g.soff = off;
-                    g.total = off + (long long)B * g.oh * g.ow * 2 * g.Dp * 4;
-                    ok = g.total < (1LL << 31) && g.n_units >= 2 && after2.CoutP == g.Dp && after2.Cout_l == g.D;
-                    for (int hf = 0; ok && hf < nhalf; ++hf) {
-                        ok = dwpws_eligible(h->dw[idw], after, nb_of[hf], ch, cw, 2) && dwpws_eligible(h->dw[idw + 1], after2, nb_of[hf], ch, cw, 2);
-                        for (int j = 2; ok && j <= g.n_units; ++j) {
-                            const ConvW &b2 = h->pw[ipw + 3 + 2 * (j - 2)], &a2 = h->pw[ipw + 3 + 2 * (j - 2) + 1];
-                            ok = dwpws_eligible(h->dw[idw + j], a2, nb_of[hf], g.oh, g.ow, 1) && a2.CoutP == g.Dp && b2.CinP == g.Dp && b2.taps == 1 &&
-                                 b2.mean && !b2.bias &&
-                                 pw_gather_supports(b2.CinP, b2.CoutP, (long long)nb_of[hf] * g.oh * g.ow, g.Dp * 4, g.total, (long long)nb_of[hf] * g.oh * g.ow * b2.CoutP * 4);
-                        }
-                    }
-                    ipw += 3 + 2 * (g.n_units - 1); idw += 2 + (g.n_units - 1);
-                    ch = g.oh; cw = g.ow;
-                }
-            }
-            if (ok) {
-                chained = true;
-                float *stage[3];
-                for (int st = 0; st < 3; ++st) SSDCHK(falloc(&stage[st], geo[st].total / 4));
-                const StageGeo &g2 = geo[2];
-                const ConvW &c5w = h->pw[g2.ipw + 3 + 2 * (g2.n_units - 1)];
-                SSDCHK(falloc(&C5, (long long)B * g2.oh * g2.ow * c5w.CoutP));
-                std::vector<Op> half_ops[2];
+            int ch = h4, cw = w4, ipw = 0, idw = 0;
+            for (int st = 0; st < 3; ++st) {
+                StageGeo &g = geo[st];
+                g.ch = ch; g.cw = cw; g.oh = ch / 2; g.ow = cw / 2; g.ipw = ipw; g.idw = idw; g.n_units = units[st];
+                const ConvW &after = h->pw[ipw + 1];
+                g.Dp = after.CoutP; g.D = after.Cout_l;
+                long long off = 0;
                 for (int hf = 0; hf < nhalf; ++hf) {
-                    const int b0 = hf == 0 ? 0 : nb_of[0], nb = nb_of[hf];
-                    std::vector<Op> &ops = half_ops[hf];
-                    float *F = nullptr, *MP;
-                    SSDCHK(falloc(&MP, (long long)nb * h4 * w4 * fc));
-                    {
-                        ssd_handle *hh = h;
-                        const DwW f = h->first;
-                        const int act = h->firstAct;
-                        const size_t off = img_off + (size_t)b0 * srcH * srcW * 3;
-                        Op op;
-                        op.cls = 3;
-                        op.flops = 2.0 * 27 * (double)nb * h2 * w2 * 24;
-                        if (sn_front) {
-                            // first convolution + max pool as one launch (front.hip): the half-resolution tensor stays in LDS
-                            op.bytes = (double)nb * H * W * 3 + (double)nb * h4 * w4 * 24 * 4.0;
-                            op.run = [=](hipStream_t s) { return launch_front_pool(hh->cur_images + off, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, MP, s); };
-                            ops.push_back(op);
-                        } else {
-                            SSDCHK(falloc(&F, (long long)nb * h2 * w2 * fc));
-                            op.bytes = (double)nb * H * W * 3 + (double)nb * h2 * w2 * 24 * 4.0;
-                            op.run = [=](hipStream_t s) {
-                                return launch_first_conv(hh->cur_images + off, nb, srcH, srcW, rnh, rnw, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s);
-                            };
-                            ops.push_back(op);
-                            Op mp;
-                            mp.cls = 5; mp.flops = 0;
-                            mp.bytes = ((double)nb * h2 * w2 + (double)nb * h4 * w4) * 24 * 4.0;
-                            mp.run = [=](hipStream_t s) { return launch_maxpool(F, nb, h2, w2, fc, MP, s); };
-                            ops.push_back(mp);
-                        }
-                    }
-                    const float *cur = MP;
-                    for (int st = 0; st < 3; ++st) {
-                        const StageGeo &g = geo[st];
-                        const ConvW &before = h->pw[g.ipw], &after = h->pw[g.ipw + 1], &after2 = h->pw[g.ipw + 2];
-                        const DwW &d1 = h->dw[g.idw], &d2 = h->dw[g.idw + 1];
-                        const int D = g.D, Dp = g.Dp, n_units = g.n_units;
-                        const long long rows = (long long)nb * g.oh * g.ow;
-                        float *t1, *U;
-                        SSDCHK(falloc(&t1, (long long)nb * g.ch * g.cw * before.CoutP));
-                        SSDCHK(falloc(&U, rows * Dp));
-                        float *sb = stage[st];
-                        // producer p's tensor of this chain (0: unit_1's second branch = x, 1: its main branch = y, j: unit j's output)
-                        auto tensor_off = [&](int p) { return g.toff[hf] + (long long)p * g.tbytes[hf]; };
-                        // the chain's rows of S start b0 images into the stage output
-                        float *S_chain = sb + g.soff / 4 + (long long)b0 * g.oh * g.ow * 2 * Dp;
-                        struct Src { int prod, col; };
-                        std::vector<Src> x(D), y(D);
-                        for (int d = 0; d < D; ++d) { x[d] = Src{0, d}; y[d] = Src{1, d}; }
-                        auto table = [&](const std::vector<Src> &v) {      // physical channel p of a D-channel row -> byte offset of its source
-                            std::vector<int> t(Dp, -1);
-                            for (int d = 0; d < D; ++d) t[ssd_phys_of_logical(d)] = (int)(tensor_off(v[d].prod) + (long long)ssd_phys_of_logical(v[d].col) * 4);
-                            return t;
-                        };
-                        std::vector<const int *> src_dev(n_units + 1, nullptr);
-                        for (int j = 2; j <= n_units; ++j) {
-                            std::vector<Src> z(2 * D);
-                            for (int d = 0; d < D; ++d) { z[2 * d] = x[d]; z[2 * d + 1] = y[d]; }
-                            std::vector<Src> xin(z.begin(), z.begin() + D);
-                            int *dv;
-                            SSDCHK(ap.upload(&dv, table(xin)));
-                            src_dev[j] = dv;
-                            for (int d = 0; d < D; ++d) { x[d] = Src{j, d}; y[d] = z[D + d]; }
-                        }
-                        int *ysrc;
-                        SSDCHK(ap.upload(&ysrc, table(y)));          // the stage output's y half (x = unit n's own channels)
-                        ops.push_back(make_conv_op(h, before, cur, t1, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU,
-                                                   {dense_level(g.ch, g.cw, g.ch, g.cw, before.CoutP)}, true));
-                        ops.push_back(make_dwpws_op(d1, after, t1, nb, g.ch, g.cw, 2, SSD_ACT_NONE, SSD_ACT_RELU, sb + tensor_off(1) / 4));
-                        ops.push_back(make_dwpws_op(d2, after2, cur, nb, g.ch, g.cw, 2, SSD_ACT_NONE, SSD_ACT_RELU, sb + tensor_off(0) / 4));
-                        for (int j = 2; j <= n_units; ++j) {
-                            const ConvW &b2 = h->pw[g.ipw + 3 + 2 * (j - 2)], &a2 = h->pw[g.ipw + 3 + 2 * (j - 2) + 1];
-                            const DwW &dd = h->dw[g.idw + j];
-                            ops.push_back(make_pw_gather_op(b2, sb, g.total, src_dev[j], Dp * 4, rows, SSD_ACT_RELU, U));
-                            if (j < n_units) ops.push_back(make_dwpws_op(dd, a2, U, nb, g.oh, g.ow, 1, SSD_ACT_NONE, SSD_ACT_RELU, sb + tensor_off(j) / 4));
-                            else ops.push_back(make_dwpws_op(dd, a2, U, nb, g.oh, g.ow, 1, SSD_ACT_NONE, SSD_ACT_RELU, S_chain, 2 * Dp));
-                        }
-                        {
-                            Op gop;
-                            gop.cls = 5; gop.flops = 0; gop.bytes = 2.0 * rows * D * 4.0;
-                            const int rs = Dp * 4, ors = 2 * Dp;
-                            float *ydst = S_chain + Dp;
-                            gop.run = [=](hipStream_t s) { return launch_gather_rows(sb, ysrc, rs, rows, Dp, ydst, ors, s); };
-                            ops.push_back(gop);
-                        }
-                        cur = S_chain;
-                    }
-                    ops.push_back(make_conv_op(h, c5w, cur, C5 + (long long)b0 * g2.oh * g2.ow * c5w.CoutP, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU,
-                                               {dense_level(g2.oh, g2.ow, g2.oh, g2.ow, c5w.CoutP)}, true, 0, X16, 0, FL));
+                    g.tbytes[hf] = (long long)nb_of[hf] * g.oh * g.ow * g.Dp * 4;       // one producer tensor of this chain
+                    g.toff[hf] = off;
+                    off += g.tbytes[hf] * g.n_units;                                  // x1, y1, o_2 .. o_{n-1}
                 }
-                for (int st = 0; st < 2; ++st) {
-                    float *S = stage[st] + geo[st].soff / 4;
-                    if (st == 0) C3 = S; else C4 = S;
-                    pl.retained[st == 0 ? "c3" : "c4"] = Retained{S, B, geo[st].oh, geo[st].ow, 2 * geo[st].D, 2 * geo[st].Dp, true, 0, geo[st].D};
-                }
-                pl.retained["c5"] = Retained{C5, B, g2.oh, g2.ow, c5w.Cout_l, c5w.CoutP, true, X16};
-                for (size_t i = 0; i < std::max(half_ops[0].size(), half_ops[1].size()); ++i)
-                    for (int hf = 0; hf < nhalf; ++hf)
-                        if (i < half_ops[hf].size()) {
-                            Op op = half_ops[hf][i];
-                            op.stream = hf;
-                            pl.ops.push_back(op);
-                            id_bb_last[hf] = (int)pl.ops.size() - 1;
-                            if (hf == 1) pl.last_aux = id_bb_last[hf];
-                        }
+                g.soff = off;
+                g.total = off + (long long)B * g.oh * g.ow * 2 * g.Dp * 4;
+                if (g.total >= (1LL << 31)) return ssd_fail(SSD_ERR_INVALID, "ssd_forward: ShuffleNet stage allocation past 2 GiB (sub-batch split failed)");
+                for (int hf = 0; hf < nhalf; ++hf)
+                    for (int j = 2; j <= g.n_units; ++j) {
+                        const ConvW &b2 = h->pw[ipw + 3 + 2 * (j - 2)];
+                        if (b2.CinP != g.Dp || b2.taps != 1 || !b2.mean || b2.bias ||
+                            !pw_gather_supports(b2.CinP, b2.CoutP, (long long)nb_of[hf] * g.oh * g.ow, g.Dp * 4, g.total, (long long)nb_of[hf] * g.oh * g.ow * b2.CoutP * 4))
+                            return ssd_fail(SSD_ERR_INVALID, "ssd_forward: a ShuffleNet unit's conv1x1_before is not a shape of the gathering kernel (sn_pw.hip)");
+                    }
+                ipw += 3 + 2 * (g.n_units - 1); idw += 2 + (g.n_units - 1);
+                ch = g.oh; cw = g.ow;
             }
         }
-        if (!chained) {
-        float *F, *MP;
-        SSDCHK(falloc(&F, (long long)B * h2 * w2 * fc));
-        SSDCHK(falloc(&MP, (long long)B * h4 * w4 * fc));
-        if (sn_front) {
-            Op op;
-            op.cls = 3;
-            op.flops = 2.0 * 27 * (double)B * h2 * w2 * 24;
-            op.bytes = (double)B * H * W * 3 + (double)B * h4 * w4 * 24 * 4.0;
-            ssd_handle *hh = h;
-            const DwW f = h->first;
-            const int act = h->firstAct;
-            op.run = [=](hipStream_t s) { return launch_front_pool(hh->cur_images + img_off, B, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, MP, s); };
-            pl.ops.push_back(op);
-        } else {
-            Op op;
-            op.cls = 3;
-            op.flops = 2.0 * 27 * (double)B * h2 * w2 * 24;
-            op.bytes = (double)B * H * W * 3 + (double)B * h2 * w2 * 24 * 4.0;
-            ssd_handle *hh = h;
-            const DwW f = h->first;
-            const int act = h->firstAct;
-            op.run = [=](hipStream_t s) {
-                return launch_first_conv(hh->cur_images + img_off, B, srcH, srcW, rnh, rnw, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s);
+        float *stage[3];
+        for (int st = 0; st < 3; ++st) SSDCHK(falloc(&stage[st], geo[st].total / 4));
+        const StageGeo &g2 = geo[2];
+        const ConvW &c5w = h->pw[g2.ipw + 3 + 2 * (g2.n_units - 1)];
+        SSDCHK(falloc(&C5, (long long)B * g2.oh * g2.ow * c5w.CoutP));
+        std::vector<Op> half_ops[2];
+        for (int hf = 0; hf < nhalf; ++hf) {
+            const int b0 = hf == 0 ? 0 : nb_of[0], nb = nb_of[hf];
+            std::vector<Op> &ops = half_ops[hf];
+            float *F = nullptr, *MP, *MID = nullptr;
+            SSDCHK(falloc(&MP, (long long)nb * h4 * w4 * fc));
+            // depthwise -> 1x1 (+ batch norms, ReLU behind the 1x1) into dense rows [M][out_rs]: one launch of the streaming kernel, or
+            // (option fuse_dw = 0, shapes it does not take) the depthwise kernel and the implicit-GEMM kernel with a tensor between them
+            auto pair = [&](const DwW &d, const ConvW &cw, const float *in, int hh, int ww, int stride, float *out, int out_rs) -> int {
+                if (sn_fuse && dwpws_eligible(d, cw, nb, hh, ww, stride)) {
+                    ops.push_back(make_dwpws_op(d, cw, in, nb, hh, ww, stride, SSD_ACT_NONE, SSD_ACT_RELU, out, out_rs));
+                    return SSD_OK;
+                }
+                if (!MID) SSDCHK(falloc(&MID, (long long)nb * h4 * w4 * std::max(fc, 32)));       // (the largest depthwise output: Stage2 unit_1 reads h4 x w4)
+                const int oh = hh / stride, ow = ww / stride;
+                if ((long long)nb * oh * ow * d.Cp > (long long)nb * h4 * w4 * std::max(fc, 32)) return ssd_fail(SSD_ERR_INVALID, "ssd_forward: depthwise scratch too small");
+                ops.push_back(make_dw_op(d, in, nb, hh, ww, stride, SSD_ACT_NONE, MID, cw.Cin_l));
+                LevelDesc lv = dense_level(oh, ow, oh, ow, cw.CoutP);
+                lv.out_rstride = out_rs > 0 ? out_rs : cw.CoutP;
+                lv.out_bstride = (long long)oh * ow * lv.out_rstride;
+                ops.push_back(make_conv_op(h, cw, MID, out, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU, {lv}, true));
+                return SSD_OK;
             };
-            pl.ops.push_back(op);
-            Op mp;
-            mp.cls = 5; mp.flops = 0;
-            mp.bytes = ((double)B * h2 * w2 + (double)B * h4 * w4) * 24 * 4.0;
-            mp.run = [=](hipStream_t s) { return launch_maxpool(F, B, h2, w2, fc, MP, s); };
-            pl.ops.push_back(mp);
-        }
-        const float *cur = MP;
-        int ch = h4, cwid = w4, ipw = 0, idw = 0;
-        for (int st = 0; st < 3; ++st) {
-            const int oh = ch / 2, ow = cwid / 2;
-            const long long rows = (long long)B * oh * ow;
-            // unit_1
-            const ConvW &before = h->pw[ipw], &after = h->pw[ipw + 1], &after2 = h->pw[ipw + 2];
-            const DwW &d1 = h->dw[idw], &d2 = h->dw[idw + 1];
-            const int Dp = after.CoutP, D = after.Cout_l;
-            ipw += 3; idw += 2;
-            float *t1, *t2, *t3, *Xa, *Xb, *Ya, *Yb, *U, *V;
-            SSDCHK(falloc(&t1, (long long)B * ch * cwid * before.CoutP));
-            SSDCHK(falloc(&t2, rows * d1.Cp));
-            SSDCHK(falloc(&t3, rows * d2.Cp));
-            SSDCHK(falloc(&Xa, rows * Dp)); SSDCHK(falloc(&Xb, rows * Dp));
-            SSDCHK(falloc(&Ya, rows * Dp)); SSDCHK(falloc(&Yb, rows * Dp));
-            SSDCHK(falloc(&U, rows * Dp)); SSDCHK(falloc(&V, rows * Dp));
-            pl.ops.push_back(make_conv_op(h, before, cur, t1, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
-                                          {dense_level(ch, cwid, ch, cwid, before.CoutP)}, true));
-            push_dw_pw(h, pl.ops, sn_fuse, d1, after, t1, t2, Ya, B, ch, cwid, 2, SSD_ACT_NONE, SSD_ACT_RELU, before.Cout_l);
-            push_dw_pw(h, pl.ops, sn_fuse, d2, after2, cur, t3, Xa, B, ch, cwid, 2, SSD_ACT_NONE, SSD_ACT_RELU, before.Cin_l);
-            float *x = Xa, *y = Ya, *xs = Xb, *ys = Yb;
-            const int *tabx = h->tabs[st * 3], *taby = h->tabs[st * 3 + 1], *tabc = h->tabs[st * 3 + 2];
-            for (int j = 2; j <= units[st]; ++j) {
-                {   // concat_shuffle_split: (x, y) -> (xs, ys)
-                    Op g;
-                    g.cls = 5; g.flops = 0; g.bytes = 4.0 * rows * D * 4.0;
-                    const float *cx = x, *cy = y; float *ox = xs, *oy = ys;
-                    g.run = [=](hipStream_t s) {
-                        hipError_t e = launch_gather_channels(cx, Dp, cy, Dp, rows, tabx, Dp, ox, s);
-                        if (e != hipSuccess) return e;
-                        return launch_gather_channels(cx, Dp, cy, Dp, rows, taby, Dp, oy, s);
-                    };
-                    pl.ops.push_back(g);
-                }
-                const ConvW &b2 = h->pw[ipw], &a2 = h->pw[ipw + 1];
-                const DwW &dd = h->dw[idw];
-                ipw += 2; idw += 1;
-                pl.ops.push_back(make_conv_op(h, b2, xs, U, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
-                                              {dense_level(oh, ow, oh, ow, Dp)}, true));
-                // new x overwrites the old x buffer (dead after the shuffle); y' = ys
-                push_dw_pw(h, pl.ops, sn_fuse, dd, a2, U, V, x, B, oh, ow, 1, SSD_ACT_NONE, SSD_ACT_RELU, D);
-                // now (x, ys) is the live pair; old y and xs are free
-                float *oldy = y;
-                y = ys; ys = oldy;
-            }
-            // concat([x, y]) -> stage output in two-part rows [x half | y half] (weights.hip)
-            const int Cc = 2 * Dp;
-            float *S;
-            SSDCHK(falloc(&S, rows * Cc));
             {
-                Op g;
-                g.cls = 5; g.flops = 0; g.bytes = 4.0 * rows * D * 4.0;
-                const float *cx = x, *cy = y;
-                g.run = [=](hipStream_t s) { return launch_gather_channels(cx, Dp, cy, Dp, rows, tabc, Cc, S, s); };
-                pl.ops.push_back(g);
+                ssd_handle *hh = h;
+                const DwW f = h->first;
+                const int act = h->firstAct;
+                const size_t off = img_off + (size_t)b0 * srcH * srcW * 3;
+                Op op;
+                op.cls = 3;
+                op.flops = 2.0 * 27 * (double)nb * h2 * w2 * 24;
+                if (sn_front) {
+                    // first convolution + max pool as one launch (front.hip): the half-resolution tensor stays in LDS
+                    op.bytes = (double)nb * H * W * 3 + (double)nb * h4 * w4 * 24 * 4.0;
+                    op.run = [=](hipStream_t s) { return launch_front_pool(hh->cur_images + off, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, MP, s); };
+                    ops.push_back(op);
+                } else {
+                    SSDCHK(falloc(&F, (long long)nb * h2 * w2 * fc));
+                    op.bytes = (double)nb * H * W * 3 + (double)nb * h2 * w2 * 24 * 4.0;
+                    op.run = [=](hipStream_t s) {
+                        return launch_first_conv(hh->cur_images + off, nb, srcH, srcW, rnh, rnw, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s);
+                    };
+                    ops.push_back(op);
+                    Op mp;
+                    mp.cls = 5; mp.flops = 0;
+                    mp.bytes = ((double)nb * h2 * w2 + (double)nb * h4 * w4) * 24 * 4.0;
+                    mp.run = [=](hipStream_t s) { return launch_maxpool(F, nb, h2, w2, fc, MP, s); };
+                    ops.push_back(mp);
+                }
             }
-            if (st == 0) { C3 = S; pl.retained["c3"] = Retained{S, B, oh, ow, 2 * D, Cc, true, 0, D}; }
-            if (st == 1) { C4 = S; pl.retained["c4"] = Retained{S, B, oh, ow, 2 * D, Cc, true, 0, D}; }
-            cur = S;
-            ch = oh; cwid = ow;
+            const float *cur = MP;
+            for (int st = 0; st < 3; ++st) {
+                const StageGeo &g = geo[st];
+                const ConvW &before = h->pw[g.ipw], &after = h->pw[g.ipw + 1], &after2 = h->pw[g.ipw + 2];
+                const DwW &d1 = h->dw[g.idw], &d2 = h->dw[g.idw + 1];
+                const int D = g.D, Dp = g.Dp, n_units = g.n_units;
+                const long long rows = (long long)nb * g.oh * g.ow;
+                float *t1, *U;
+                SSDCHK(falloc(&t1, (long long)nb * g.ch * g.cw * before.CoutP));
+                SSDCHK(falloc(&U, rows * Dp));
+                float *sb = stage[st];
+                // producer p's tensor of this chain (0: unit_1's second branch = x, 1: its main branch = y, j: unit j's output)
+                auto tensor_off = [&](int p) { return g.toff[hf] + (long long)p * g.tbytes[hf]; };
+                // the chain's rows of S start b0 images into the stage output
+                float *S_chain = sb + g.soff / 4 + (long long)b0 * g.oh * g.ow * 2 * Dp;
+                struct Src { int prod, col; };
+                std::vector<Src> x(D), y(D);
+                for (int d = 0; d < D; ++d) { x[d] = Src{0, d}; y[d] = Src{1, d}; }
+                auto table = [&](const std::vector<Src> &v) {      // physical channel p of a D-channel row -> byte offset of its source
+                    std::vector<int> t(Dp, -1);
+                    for (int d = 0; d < D; ++d) t[ssd_phys_of_logical(d)] = (int)(tensor_off(v[d].prod) + (long long)ssd_phys_of_logical(v[d].col) * 4);
+                    return t;
+                };
+                std::vector<const int *> src_dev(n_units + 1, nullptr);
+                for (int j = 2; j <= n_units; ++j) {
+                    std::vector<Src> z(2 * D);
+                    for (int d = 0; d < D; ++d) { z[2 * d] = x[d]; z[2 * d + 1] = y[d]; }
+                    std::vector<Src> xin(z.begin(), z.begin() + D);
+                    int *dv;
+                    SSDCHK(ap.upload(&dv, table(xin)));
+                    src_dev[j] = dv;
+                    for (int d = 0; d < D; ++d) { x[d] = Src{j, d}; y[d] = z[D + d]; }
+                }
+                int *ysrc;
+                SSDCHK(ap.upload(&ysrc, table(y)));          // the stage output's y half (x = unit n's own channels)
+                ops.push_back(make_conv_op(h, before, cur, t1, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU,
+                                           {dense_level(g.ch, g.cw, g.ch, g.cw, before.CoutP)}, true));
+                SSDCHK(pair(d1, after, t1, g.ch, g.cw, 2, sb + tensor_off(1) / 4, 0));
+                SSDCHK(pair(d2, after2, cur, g.ch, g.cw, 2, sb + tensor_off(0) / 4, 0));
+                for (int j = 2; j <= n_units; ++j) {
+                    const ConvW &b2 = h->pw[g.ipw + 3 + 2 * (j - 2)], &a2 = h->pw[g.ipw + 3 + 2 * (j - 2) + 1];
+                    const DwW &dd = h->dw[g.idw + j];
+                    ops.push_back(make_pw_gather_op(b2, sb, g.total, src_dev[j], Dp * 4, rows, SSD_ACT_RELU, U));
+                    if (j < n_units) SSDCHK(pair(dd, a2, U, g.oh, g.ow, 1, sb + tensor_off(j) / 4, 0));
+                    else SSDCHK(pair(dd, a2, U, g.oh, g.ow, 1, S_chain, 2 * Dp));
+                }
+                {
+                    Op gop;
+                    gop.cls = 5; gop.flops = 0; gop.bytes = 2.0 * rows * D * 4.0;
+                    const int rs = Dp * 4, ors = 2 * Dp;
+                    float *ydst = S_chain + Dp;
+                    gop.run = [=](hipStream_t s) { return launch_gather_rows(sb, ysrc, rs, rows, Dp, ydst, ors, s); };
+                    ops.push_back(gop);
+                }
+                cur = S_chain;
+            }
+            ops.push_back(make_conv_op(h, c5w, cur, C5 + (long long)b0 * g2.oh * g2.ow * c5w.CoutP, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU,
+                                       {dense_level(g2.oh, g2.ow, g2.oh, g2.ow, c5w.CoutP)}, true, 0, X16, 0, FL));
         }
-        const ConvW &c5 = h->pw[ipw];
-        SSDCHK(falloc(&C5, (long long)B * ch * cwid * c5.CoutP));
-        pl.ops.push_back(make_conv_op(h, c5, cur, C5, nullptr, nullptr, B, 1, 0, SSD_ACT_RELU,
-                                      {dense_level(ch, cwid, ch, cwid, c5.CoutP)}, true, 0, X16, 0, FL));
-        pl.retained["c5"] = Retained{C5, B, ch, cwid, c5.Cout_l, c5.CoutP, true, X16};
+        for (int st = 0; st < 2; ++st) {
+            float *S = stage[st] + geo[st].soff / 4;
+            if (st == 0) C3 = S; else C4 = S;
+            pl.retained[st == 0 ? "c3" : "c4"] = Retained{S, B, geo[st].oh, geo[st].ow, 2 * geo[st].D, 2 * geo[st].Dp, true, 0, geo[st].D};
         }
+        pl.retained["c5"] = Retained{C5, B, g2.oh, g2.ow, c5w.Cout_l, c5w.CoutP, true, X16};
+        for (size_t i = 0; i < std::max(half_ops[0].size(), half_ops[1].size()); ++i)
+            for (int hf = 0; hf < nhalf; ++hf)
+                if (i < half_ops[hf].size()) {
+                    Op op = half_ops[hf][i];
+                    op.stream = hf;
+                    pl.ops.push_back(op);
+                    id_bb_last[hf] = (int)pl.ops.size() - 1;
+                }
     }
 
     // ---------------- FPN (feature_extractor.py:40-76)
@@ -844,25 +653,23 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     SSDCHK(falloc(&X3, (long long)B * py.h[0] * py.w[0] * 256));
     SSDCHK(falloc(&T6, (long long)B * py.h[3] * py.w[3] * 256));
     auto lvl = [&](int l, int CoutP) { return dense_level(py.h[l], py.w[l], py.h[l], py.w[l], CoutP); };
-    // Three streams, explicit dependencies.  Main: lateral5 -> lateral4 (+up) -> lateral3 (+up) -> p3 (the critical
-    // path); second stream: p5 (needs x5) -> p4 (needs x4); third stream: p6 -> p7 (need only c5).  p6 is a chain of
-    // 288 dependent K-steps on a handful of tiles (K = 9 x 1024, M = B x 140): at batch 1 it takes 0.29 ms whatever
-    // the GPU does beside it, so nothing may queue behind it -- with p7, p5, p4 behind it on one stream the head towers
-    // started 0.12 ms later (batch-1 kernel trace, profiles/r02_batch1_timeline.txt).
-    // All of them are the same 3x3 kernel, and two such kernels side by side fill each other's
-    // tails (measured: paired tower layers run at 0.91 of the MFMA peak, a lone one at 0.85).
+    // Three streams, explicit dependencies.  Serving batches: main: lateral5 -> lateral4 (+up) -> lateral3 (+up) -> p3 (the
+    // critical path); second stream: p5 (needs x5) -> p4 (needs x4); third stream: p6 -> p7 (need only c5).
+    // All of them are the same 3x3 kernel, and two such kernels side by side fill each other's tails.
     auto push = [&](Op op, int stream, std::vector<int> deps = {}) {
         op.stream = stream;
         std::sort(deps.begin(), deps.end());                     // (one wait per producer: with p7 inside the grouped launch the towers
         deps.erase(std::unique(deps.begin(), deps.end()), deps.end());      //  name that launch twice)
         op.deps = deps;
         pl.ops.push_back(op);
-        if (stream == 1) pl.last_aux = (int)pl.ops.size() - 1;
         return (int)pl.ops.size() - 1;
     };
     // last backbone op on the main stream (produces c5, or its first half); the second half, if any, ends on the
     // second stream: the main stream's first FPN op waits for it
     const int id_c5 = id_bb_last[0] >= 0 ? id_bb_last[0] : (int)pl.ops.size() - 1;
+    // Batch 1-2 in exact fp32: p3, p4, p5 (the same 3x3 256 -> 256 + batch norm + ReLU on x3, x4, x5) and p7 as ONE launch
+    // behind lateral3, each level with its own kernel (IgemmLevel::wt_off into h->pgroup) and batch norm: 736 tiles -- a
+    // tower-sized launch -- instead of three launches that stretch each other.  Option fpn_group = 0 / 1 pins it.
     bool grouped = false;
     if (!X16 && h->pgroup.wt) {
         const long long b64 = (((long long)B * py.h[0] * py.w[0] + 63) / 64) * (256 / 64);
@@ -870,26 +677,17 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         const int pin = ssd_opt(h, OPT_FPN_GROUP, -1);
         if (pin >= 0) grouped = pin != 0;
     }
-    // Batch <= 2 with the grouped launch: p6 -> p7 on the MAIN stream right behind c5 and the lateral chain on the third stream
-    // beside them; the grouped launch waits for lateral3 (done long before p7) and nothing waits for p7 across streams.  With
-    // p6 -> p7 on the third stream (option fpn_p6_first = 0) p6 is starved beside the grouped launch -- a chain of 32-cycle MFMAs
-    // among 64-cycle ones: 57 us alone, ~170 there -- and the towers wait ~50 us for p7 behind it; the grouped launch waiting
-    // for p6 or p7 there (= 1 / 2) moved nothing.  Batch-1 forward 1.661 -> 1.653 ms (profiles/r03_batch1_option_ab.log).
-    const int p6opt = ssd_opt(h, OPT_FPN_P6_FIRST, 3);
-    const bool swap67 = grouped && B <= 2 && !ssd_opt(h, OPT_GRAPH, 0) && (p6opt == 3 || p6opt == 4);
-    // = 4: p6 on the caller's stream, p7 (needs p6 only) on the third stream BEHIND the laterals and beside the grouped launch,
-    // which then follows p6 directly: p7's 17 us leave the critical path c5 -> p6 -> grouped -> towers (the towers wait for it)
-    const bool p7side = swap67 && p6opt == 4;
-    // fpn p7 (3x3 stride 2 on ReLU(p6 pre-BN), 35 positions per image: four more 64x64 tiles of the same 72 K-steps) as a fourth
-    // level of the grouped launch behind p6: its launch (17 us alone, a chain of 576 dependent 16x16x4 MFMAs on 48 waves) and
-    // one kernel boundary leave the critical path c5 -> p6 -> p7 -> grouped -> towers.  Same k-ordered chain, same bits.
-    const bool p7grouped = swap67 && !p7side && ssd_opt(h, OPT_FPN_P7_GROUP, 1) != 0;
+    // ... and then p6 (-> p7) runs on the MAIN stream right behind c5 with the lateral chain on the third stream beside it: the
+    // grouped launch waits for lateral3 (done long before p6) and nothing waits for p6 across streams.
+    const bool swap67 = grouped && B <= 2;
+    // fpn p7 (3x3 stride 2 on ReLU(p6 pre-BN), 35 positions per image) as a fourth level of the grouped launch behind p6: its
+    // launch and one kernel boundary leave the critical path c5 -> p6 -> p7 -> grouped -> towers.  Same k-ordered chain, same bits.
+    const bool p7grouped = swap67 && ssd_opt(h, OPT_FPN_P7_GROUP, 1) != 0;
     const int s_lat = swap67 ? 2 : 0;
     // Batch <= 2 (swap67), one backbone chain: lateral4(c4) and lateral3(c3) -- WITHOUT their upsampled operands -- on the third
     // stream as soon as c4 exists (c3 precedes it on the caller's stream), beside the backbone's last four layers; behind c5
     // the third stream then runs lateral5 and ONE elementwise launch for both top-down sums (fpn_merge_kernel) instead of a
-    // chain of three convolutions: since p6 lost its v_mov packing (62 -> 44 us) that chain (55 us beside p6) was the longer
-    // side of the fork in front of the grouped launch.  Same additions, same bits.  Option fpn_early_lat = 0 / 1 pins it.
+    // chain of three convolutions.  Same additions, same bits.  Option fpn_early_lat = 0 / 1 pins it.
     bool early = swap67 && !X16 && id_c4 >= 0;
     { const int pin = ssd_opt(h, OPT_FPN_EARLY_LAT, -1); if (pin >= 0) early = early && pin != 0; }
     float *L4T = nullptr;
@@ -902,28 +700,18 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     for (int c = 1; c < 4; ++c) if (id_bb_last[c] >= 0) l5_deps.push_back(id_bb_last[c]);
     if (swap67) l5_deps.push_back(id_c5);
     const int id_l5 = push(make_conv_op(h, h->lat[2], C5, X5, nullptr, nullptr, B, 1, 0, SSD_ACT_NONE, {lvl(2, 256)}, true, X16, X16, 0, FL), s_lat, l5_deps);
-    // (hipGraph capture of a forward with this third forked stream crashed inside the ROCm 7.2 runtime, and so did a captured
-    //  wait on an event of the waiting stream itself: with option graph = 1 p6 -> p7 stay on the second stream, in front of p5
-    //  and p4, as in round 1; enqueue_forward skips same-stream waits)
-    const int s6 = ssd_opt(h, OPT_GRAPH, 0) ? 1 : 2;
     std::vector<int> p6_deps = {id_c5};             // c5 of every backbone chain that is not on p6's own stream
-    for (int c = 1; c < 4; ++c) if (c != s6 && id_bb_last[c] >= 0) p6_deps.push_back(id_bb_last[c]);
-    int id_p6, id_p7;
+    for (int c = 1; c < 4; ++c) if (c != 2 && id_bb_last[c] >= 0) p6_deps.push_back(id_bb_last[c]);
+    int id_p7;
     {   // p6 = conv s2 (c5): BN+ReLU -> P6, ReLU(raw) -> T6 (input of p7, :60)
         LevelDesc d = dense_level(py.h[2], py.w[2], py.h[3], py.w[3], 256);
         d.out_off = py.off[3];
-        id_p6 = push(make_conv_op(h, h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), swap67 ? 0 : s6, p6_deps);
+        push(make_conv_op(h, h->pconv[3], C5, P, T6 - py.off[3], nullptr, B, 2, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), swap67 ? 0 : 2, p6_deps);
         LevelDesc d7 = dense_level(py.h[3], py.w[3], py.h[4], py.w[4], 256);
         d7.out_off = py.off[4];
-        if (!p7side && !p7grouped) id_p7 = push(make_conv_op(h, h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true, X16, X16, 0, FL), swap67 ? 0 : s6);
+        if (!p7grouped) id_p7 = push(make_conv_op(h, h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true, X16, X16, 0, FL), swap67 ? 0 : 2);
         else id_p7 = -1;
     }
-    // Batch 1 in exact fp32: p3, p4 and p5 (the same 3x3 256 -> 256 + batch norm + ReLU on x3, x4, x5) as ONE launch behind
-    // lateral3, each level with its own kernel (IgemmLevel::wt_off into h->pgroup) and batch norm.  Measured, one stream
-    // (profiles/r03_batch1_timeline_single_stream.txt): p3 105 us (560 tiles of 64x64: 2.2 per CU), p4 38, p5 38 us alone;
-    // beside each other on three streams they stretched to 129 / 73 / 61 us and the towers started 266 us after c5.  The
-    // grouped launch is 736 tiles -- a tower-sized launch, ~108 us -- and nothing else competes with the lateral chain.
-    // Option fpn_group = 0 / 1 pins it.
     if (!grouped) {   // p5 = conv(x5)
         LevelDesc d = lvl(2, 256);
         d.out_off = py.off[2];
@@ -955,16 +743,10 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     }
     const int id_l3 = early ? id_merge
                             : push(make_conv_op(h, h->lat[0], C3, X3, nullptr, X4, B, 1, 0, SSD_ACT_NONE, {lvl(0, 256)}, true, LF, X16, X16, FL), s_lat);
-    if (p7side) {
-        LevelDesc d7 = dense_level(py.h[3], py.w[3], py.h[4], py.w[4], 256);
-        d7.out_off = py.off[4];
-        id_p7 = push(make_conv_op(h, h->pconv[4], T6, P, nullptr, nullptr, B, 2, 1, SSD_ACT_RELU, {d7}, true, X16, X16, 0, FL), s_lat, {id_p6});
-    }
     if (!grouped) {
         LevelDesc d = lvl(0, 256);
         d.out_off = py.off[0];
         id_p3 = push(make_conv_op(h, h->pconv[0], X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, {d}, true, X16, X16, 0, FL), 0);
-        pl.ops[id_p3].fpn_end = true;
     } else {
         const ConvW &g = h->pgroup;
         const float *xin[3] = {X3, X4, X5};
@@ -988,11 +770,8 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         }
         std::vector<int> gdeps;
         if (swap67) gdeps.push_back(id_l3);
-        else if (s6 == 2 && p6opt == 1) gdeps.push_back(id_p6);
-        else if (s6 == 2 && p6opt == 2) gdeps.push_back(id_p7);
         id_p3 = id_p4 = push(make_conv_op(h, g, X3, P, nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv3, true), 0, gdeps);
         if (p7grouped) id_p7 = id_p3;
-        pl.ops[id_p3].fpn_end = true;
     }
     for (int l = 0; l < 5; ++l) {
         char nm[8];
@@ -1029,144 +808,50 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     HIPCHK(hipMemset(p.scan_bits, 0, post_scan_bitmap_bytes(B, (int)N, C)));
     HIPCHK(hipMemset(p.counts, 0, (size_t)B * C * sizeof(int)));      // the post-processing kernels leave these zeroed again
     p.self_clean = 1;
-    // (Measured and not adopted, batch 1: the two coarse levels -- 175 of 11 935 positions -- as launches of their own on a
-    //  third / fourth stream behind p7, so that the towers of levels 3..5 start when p3..p5 exist: 2.12 -> 2.29 ms per forward;
-    //  ten more launches of 72-step chains beside the big ones cost more than the 0.07 ms earlier start.  option level_split = 1
-    //  keeps the experiment reachable.)
-    const bool split_levels = B <= 2 && s6 == 2 && ssd_opt(h, OPT_LEVEL_SPLIT, 0) == 1;
-    // (Measured and not adopted either, round 3, level_split = 2: only the FIRST tower layer split -- its levels 3..5 start when
-    //  p3..p5 exist (p6, starved beside the grouped p3+p4+p5 launch, and p7 behind it hold the towers back ~50 us), its levels
-    //  6..7, 175 positions on the latency kernel, run behind p7 on p7's stream, and the second layer waits for both: batch-1
-    //  forward 1.674 -> 1.700 ms, batch 2 unchanged.  The earlier tower layer starves p6 for longer.)
-    const bool split0 = !split_levels && !X16 && B <= 2 && s6 == 2 && ssd_opt(h, OPT_LEVEL_SPLIT, 0) == 2;
-    // Option tower_group = 1 (exact fp32): layer i of the box tower and of the class tower as ONE launch over 2 x 5 levels
-    // (h->tgroup: both kernels, the ten batch norms; a level's IgemmLevel carries its net's kernel offset, input and output).
-    // Its time does not depend on which hardware queues the plan's streams got (ssd_side_stream above), and a one-stream plan
-    // gains 1.9 % with it (784 -> 799 img/s) -- but two launches side by side on two well-placed streams are a little better
-    // still: they run out of phase, one's prologues and epilogues under the other's K loops, where the blocks of ONE launch
-    // start and finish together.  Measured (profiles/r03_hw_queue_mapping.log): 32 images 806 / 810 img/s grouped against 812 /
-    // 816 on two streams; batch-1 forward 1.680-1.689 ms in seven processes against 1.658-1.689 (mean 1.670).  Off.
-    bool tgrouped = false;
-    { const int pin = ssd_opt(h, OPT_TOWER_GROUP, -1); if (pin >= 0) tgrouped = !X16 && !split_levels && h->tgroup[0].wt != nullptr && pin != 0; }
-    const int ngrp = split_levels ? 2 : 1;
-    const int g_lo[2] = {0, 3}, g_hi[2] = {split_levels ? 3 : 5, 5};
-    std::vector<Op> tower_ops[2][2];            // [tower][level group]
-    std::vector<Op> tg_ops;                     // grouped form: layer i of both towers
-    Op coarse0[2];                              // split0: the first layer's levels 6..7
-    const float *tower_out[2] = {nullptr, nullptr};
+    std::vector<Op> tower_ops[2];
     float *TAB[2][2];
     for (int t = 0; t < 2; ++t)
         for (int k = 0; k < 2; ++k) SSDCHK(falloc(&TAB[t][k], py.total));
-    if (tgrouped) {
-        const float *in[2] = {P, P};
-        int cur = 0;
-        for (int i = 0; i < 4; ++i) {
-            const ConvW &g = h->tgroup[i];
-            std::vector<LevelDesc> lv;
-            for (int t = 0; t < 2; ++t)
-                for (int l = 0; l < 5; ++l) {
-                    LevelDesc d = dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, (in[t] - in[0]) + py.off[l],
-                                              (TAB[t][cur] - TAB[0][cur]) + py.off[l], (t * 5 + l) * g.CoutP);
-                    d.wt_off = (long long)t * g.taps * g.CoutPad * g.CinP;
-                    lv.push_back(d);
-                }
-            tg_ops.push_back(make_conv_op(h, g, in[0], TAB[0][cur], nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true));
-            for (int t = 0; t < 2; ++t) in[t] = TAB[t][cur];
-            cur ^= 1;
-        }
-        for (int t = 0; t < 2; ++t) tower_out[t] = in[t];
-    }
     bool all_marked = true;
     for (int t = 0; t < 2; ++t) {
         const float *in = P;
         int cur = 0;
-        if (!tgrouped) {
-            for (int i = 0; i < 4; ++i) {
-                for (int g = 0; g < ngrp; ++g) {
-                    std::vector<LevelDesc> lv;
-                    const int hi = (split0 && i == 0) ? 3 : g_hi[g];
-                    for (int l = g_lo[g]; l < hi; ++l) lv.push_back(dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, py.off[l], py.off[l], l * 256));
-                    tower_ops[t][g].push_back(make_conv_op(h, h->tower[t][i], in, TAB[t][cur], nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true, X16, X16, 0, FL));
-                }
-                if (split0 && i == 0) {
-                    std::vector<LevelDesc> lv;
-                    for (int l = 3; l < 5; ++l) lv.push_back(dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, py.off[l], py.off[l], l * 256));
-                    coarse0[t] = make_conv_op(h, h->tower[t][i], in, TAB[t][cur], nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true, X16, X16, 0, FL);
-                }
-                in = TAB[t][cur];
-                cur ^= 1;
-            }
-        } else {
-            in = tower_out[t];
+        for (int i = 0; i < 4; ++i) {
+            std::vector<LevelDesc> lv;
+            for (int l = 0; l < 5; ++l) lv.push_back(dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 256, py.off[l], py.off[l], l * 256));
+            tower_ops[t].push_back(make_conv_op(h, h->tower[t][i], in, TAB[t][cur], nullptr, nullptr, B, 1, 1, SSD_ACT_RELU, lv, true, X16, X16, 0, FL));
+            in = TAB[t][cur];
+            cur ^= 1;
         }
         const int per = t == 0 ? 4 : C;     // values per anchor
         // class logits: the convolution's epilogue also marks the octets that hold a candidate (p.scan_bits) and
         // post_scan_kernel reads the bitmap instead of all logits
         const bool can_mark = t == 1 && ((long long)N * C) % 8 == 0 && (6 * C) % 8 == 0;
-        for (int g = 0; g < ngrp; ++g) {
-            std::vector<LevelDesc> lv;
-            for (int l = g_lo[g]; l < g_hi[g]; ++l) {
-                LevelDesc d = dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 0, py.off[l]);
-                d.out_off = aoff[l] * per;
-                d.out_bstride = N * per;
-                d.out_rstride = A * per;
-                d.param_off = 0;
-                lv.push_back(d);
-            }
-            bool marked = false;
-            Op fop = make_conv_op(h, h->final_[t], in, t == 0 ? codes : logits, nullptr, nullptr, B, 1, 1, SSD_ACT_NONE, lv, false, X16, 0, 0, FL,
-                                  can_mark ? p.scan_bits : nullptr, conservative_logit_bound(h->cfg.score_threshold), &marked);
-            if (t == 1) all_marked = all_marked && marked;
-            tower_ops[t][g].push_back(fop);
+        std::vector<LevelDesc> lv;
+        for (int l = 0; l < 5; ++l) {
+            LevelDesc d = dense_level(py.h[l], py.w[l], py.h[l], py.w[l], 0, py.off[l]);
+            d.out_off = aoff[l] * per;
+            d.out_bstride = N * per;
+            d.out_rstride = A * per;
+            d.param_off = 0;
+            lv.push_back(d);
         }
+        bool marked = false;
+        Op fop = make_conv_op(h, h->final_[t], in, t == 0 ? codes : logits, nullptr, nullptr, B, 1, 1, SSD_ACT_NONE, lv, false, X16, 0, 0, FL,
+                              can_mark ? p.scan_bits : nullptr, conservative_logit_bound(h->cfg.score_threshold), &marked);
+        if (t == 1) all_marked = all_marked && marked;
+        tower_ops[t].push_back(fop);
     }
     p.scan_fused = all_marked ? 1 : 0;
     // enqueue order interleaved so the hardware queues stay fed.  The first box-tower layer (main) needs p4, p5 from the
-    // second stream (and, unless the coarse levels run apart, p6, p7 from the third); the first class-tower layer (second
-    // stream) needs p3 from the main stream (and p6, p7).  Coarse-level chains: box on the third stream (behind p7, same
-    // stream), class on the fourth (waits for p7).
-    // Option head_serial = 1: the box head (24 of 32 columns, 1.3 GFLOP) BEHIND the class logits on the second stream instead
-    // of beside them.  Batch 1, alone: logits 203 us, box head 41 us; side by side 293 / 168 us when the class tower finishes
-    // first -- but when the box tower does, the box head runs beside the class tower's last layer and the logits run alone:
-    // measured on one box, serial 1 823 us per forward, side by side 1 782 us (profiles/r03_batch1_timeline_*.txt).  Off.
-    bool head_serial = false;
-    { const int pin = ssd_opt(h, OPT_HEAD_SERIAL, -1); if (pin >= 0) head_serial = pin != 0 && !split_levels; }
-    if (tgrouped) {
-        // main stream: the four grouped tower layers, then the class logits; the box head beside the logits on the second stream
-        int id_last = -1;
-        for (size_t i = 0; i < tg_ops.size(); ++i) {
-            std::vector<int> deps;
-            if (i == 0) { deps.push_back(id_p3); deps.push_back(id_p4); deps.push_back(id_p7); }
-            id_last = push(tg_ops[i], 0, deps);
-        }
-        const int id_logits = push(tower_ops[1][0][0], 0);
-        if (head_serial) push(tower_ops[0][0][0], 0);
-        else push(tower_ops[0][0][0], 1, {id_last});
-        (void)id_logits;
-    } else {
-    int id_box_last = -1;
-    int id_coarse0[2] = {-1, -1};
-    if (split0)
-        for (int t = 0; t < 2; ++t) id_coarse0[t] = push(coarse0[t], s6, {id_p7});     // behind p7 (a same-stream wait is skipped)
-    for (size_t i = 0; i < tower_ops[0][0].size(); ++i)
+    // second stream and p6, p7 from the third; the first class-tower layer (second stream) needs p3 from the main stream
+    // (and p6, p7).  The box head (24 of 32 columns) runs beside the class logits.
+    for (size_t i = 0; i < tower_ops[0].size(); ++i)
         for (int t = 1; t >= 0; --t) {
             std::vector<int> deps;
-            if (i == 0) { deps.push_back(t == 0 ? id_p4 : id_p3); if (!split_levels && !split0) deps.push_back(id_p7); }
-            if (i == 1 && split0) deps.push_back(id_coarse0[t]);
-            if (head_serial && t == 0 && i + 1 == tower_ops[0][0].size()) {
-                push(tower_ops[0][0][i], 1, {id_box_last});          // behind the logits (pushed just before), after the box tower
-                continue;
-            }
-            const int id = push(tower_ops[t][0][i], t, deps);
-            if (t == 0) id_box_last = id;
-            if (split_levels) {
-                std::vector<int> d2;
-                if (i == 0) d2.push_back(id_p7);
-                push(tower_ops[t][1][i], t == 0 ? 2 : 3, d2);
-            }
+            if (i == 0) { deps.push_back(t == 0 ? id_p4 : id_p3); deps.push_back(id_p7); }
+            push(tower_ops[t][i], t, deps);
         }
-    }
-    pl.tail_on[0] = pl.tail_on[1] = split_levels;
     {   // does a chain start on an internal stream without a dependency (the second backbone chain from 4 images on)?
         bool seen[4] = {true, false, false, false};
         for (const Op &op : pl.ops) {
@@ -1236,35 +921,21 @@ static hipError_t run_op(ssd_handle *h, const Op &op, hipStream_t s)
 // torch.distributed, RCCL's streams first: 788 instead of 822 img/s; a second engine in one process: batch-1 forward +30 us).
 // The streams are created once per process, with the first plan; a process that wants the clean mapping creates its first
 // engine (and runs one forward) before other stream-creating libraries -- bench.py does, INTEGRATION.md section 2.
-// Measured and not adopted (profiles/r03_batch1_option_ab.log): streams of the highest priority, whose queues come from a
-// pool of their own (option streams = 2): robust against what the framework created, 815 / 807 img/s plain / under
-// torch.distributed -- but with two engines in a process the second one's batch-1 forward took 2.4 ms instead of 1.64 (more
-// hardware queues than the command processor holds resident; GPU_MAX_HW_QUEUES=8 shows the same cliff at the third engine);
-// a CU-masked stream, which gets a queue of its own, is a BLOCKING stream (hipExtStreamCreateWithCUMask has no flags) and
-// would serialise with the legacy default stream.
-int ssd_side_stream(ssd_handle *h, hipStream_t *out)
-{
-    int least = 0, greatest = 0;
-    if (ssd_opt(h, OPT_STREAMS, 0) == 2 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
-        if (hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest) == hipSuccess) return SSD_OK;
-        (void)hipGetLastError();
-    }
-    HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
-    return SSD_OK;
-}
-
+// (Measured and not adopted, profiles/r03_batch1_option_ab.log: streams of the highest priority, whose queues come from a pool
+// of their own -- robust against what the framework created, but a second engine's batch-1 forward took 2.4 ms instead of 1.64;
+// a CU-masked stream is a BLOCKING stream and would serialise with the legacy default stream.)
 int make_plans(ssd_handle *h, int B, int H, int W)
 {
     free_plans(h);
-    // Measured on MI355X (B = 32, 640x896): 1 / 2 / 4 / 8 sub-batches -> 730 / 696 / 647 / 587 img/s.
-    // Backbone kernels running beside head kernels take CU slots from them and stretch far more
-    // than the overlap returns, so the default is ONE plan; option nsub keeps the experiment alive.
+    // ONE plan per forward (round 1: 1 / 2 / 4 / 8 staggered sub-batch plans -> 730 / 696 / 647 / 587 img/s: backbone kernels
+    // beside head kernels take CU slots from them and stretch far more than the overlap returns).  Consecutive sub-batch plans
+    // exist for one reason: every tensor a launch addresses with 32-bit byte offsets must stay < 2 GiB.  Per image: the largest
+    // backbone tensor (first conv / max-pool output [H/2, W/2, 32]; MobileNet's Conv2d_1_pointwise doubles the channels at that
+    // resolution), the concatenated pyramid of a head tower (256 channels), the class logits [N, C], the box codes, and the
+    // uint8 source image.  Option nsub = n forces at least n plans (the tests' way to reach this path without a 2 GiB batch).
     int nsub = 1;
     { const int v = ssd_opt(h, OPT_NSUB, 0); if (v >= 1 && v <= 8) nsub = v; }
-    {   // every tensor a launch addresses with 32-bit byte offsets must stay < 2 GiB -> split very large batches into
-        // consecutive sub-batch plans.  Per image: the largest backbone tensor (first conv / max-pool output
-        // [H/2, W/2, 32]; MobileNet's Conv2d_1_pointwise doubles the channels at that resolution), the concatenated
-        // pyramid of a head tower (256 channels), the class logits [N, C], the box codes, and the uint8 source image.
+    {
         const ResizeDims rd = resize_dims(H, W, h->cfg.min_dimension, 128);
         const int nH = rd.nh + rd.ph, nW = rd.nw + rd.pw;
         const int cmax = h->cfg.backbone == SSD_BACKBONE_MOBILENET && !h->pw.empty() ? std::max(h->firstCp, h->pw[0].CoutP) : h->firstCp;
@@ -1273,6 +944,14 @@ int make_plans(ssd_handle *h, int B, int H, int W)
         per_img = std::max(per_img, py1.total * 4);
         per_img = std::max(per_img, (long long)ssd_num_anchors(nH, nW) * std::max(h->cfg.num_classes, 4) * 4);
         per_img = std::max(per_img, (long long)H * W * 3);
+        if (h->cfg.backbone == SSD_BACKBONE_SHUFFLENET) {        // a ShuffleNet stage is one allocation: its producers' tensors + its two-part output
+            const int un[3] = {4, 8, 4};
+            int ipw = 0, hh = nH / 8, ww = nW / 8;
+            for (int st = 0; st < 3 && ipw + 1 < (int)h->pw.size(); ++st) {
+                per_img = std::max(per_img, (long long)hh * ww * (un[st] + 2) * h->pw[ipw + 1].CoutP * 4);
+                ipw += 3 + 2 * (un[st] - 1); hh /= 2; ww /= 2;
+            }
+        }
         const long long bmax = ((1LL << 31) - 1) / per_img;
         if (bmax < 1) return ssd_fail(SSD_ERR_INVALID, "ssd_forward: image too large for one launch");
         const int need = (int)((B + bmax - 1) / bmax);
@@ -1284,41 +963,25 @@ int make_plans(ssd_handle *h, int B, int H, int W)
         const int bk = B / nsub + (k < B % nsub ? 1 : 0);
         Plan *pl = new Plan();
         h->plans.push_back(pl);
-        {   // option side_priority: the third / fourth stream (fpn p6 -> p7 at batch 1) at the lowest (1) / highest (2) dispatch
-            // priority (measurements: DESIGN section 8) -- streams of the plan's own; otherwise the handle's
-            int least = 0, greatest = 0;
-            const int want = ssd_opt(h, OPT_SIDE_PRIORITY, 0);          // 1: lowest, 2: highest
-            const bool have = (want == 1 || want == 2) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
-            if (have) {
-                pl->own_streams = true;
-                if (k > 0) HIPCHK(hipStreamCreateWithFlags(&pl->s_main, hipStreamNonBlocking));
-                HIPCHK(hipStreamCreateWithFlags(&pl->s_aux, hipStreamNonBlocking));
-                for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithPriority(&pl->s_bb[i], hipStreamNonBlocking, want == 1 ? least : greatest));
-            } else {
-                // ONE set of internal streams per device and process, created by the first plan that needs them and shared by every
-                // handle after it (a handle's ops stay ordered per stream and across streams by their events; two handles that
-                // run at the same time merely take turns on them): a second engine -- bench.py's ShuffleNet leg behind the
-                // MobileNet one -- runs on the hardware queues the first one got, instead of on whatever is least loaded by then
-                // (measured: 1 113 instead of 1 200 img/s when its class-tower stream landed on the caller's queue).
-                static std::mutex pool_mu;
-                static std::map<int, std::vector<hipStream_t>> pool;       // device -> [4 k + i]
-                std::lock_guard<std::mutex> lk(pool_mu);
-                std::vector<hipStream_t> &pv = pool[h->cfg.device];
-                if (pv.size() < (size_t)4 * (k + 1)) pv.resize((size_t)4 * (k + 1), nullptr);
-                hipStream_t *ss = &pv[(size_t)4 * k];
-                for (int i = (k > 0 ? 0 : 1); i < 4; ++i)
-                    if (!ss[i]) SSDCHK(ssd_side_stream(h, &ss[i]));
-                pl->s_main = k > 0 ? ss[0] : nullptr;
-                pl->s_aux = ss[1];
-                pl->s_bb[0] = ss[2];
-                pl->s_bb[1] = ss[3];
-            }
+        {
+            // ONE set of internal streams per device and process, created by the first plan that needs them and shared by every
+            // handle and every sub-batch plan after it (a handle's ops stay ordered per stream and across streams by their events;
+            // two handles that run at the same time merely take turns on them): a second engine -- bench.py's ShuffleNet leg behind
+            // the MobileNet one -- runs on the hardware queues the first one got, instead of on whatever is least loaded by then
+            // (measured: 1 113 instead of 1 200 img/s when its class-tower stream landed on the caller's queue).
+            static std::mutex pool_mu;
+            static std::map<int, std::vector<hipStream_t>> pool;       // device -> [second, third, fourth stream]
+            std::lock_guard<std::mutex> lk(pool_mu);
+            std::vector<hipStream_t> &pv = pool[h->cfg.device];
+            if (pv.size() < 3) pv.resize(3, nullptr);
+            for (int i = 0; i < 3; ++i)
+                if (!pv[i]) HIPCHK(hipStreamCreateWithFlags(&pv[i], hipStreamNonBlocking));
+            pl->s_aux = pv[0];
+            pl->s_bb[0] = pv[1];
+            pl->s_bb[1] = pv[2];
         }
-        HIPCHK(hipEventCreateWithFlags(&pl->ev_fpn, ssd_sync_event_flags(h)));
         HIPCHK(hipEventCreateWithFlags(&pl->ev_join, ssd_sync_event_flags(h)));
-        HIPCHK(hipEventCreateWithFlags(&pl->ev_done, ssd_sync_event_flags(h)));
         HIPCHK(hipEventCreateWithFlags(&pl->ev_begin, ssd_sync_event_flags(h)));
-        for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&pl->ev_join_bb[i], ssd_sync_event_flags(h)));
         SSDCHK(build_plan(h, *pl, bk, H, W, img0));
         img0 += bk;
     }
@@ -1326,8 +989,8 @@ int make_plans(ssd_handle *h, int B, int H, int W)
     return SSD_OK;
 }
 
-// Enqueues one forward on stream `s` (plus the plans' internal streams): kernels only, no host
-// synchronisation -- also what a hipGraph capture records.
+// Enqueues one forward on stream `s` (plus the plans' internal streams): kernels only, no host synchronisation.  Sub-batch plans
+// (batches past 2 GiB of activations) run one after the other: every plan starts on `s` and joins back into it.
 int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, int32_t *labels_dev,
                            float *scores_dev, int32_t *num_boxes_dev, long long out_stride, hipStream_t s)
 {
@@ -1339,43 +1002,30 @@ int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, 
         h->ref_evs.push_back(ref);
     }
     const int T = h->cfg.num_classes * h->cfg.max_boxes_per_class;
-    if (h->plans.size() > 1) HIPCHK(hipEventRecord(h->ev_start, s));       // (sub-batch plans start behind the caller's prior work)
     for (size_t k = 0; k < h->plans.size(); ++k) {
         Plan &pl = *h->plans[k];
-        hipStream_t sm = pl.s_main ? pl.s_main : s;
-        if (k > 0) {
-            // staggered start: after the caller's prior work, and once the previous sub-batch
-            // has left its backbone + FPN (so this backbone runs beneath that one's heads)
-            HIPCHK(hipStreamWaitEvent(sm, h->ev_start, 0));
-            HIPCHK(hipStreamWaitEvent(sm, h->plans[k - 1]->ev_fpn, 0));
-        }
-        if (pl.need_begin) HIPCHK(hipEventRecord(pl.ev_begin, sm));
-        // option streams = 1: every op on the plan's main stream, in plan order (a valid order: an op's dependencies precede it) --
+        // (k > 0: the previous plan's side streams were joined into `s` before its post-processing, and this plan's chains on
+        //  them start behind ev_begin or behind an op of this plan: the shared streams need no further ordering)
+        if (pl.need_begin) HIPCHK(hipEventRecord(pl.ev_begin, s));
+        // option streams = 1: every op on the caller's stream, in plan order (a valid order: an op's dependencies precede it) --
         // a measurement aid that shows what the kernels cost without each other beside them
         const bool single = ssd_opt(h, OPT_STREAMS, 0) == 1;
-        bool aux_used = false, started[4] = {true, false, false, false};
+        bool used[4] = {true, false, false, false};
         for (const Op &op : pl.ops) {
             const int os = single ? 0 : op.stream;
-            hipStream_t st = os == 0 ? sm : (os == 1 ? pl.s_aux : pl.s_bb[os - 2]);
-            if (!started[os] && op.deps.empty())                    // a chain that starts on another stream:
+            hipStream_t st = os == 0 ? s : (os == 1 ? pl.s_aux : pl.s_bb[os - 2]);
+            if (!used[os] && op.deps.empty())                       // a chain that starts on another stream:
                 HIPCHK(hipStreamWaitEvent(st, pl.ev_begin, 0));     // behind the plan's own start
-            started[os] = true;
-            for (int d : op.deps)           // (same stream: already ordered -- and a captured self-wait corrupted the ROCm 7.2 graph runtime's heap)
+            used[os] = true;
+            for (int d : op.deps)           // (same stream: already ordered)
                 if (!single && pl.ops[d].stream != op.stream) HIPCHK(hipStreamWaitEvent(st, pl.ops[d].done, 0));
             HIPCHK(run_op(h, op, st));
             if (op.done && !single) HIPCHK(hipEventRecord(op.done, st));
-            if (op.fpn_end && h->plans.size() > 1) HIPCHK(hipEventRecord(pl.ev_fpn, sm));     // (only a following sub-batch plan waits for it)
-            aux_used |= os == 1;
         }
-        if (aux_used) {                             // join before the post-processing reads the logits
+        if (used[1]) {                              // join before the post-processing reads the logits
             HIPCHK(hipEventRecord(pl.ev_join, pl.s_aux));
-            HIPCHK(hipStreamWaitEvent(sm, pl.ev_join, 0));
+            HIPCHK(hipStreamWaitEvent(s, pl.ev_join, 0));
         }
-        for (int c = 2; c < 4; ++c)                 // ... and the third / fourth stream, when the plan ends chains there
-            if (pl.tail_on[c - 2] && !single) {
-                HIPCHK(hipEventRecord(pl.ev_join_bb[c - 2], pl.s_bb[c - 2]));
-                HIPCHK(hipStreamWaitEvent(sm, pl.ev_join_bb[c - 2], 0));
-            }
         PostArgs p = pl.post;
         p.out_stride = out_stride;
         p.boxes = boxes_dev + (out_stride ? (size_t)pl.img0 * out_stride : (size_t)pl.img0 * T * 4);
@@ -1388,9 +1038,7 @@ int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, 
         pop.flops = 0;
         pop.bytes = (double)pl.B * p.N * (p.C + 8) * 4.0;
         pop.run = [p](hipStream_t st) { return launch_postprocess(p, st); };
-        HIPCHK(run_op(h, pop, sm));
-        if (k > 0) HIPCHK(hipEventRecord(pl.ev_done, sm));
+        HIPCHK(run_op(h, pop, s));
     }
-    for (size_t k = 1; k < h->plans.size(); ++k) HIPCHK(hipStreamWaitEvent(s, h->plans[k]->ev_done, 0));
     return SSD_OK;
 }

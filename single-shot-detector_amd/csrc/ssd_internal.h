@@ -119,7 +119,7 @@ enum IgemmLatTile { IGEMM_LAT_1x1 = 20, IGEMM_LAT_1x2 = 21, IGEMM_LAT_2x1 = 22, 
 #ifdef SSD_DIAG
 static inline bool igemm_is_lat(int tile) { return tile >= IGEMM_LAT_1x1 && tile <= 36; }      // 33 .. 36: ablations of the interleaved K-step
 #else
-static inline bool igemm_is_lat(int tile) { return tile >= IGEMM_LAT_1x1 && tile <= IGEMM_LAT_1x1_D8_NM; }
+static inline bool igemm_is_lat(int tile) { return (tile >= IGEMM_LAT_1x1 && tile <= IGEMM_LAT_W4_1x2) || tile == IGEMM_LAT_1x1_D16; }   // (28, 29, 31, 32: diag build)
 #endif
 int igemm_lat_bm(int tile);
 int igemm_lat_bn(int tile);
@@ -169,18 +169,6 @@ struct PwGArgs {
 int pw_gather_tile_n(int CoutP);
 bool pw_gather_supports(int K, int CoutP, long long M, int rs, long long base_bytes, long long out_bytes);
 hipError_t launch_pw_gather(const PwGArgs &a, hipStream_t s);
-
-// depthwise -> pointwise in the latency form (dwpw_lat.hip, batch 1-2): the four-wave block of igemm_lat.hip whose position
-// operand is produced by the depthwise arithmetic instead of loaded --------------------------------------------------
-struct DwPwLArgs {
-    IgemmArgs g;                           // the pointwise product: in = the DEPTHWISE input [B,H,W,K], wt_lat, batch norm, act, one
-                                           // dense level (M = B*OH*OW rows of the depthwise output), Cin = K, n_tiles_n = CoutPad / (64 ct)
-    const float *dw_pack;                  // [K/32][12][32]: per 32-channel slice 9 taps, mean, sf, beta of the depthwise layer (DwW::pack)
-    int H, W;                              // depthwise input size
-    int dstride, dpad, dact;               // depthwise stride (1 | 2), pad_beg (TF 'SAME': 1 | 0), activation
-};
-bool dwpw_lat_supports(const DwPwLArgs &q, int ct);
-hipError_t launch_dwpw_lat(int ct /* 16-channel tiles per wave: 1 | 2 | 4 */, const DwPwLArgs &q, hipStream_t s);
 
 // MobileNet's first three layers in one launch (front.hip): first convolution 3x3 stride 2 on the uint8 frame (3 -> 32) ->
 // depthwise 3x3 -> pointwise 32 -> 64, each with its batch norm and activation; the 32-channel tensor stays in LDS --------

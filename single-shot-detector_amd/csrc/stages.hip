@@ -275,12 +275,7 @@ extern "C" int ssd_dw_pw(const float *in_dev, int32_t B, int32_t H, int32_t W, i
         BnHost b;
         for (int p : outmap) { b.mean.push_back(p < 0 ? 0.f : pw_mean[p]); b.sf.push_back(p < 0 ? 0.f : pw_sf[p]); b.beta.push_back(p < 0 ? 0.f : pw_beta[p]); }
         SSDCHK(upload_bn(pool, b, cw));
-        // option dwpw_lat = 1 | 2 | 4 (process-wide): the latency-form kernel (dwpw_lat.hip) where it takes the shape
-        const int lopt = ssd_opt(nullptr, OPT_DWPW_LAT, 0);
-        const int lct = lopt > 0 ? dwpw_lat_ct(nullptr, d, cw, B, H, W, stride) : 0;
-        if (lopt > 1 && lct != lopt)         // a pinned form must run or fail: the parity tests rely on it
-            return ssd_fail(SSD_ERR_INVALID, "ssd_dw_pw: option dwpw_lat pins a block form that does not take this shape (K % 64 == 0, padded width % (64 ct) == 0)");
-        if (!lct && !dwpws_eligible(d, cw, B, H, W, stride))
+        if (!dwpws_eligible(d, cw, B, H, W, stride))
             return ssd_fail(SSD_ERR_INVALID, "ssd_dw_pw: shape not supported by the fused kernel (every tensor below 2 GiB, stride 2 needs even H and W)");
         const int OH = H / stride, OW = W / stride;
         float *tin, *tout;
@@ -288,7 +283,7 @@ extern "C" int ssd_dw_pw(const float *in_dev, int32_t B, int32_t H, int32_t W, i
         SSDCHK(pool.alloc((void **)&tin, (size_t)rin * Cp * 4));
         SSDCHK(pool.alloc((void **)&tout, (size_t)rout * CoutP * 4));
         HIPCHK(launch_permute_channels(in_dev, rin, C, Cp, 1, tin, s));
-        Op op = lct ? make_dwpw_lat_op(lct, d, cw, tin, B, H, W, stride, dw_act, pw_act, tout) : make_dwpws_op(d, cw, tin, B, H, W, stride, dw_act, pw_act, tout);
+        Op op = make_dwpws_op(d, cw, tin, B, H, W, stride, dw_act, pw_act, tout);
         HIPCHK(op.run(s));
         HIPCHK(launch_permute_channels(tout, rout, Cout, CoutP, 0, out_dev, s));
         HIPCHK(hipStreamSynchronize(s));

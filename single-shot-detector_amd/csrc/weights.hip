@@ -1,6 +1,6 @@
 // ssd_finalize's work: the reference's TF variables (by name) -> the packed device weights of the HIP kernels:
 // physical channel order and padding (ssd_internal.h), transposed [tap][CoutPad][Cin] conv kernels (+ their split-fp16
-// form for precision mode f16x3), batch-norm scale factors, slice-major depthwise packs, ShuffleNet gather tables.
+// form for precision mode f16x3), batch-norm scale factors, slice-major depthwise packs.
 #include "host.h"
 
 #include <cmath>
@@ -316,24 +316,6 @@ static int finalize_shufflenet(ssd_handle *h)
             cw = ConvW();
             SSDCHK(load_conv(h, u + "/conv1x1_after/weights", u + "/conv1x1_after/batch_norm", 1, D, D, cw)); h->pw.push_back(cw);
         }
-        // gather tables for this stage: shuffle (two outputs) and final concat
-        const int Dp = round_up(D, 32), Cc = 2 * Dp;
-        std::vector<int> tx(2 * Dp, -1), ty(2 * Dp, -1), tc(2 * Cc, -1);
-        for (int p = 0; p < Dp; ++p) {
-            const int j = ssd_logical_of_phys(p);
-            if (j >= D) continue;
-            const int zx = j, zy = D + j;
-            tx[2 * p] = zx & 1; tx[2 * p + 1] = ssd_phys_of_logical(zx >> 1);
-            ty[2 * p] = zy & 1; ty[2 * p + 1] = ssd_phys_of_logical(zy >> 1);
-        }
-        for (int p = 0; p < Cc; ++p) {          // two-part rows: the concat copies the halves side by side
-            if (ssd_logical_of_phys(p % Dp) >= D) continue;
-            tc[2 * p] = p / Dp;
-            tc[2 * p + 1] = p % Dp;
-        }
-        int *dx, *dy, *dc;
-        SSDCHK(h->wpool.upload(&dx, tx)); SSDCHK(h->wpool.upload(&dy, ty)); SSDCHK(h->wpool.upload(&dc, tc));
-        h->tabs.push_back(dx); h->tabs.push_back(dy); h->tabs.push_back(dc);
         cin = out;
         split = D;
         if (st == 0) { h->c_ch[0] = out; h->c_split[0] = D; }
@@ -417,27 +399,6 @@ static int finalize_fpn_heads(ssd_handle *h)
         bpad.resize((size_t)round_up(Cout, 4), 0.0f);     // the epilogue reads parameters 4 at a time
         SSDCHK(h->wpool.upload(&cw.bias, bpad));
     }
-    // layer i of both towers behind one pointer each (same shapes: 3x3, 256 -> 256, five batch norms per net): one launch per
-    // layer over 2 x 5 levels (plan.hip), box net first
-    for (int i = 0; i < 4; ++i) {
-        ConvW &g = h->tgroup[i];
-        const ConvW &b0 = h->tower[0][i], &b1 = h->tower[1][i];
-        g = b0;
-        g.wt16 = g.wt16w = g.wlat = nullptr;       // (exact fp32, the 32x32x2 kernel only)
-        if (b0.CoutPad != b1.CoutPad || b0.CinP != b1.CinP || b0.CoutP != b1.CoutP) return ssd_fail(SSD_ERR_WEIGHT, "box / class tower kernels differ in shape");
-        const size_t wn = (size_t)g.taps * g.CoutPad * g.CinP, pn = (size_t)5 * g.CoutP;
-        SSDCHK(h->wpool.alloc((void **)&g.wt, 2 * wn * sizeof(float)));
-        SSDCHK(h->wpool.alloc((void **)&g.mean, 2 * pn * sizeof(float)));
-        SSDCHK(h->wpool.alloc((void **)&g.sf, 2 * pn * sizeof(float)));
-        SSDCHK(h->wpool.alloc((void **)&g.beta, 2 * pn * sizeof(float)));
-        for (int t = 0; t < 2; ++t) {
-            const ConvW &src = h->tower[t][i];
-            HIPCHK(hipMemcpy(g.wt + t * wn, src.wt, wn * sizeof(float), hipMemcpyDeviceToDevice));
-            HIPCHK(hipMemcpy(g.mean + t * pn, src.mean, pn * sizeof(float), hipMemcpyDeviceToDevice));
-            HIPCHK(hipMemcpy(g.sf + t * pn, src.sf, pn * sizeof(float), hipMemcpyDeviceToDevice));
-            HIPCHK(hipMemcpy(g.beta + t * pn, src.beta, pn * sizeof(float), hipMemcpyDeviceToDevice));
-        }
-    }
     return SSD_OK;
 }
 
@@ -447,7 +408,7 @@ int finalize_weights(ssd_handle *h)
     if (r == SSD_OK) r = finalize_fpn_heads(h);
     if (r != SSD_OK) {
         h->wpool.free_all();
-        h->dw.clear(); h->pw.clear(); h->tabs.clear();
+        h->dw.clear(); h->pw.clear();
     }
     return r;
 }

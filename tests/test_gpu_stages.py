@@ -169,8 +169,7 @@ DWPW_STREAM_CASES = [
 ]
 
 
-# shapes of the latency-form kernel (dwpw_lat.hip: K % 64 == 0): batch-1 Conv2d_5 .. 13 at 640x896 / 4, position tails, a
-# single slice, activation-free depthwise
+# batch-1 Conv2d_5 .. 13 at 640x896 / 4, position tails, a single slice, activation-free depthwise
 DWPW_LAT_CASES = [
     (1, 20, 28, 256, 256, 1, "relu6", "relu6"),     # Conv2d_5
     (1, 20, 28, 256, 512, 2, "relu6", "relu6"),     # Conv2d_6
@@ -179,26 +178,11 @@ DWPW_LAT_CASES = [
 ]
 
 
-def _padded_width(cout):
-    """ConvW::CoutPad (weights.hip pick_tile): the padded width of a dense convolution's packed weights."""
-    cp = -(-cout // 8) * 8
-    bn = 32 if cp <= 32 else 64 if cp <= 64 else 96 if (cp % 128 and cp % 96 == 0) else 128
-    return -(-cp // bn) * bn
-
-
-@pytest.mark.parametrize("form", ["stream", "lat1", "lat2", "lat4"])
 @pytest.mark.parametrize("case", DWPW_CASES + DWPW_STREAM_CASES + DWPW_LAT_CASES,
                          ids=[str(i) for i in range(len(DWPW_CASES) + len(DWPW_STREAM_CASES) + len(DWPW_LAT_CASES))])
-def test_dw_pw_fused(cuda, ssd, oracle_ops, case, form, libopt):
-    # dwpw_stream.hip: LDS-DMA staged input patches, K streamed in 32-channel slices;
-    # dwpw_lat.hip (option dwpw_lat = 2 | 4 pins its 128- / 256-channel blocks, 1 lets it choose): the depthwise values
-    # produced in front of each 64-channel slice of a latency-form 1x1 -- the same bits from every form
+def test_dw_pw_fused(cuda, ssd, oracle_ops, case):
+    # dwpw_stream.hip: LDS-DMA staged input patches, K streamed in 32-channel slices
     B, H, W, C, Cout, stride, dact, pact = case
-    if form != "stream":
-        ct = int(form[3:])
-        if C % 64 or (ct > 1 and _padded_width(Cout) % (64 * ct)) or (ct == 1 and _padded_width(Cout) % 64):
-            pytest.skip("not a shape of this block form")
-        libopt(dwpw_lat=ct)
     rng = np.random.default_rng(500 + (DWPW_CASES + DWPW_STREAM_CASES + DWPW_LAT_CASES).index(case))
     x = rng.standard_normal((B, H, W, C)).astype(np.float32)
     wd = rng.standard_normal((3, 3, C, 1)).astype(np.float32)
