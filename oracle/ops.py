@@ -48,6 +48,19 @@ def get_max_threads():
     return int(lib().orc_get_max_threads())
 
 
+# Parity risk register (ssd_oracle.c: five single-sourced TF semantics, each with an oracle-side alternate reading; 0 = default)
+ALTERNATES = {"nms_tie": 0, "fast_exp": 1, "round": 2, "resize": 3, "bn_form": 4}
+
+
+def set_alternate(name, value):
+    if lib().orc_set_alternate(_i(ALTERNATES[name]), _i(int(value))) != 0:
+        raise ValueError(name)
+
+
+def get_alternate(name):
+    return int(lib().orc_get_alternate(_i(ALTERNATES[name])))
+
+
 def _p(a, ty=ctypes.c_float):
     return a.ctypes.data_as(ctypes.POINTER(ty))
 

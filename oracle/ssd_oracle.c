@@ -48,6 +48,30 @@ ORC_API int orc_get_max_threads(void) { return 1; }
 #endif
 
 /* ------------------------------------------------------------------------- */
+/* PARITY RISK REGISTER (scripts/parity_risk.py).  Five TF-op semantics of this restatement are   */
+/* single-sourced: recalled from the published TF r1.12 kernels, pinned by no fixture of the reference.  Each has an   */
+/* ORACLE-SIDE switch here that selects the plausible alternate reading; the product has no such switch (it implements */
+/* the default reading only).  The register script counts how many detections of the benchmark's frames change under   */
+/* each alternate: "unpinned" becomes "unpinned, bounded".  All switches are 0 by default and in every test.           */
+/*   0 ORC_ALT_NMS_TIE      equal scores in NonMaxSuppressionV3: 0 lower box index first | 1 higher index first        */
+/*   1 ORC_ALT_FAST_EXP     tf.sigmoid / tf.exp: 0 correctly rounded fp32 | 1 a polynomial expf in fp32 arithmetic      */
+/*                          (Cephes expf, the form of Eigen's packet exp) and sigmoid = 1 / (1 + expf(-x)) on top of it */
+/*   2 ORC_ALT_ROUND        tf.round of the resized long side: 0 half to even | 1 half up                               */
+/*   3 ORC_ALT_RESIZE       ResizeNearestNeighbor source index: 0 min(floor(dst * in / out), in - 1) | 1 half-pixel     */
+/*                          centres floor((dst + 0.5) * in / out) | 2 align_corners round(dst * (in - 1) / (out - 1))   */
+/*   4 ORC_ALT_BN_FORM      inference batch norm: 0 (x - mean) * (gamma * rsqrt(var + eps)) + beta (FusedBatchNorm) |   */
+/*                          1 x * inv + (beta - mean * inv), inv = gamma * rsqrt(var + eps) (tf.nn.batch_normalization)  */
+enum { ORC_ALT_NMS_TIE = 0, ORC_ALT_FAST_EXP = 1, ORC_ALT_ROUND = 2, ORC_ALT_RESIZE = 3, ORC_ALT_BN_FORM = 4, ORC_ALT_COUNT = 5 };
+static int g_alt[ORC_ALT_COUNT] = {0, 0, 0, 0, 0};
+ORC_API int orc_set_alternate(int which, int value)
+{
+    if (which < 0 || which >= ORC_ALT_COUNT) return -1;
+    g_alt[which] = value;
+    return 0;
+}
+ORC_API int orc_get_alternate(int which) { return which >= 0 && which < ORC_ALT_COUNT ? g_alt[which] : -1; }
+
+/* ------------------------------------------------------------------------- */
 /* create_pb.py:42-47 + mobilenet_v1.py:34 / shufflenet_v2.py:37             */
 /* uint8 -> float, *(1/255), then 2*x - 1 (two separately rounded ops).      */
 ORC_API void orc_preprocess_f(const float *img, int64_t n, float *out)
@@ -83,11 +107,13 @@ ORC_API void orc_resize_dims(int height, int width, int min_dimension, int divis
     const float scale_factor = (float)((double)min_dimension / (double)omin);
     int nh, nw, ph = 0, pw = 0;
     if (height >= width) {
-        const int unp = (int)rintf((float)height * scale_factor);
+        const float v = (float)height * scale_factor;
+        const int unp = g_alt[ORC_ALT_ROUND] ? (int)floorf(v + 0.5f) : (int)rintf(v);
         const int x = (int)ceil((double)unp / (double)divisor);
         nh = unp; ph = divisor * x - unp; nw = min_dimension;
     } else {
-        const int unp = (int)rintf((float)width * scale_factor);
+        const float v = (float)width * scale_factor;
+        const int unp = g_alt[ORC_ALT_ROUND] ? (int)floorf(v + 0.5f) : (int)rintf(v);
         const int x = (int)ceil((double)unp / (double)divisor);
         nw = unp; pw = divisor * x - unp; nh = min_dimension;
     }
@@ -113,6 +139,12 @@ ORC_API void orc_resize_pad(const float *img, int B, int H, int W, int C, int nh
                 float *o = out + (((int64_t)b * OH + y) * OW + x) * C;
                 if (y >= nh || x >= nw) { for (int c = 0; c < C; ++c) o[c] = 0.0f; continue; }
                 int sy = (int)floorf((float)y * hs), sx = (int)floorf((float)x * ws);
+                if (g_alt[ORC_ALT_RESIZE] == 1) {          /* half-pixel centres */
+                    sy = (int)floorf(((float)y + 0.5f) * hs); sx = (int)floorf(((float)x + 0.5f) * ws);
+                } else if (g_alt[ORC_ALT_RESIZE] == 2) {   /* align_corners */
+                    const float hs2 = nh > 1 ? (float)(H - 1) / (float)(nh - 1) : 0.0f, ws2 = nw > 1 ? (float)(W - 1) / (float)(nw - 1) : 0.0f;
+                    sy = (int)roundf((float)y * hs2); sx = (int)roundf((float)x * ws2);
+                }
                 sy = sy < H - 1 ? sy : H - 1;
                 sx = sx < W - 1 ? sx : W - 1;
                 const float *ip = img + (((int64_t)b * H + sy) * W + sx) * C;
@@ -284,6 +316,16 @@ ORC_API void orc_bn_act(float *x, int64_t rows, int C, const float *mean, const 
 #pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < rows; ++r) {
         float *p = x + r * C;
+        if (g_alt[ORC_ALT_BN_FORM]) {
+            for (int c = 0; c < C; ++c) {
+                float off = mean[c] * sf[c];
+                off = beta[c] - off;
+                float v = p[c] * sf[c];
+                v = v + off;
+                p[c] = act_apply(v, act);
+            }
+            continue;
+        }
         for (int c = 0; c < C; ++c) {
             float v = (p[c] - mean[c]) * sf[c];
             v = v + beta[c];
@@ -474,9 +516,37 @@ ORC_API long long orc_anchors_ex(int H, int W, int n_levels, const int *strides,
 
 /* ------------------------------------------------------------------------- */
 /* ssd.py:60 tf.sigmoid; correctly rounded fp32 value of 1/(1+e^-x).         */
-ORC_API float orc_sigmoid(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
+/* ORC_ALT_FAST_EXP: Cephes expf in separately rounded fp32 operations -- x = n ln2 + r, degree-5 polynomial in r, scaled by 2^n  */
+/* (the published algorithm behind Eigen's packet exp; ~1 ulp).                                                                    */
+static float expf_poly(float x)
+{
+    if (x > 88.3762626647949f) x = 88.3762626647949f;
+    if (x < -88.3762626647949f) x = -88.3762626647949f;
+    float fx = x * 1.44269504088896341f;
+    fx = floorf(fx + 0.5f);
+    float t = fx * 0.693359375f;
+    float r = x - t;
+    t = fx * -2.12194440e-4f;
+    r = r - t;
+    float y = 1.9875691500E-4f;
+    y = y * r; y = y + 1.3981999507E-3f;
+    y = y * r; y = y + 8.3334519073E-3f;
+    y = y * r; y = y + 4.1665795894E-2f;
+    y = y * r; y = y + 1.6666665459E-1f;
+    y = y * r; y = y + 5.0000001201E-1f;
+    float r2 = r * r;
+    y = y * r2;
+    y = y + r;
+    y = y + 1.0f;
+    return ldexpf(y, (int)fx);
+}
+ORC_API float orc_sigmoid(float x)
+{
+    if (g_alt[ORC_ALT_FAST_EXP]) { float e = expf_poly(-x); e = 1.0f + e; return 1.0f / e; }
+    return (float)(1.0 / (1.0 + exp(-(double)x)));
+}
 
-static inline float exp_f32(float x) { return (float)exp((double)x); }
+static inline float exp_f32(float x) { return g_alt[ORC_ALT_FAST_EXP] ? expf_poly(x) : (float)exp((double)x); }
 
 /* box_utils.py:114-142 decode (+ :64-77 to_center_coordinates),             */
 /* SCALE_FACTORS constants.py:15; then nms.py:77 clip_by_value(0, 1).        */
@@ -544,6 +614,7 @@ static int cand_cmp(const void *a, const void *b)
     const cand_t *x = (const cand_t *)a, *y = (const cand_t *)b;
     if (x->score > y->score) return -1;
     if (x->score < y->score) return 1;
+    if (g_alt[ORC_ALT_NMS_TIE]) return x->idx > y->idx ? -1 : (x->idx < y->idx ? 1 : 0);
     return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
 }
 

@@ -284,8 +284,10 @@ constexpr int QY = 7, QX = 8, QPH = 2 * QY + 1, QPW = 2 * QX + 1, QSLOT = QPH * 
 static_assert(QSLOT <= 256, "one lane per patch position");
 }
 struct FrontPoolDims { int B, H, W, act0, tiles_y, tiles_x; };
-// COUT: physical channels of the convolution's output -- 24, or 32 inside the network, whose tensors carry 8 zero pad channels
-template <int COUT>
+// COUT: channels the convolution computes (24: the layer's width is 3 whole octets, so its physical channels are 0 .. 23);
+// CS: physical channels of a stored row -- 24, or 32 inside the network, whose tensors carry 8 zero pad channels (stored as zeros
+// here: round 5 -- computing them cost a quarter of the kernel's multiply-adds)
+template <int COUT, int CS>
 __global__ __launch_bounds__(256, 2) void front_pool_kernel(const uint8_t *__restrict__ a_img, const float *__restrict__ a_w0,
                                                              const float *__restrict__ a_m0, const float *__restrict__ a_s0,
                                                              const float *__restrict__ a_b0, float *__restrict__ a_out,
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void front_pool_kernel(const uint8_t *__res
     const int H = a.H, W = a.W, OH = H >> 1, OW = W >> 1, PH2 = OH >> 1, PW2 = OW >> 1;
     const int tiles_img = a.tiles_y * a.tiles_x, total = a.B * tiles_img;
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_img, 0, (int)((long long)a.B * H * W * 3), 0x00020000);
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_out, 0, (int)((long long)a.B * PH2 * PW2 * COUT * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_out, 0, (int)((long long)a.B * PH2 * PW2 * CS * 4), 0x00020000);
     const int ppy = tid / QPW, ppx = tid - ppy * QPW;
     unsigned raw[9];
     auto fetch = [&](int t) {
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void front_pool_kernel(const uint8_t *__res
                 for (int i = 0; i < COUT; ++i) acc[i] = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 27; ++k) {
-                    const float *wr = a_w0 + k * COUT;
+                    const float *wr = a_w0 + k * CS;             // (weights [27][CS])
 #pragma unroll
                     for (int i = 0; i < COUT; ++i) acc[i] = fmaf(x[k], wr[i], acc[i]);
                 }
@@ -344,24 +346,28 @@ __global__ __launch_bounds__(256, 2) void front_pool_kernel(const uint8_t *__res
             }
         }
         __syncthreads();
-        // ---- phase 2: 56 pooled positions x COUT / 4 channel quads: a thread = (quad tid & 7, position tid >> 3 [+ 32])
+        // ---- phase 2: 56 pooled positions x CS / 4 channel quads: a thread = (quad tid & 7, position tid >> 3 [+ 32]); quads past the
+        // computed channels are the tensor's zero pad channels
 #pragma unroll
         for (int rnd = 0; rnd < 2; ++rnd) {
             const int c4 = tid & 7, p = (tid >> 3) + 32 * rnd;
-            if (c4 < COUT / 4 && p < QY * QX) {
+            if (c4 < CS / 4 && p < QY * QX) {
                 const int py = p / QX, qx = p - py * QX;
                 const int oy = QY * ty + py, ox = QX * tx + qx;
-                v4f m = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+                v4f m = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (c4 < COUT / 4) {
+                    m = (v4f){-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int slot = (2 * py + ky) * QPW + 2 * qx + kx;
-                        const v4f xv = *(const v4f *)(lds + slot * 128 + ((c4 ^ (slot & 7)) << 4));
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int slot = (2 * py + ky) * QPW + 2 * qx + kx;
+                            const v4f xv = *(const v4f *)(lds + slot * 128 + ((c4 ^ (slot & 7)) << 4));
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) m[e] = xv[e] > m[e] ? xv[e] : m[e];
-                    }
-                const unsigned o = (oy < PH2 && ox < PW2) ? (unsigned)((((b * PH2 + oy) * PW2 + ox) * COUT + c4 * 4) * 4) : 0x80000000u;
+                            for (int e = 0; e < 4; ++e) m[e] = xv[e] > m[e] ? xv[e] : m[e];
+                        }
+                }
+                const unsigned o = (oy < PH2 && ox < PW2) ? (unsigned)((((b * PH2 + oy) * PW2 + ox) * CS + c4 * 4) * 4) : 0x80000000u;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, m), orsrc, (int)o, 0, 0);
             }
         }
@@ -383,8 +389,8 @@ hipError_t launch_front_pool(const uint8_t *img, int B, int H, int W, const floa
     const long long total = (long long)B * d.tiles_y * d.tiles_x;
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
     const int grid = (int)(total < 4096 ? total : 4096);
-    if (C0 == 24) hipLaunchKernelGGL(front_pool_kernel<24>, dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d);
-    else hipLaunchKernelGGL(front_pool_kernel<32>, dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d);
+    if (C0 == 24) hipLaunchKernelGGL((front_pool_kernel<24, 24>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d);
+    else hipLaunchKernelGGL((front_pool_kernel<24, 32>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d);
     return hipGetLastError();
 }
 
