@@ -26,7 +26,7 @@
  *     and uploads (anchor table), then enqueues.  A serving loop sees this once per shape.
  *     ssd_status, ssd_get_tensor and ssd_set_precision synchronise (documented at each).  The
  *     stage entry points that take host weights (ssd_conv2d, ssd_depthwise3x3, ssd_dw_pw,
- *     ssd_first_conv, ssd_concat_shuffle_split) are test conveniences and synchronise before
+ *     ssd_first_conv, ssd_concat_shuffle_split, ssd_shuffle_conv1x1) are test conveniences and synchronise before
  *     returning.
  *   - one handle per device.  Every entry point that takes a handle holds the handle's mutex, so concurrent calls on
  *     one handle are serialised by the library, and a forward enqueued on another stream than the previous one first
@@ -308,6 +308,14 @@ int ssd_maxpool3x3s2(const float *in_dev, int32_t B, int32_t H, int32_t W, int32
 /* concat_shuffle_split (shufflenet_v2.py:94-115) on [rows, D] tensors. */
 int ssd_concat_shuffle_split(const float *x_dev, const float *y_dev, int64_t rows, int32_t D,
                              float *xo_dev, float *yo_dev, void *stream);
+
+/* concat_shuffle_split (shufflenet_v2.py:94-115) followed by the unit's conv1x1_before + batch norm + activation (:119) on the
+ * new x half, as the ONE kernel the layer plan runs for it (sn_pw.hip): the shuffle is the kernel's per-channel source table.
+ * x_dev, y_dev [rows, D] (D even), w_host [1,1,D,Cout] -> out_dev [rows, Cout]; bit-identical to ssd_concat_shuffle_split
+ * followed by ssd_conv2d on its first output. */
+int ssd_shuffle_conv1x1(const float *x_dev, const float *y_dev, int64_t rows, int32_t D,
+                        const float *w_host, int32_t Cout, const float *bn_mean_host, const float *bn_sf_host,
+                        const float *bn_beta_host, int32_t act, float *out_dev, void *stream);
 
 /* SSD.get_predictions (ssd.py:42-69) = sigmoid + batch_multiclass_non_max_suppression
  * (nms.py:48-102, decode box_utils.py:114-142, tf.image.non_max_suppression of TF r1.12)

@@ -160,6 +160,7 @@ SIGNATURES = {
     "ssd_first_conv_maxpool": (ctypes.c_int, [_vp, _i, _i, _i, _f, _i, _f, _f, _f, _i, _vp, _vp]),
     "ssd_maxpool3x3s2": (ctypes.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "ssd_concat_shuffle_split": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _i, _vp, _vp, _vp]),
+    "ssd_shuffle_conv1x1": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _i, _f, _i, _f, _f, _f, _i, _vp, _vp]),
     "ssd_postprocess_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i, _i]),
     "ssd_postprocess": (ctypes.c_int, [_vp, _vp, _vp, _i, _i, _i, ctypes.c_float, ctypes.c_float,
                                        _i, _f, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),

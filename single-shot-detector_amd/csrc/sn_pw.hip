@@ -98,15 +98,17 @@ __global__ __launch_bounds__(256, WN == 1 ? 4 : 3) void pw_gather_kernel(const P
     }
     auto dma_a = [&](int iter, int tile, int g0, int g1) {
         unsigned char *dst = lds + (iter & 1) * A_BYTES + wave * 256;
-        const int o0 = g0 < 0 ? (int)OOB : vrow + g0, o1 = g1 < 0 ? (int)OOB : vrow + g1;
         const int r0 = tile * BM + 2 * wave;                     // scalar: first row of pair `wave`; pairs i and i + 4 are 8 rows apart
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
-            // (the scalar offset takes no part in the buffer's range check: a pair past the tensor's last row -- the ragged
-            //  last tile, whose rows are never stored -- re-reads the last pair instead of leaving the allocation)
+            // (the scalar offset takes no part in the buffer's range check: rows past the tensor's last one -- the ragged last
+            //  tile, whose rows are never stored -- re-read row M - 1 instead of leaving the tensor; a pair whose FIRST row is
+            //  the last one (odd M) reads it for both of its rows)
             const int row = r0 + 8 * m;
-            const int so = (row < a.M - 2 ? row : a.M - 2) * a.rs;
-            const int off = (m & 1) ? o1 : o0;
+            const int so = (row < a.M - 1 ? row : a.M - 1) * a.rs;
+            const int vr = row + 1 < a.M ? vrow : 0;
+            const int g = (m & 1) ? g1 : g0;
+            const int off = g < 0 ? (int)OOB : g + vr;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(irsrc, (lds_ptr_t)(dst + m * 1024), 4, off, so, 0, 0);
         }
     };
@@ -228,7 +230,7 @@ static hipError_t launch_g(const PwGArgs &a, hipStream_t s)
 
 bool pw_gather_supports(int K, int CoutP, long long M, int rs, long long base_bytes, long long out_bytes)
 {
-    if (K < 32 || K % 32 || K > 512 || CoutP < 4 || CoutP % 4 || M < 2 || rs < 4 || (rs & 3)) return false;
+    if (K < 32 || K % 32 || K > 512 || CoutP < 4 || CoutP % 4 || M < 1 || rs < 4 || (rs & 3)) return false;
     if (base_bytes <= 0 || base_bytes >= (1LL << 31) || out_bytes <= 0 || out_bytes >= (1LL << 31)) return false;
     const int BN = pw_gather_tile_n(CoutP);
     if ((CoutP + BN - 1) / BN > 32) return false;

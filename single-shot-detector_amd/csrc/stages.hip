@@ -457,6 +457,52 @@ extern "C" int ssd_concat_shuffle_split(const float *x_dev, const float *y_dev, 
     return rc;
 }
 
+// concat_shuffle_split (shufflenet_v2.py:94-115) followed by the unit's conv1x1_before + batch norm + activation (:119) on the new x
+// half -- as the ONE kernel the layer plan runs for it (sn_pw.hip): x and y stay where their producers stored them (two dense
+// tensors of one allocation), the shuffle is the kernel's per-channel source table.
+extern "C" int ssd_shuffle_conv1x1(const float *x_dev, const float *y_dev, int64_t rows, int32_t D, const float *w_host, int32_t Cout,
+                                   const float *bn_mean_host, const float *bn_sf_host, const float *bn_beta_host, int32_t act, float *out_dev,
+                                   void *stream)
+{
+    if (!x_dev || !y_dev || !w_host || !bn_mean_host || !bn_sf_host || !bn_beta_host || !out_dev || rows < 1 || D < 2 || (D & 1) || Cout < 1)
+        return ssd_fail(SSD_ERR_INVALID, "ssd_shuffle_conv1x1: bad arguments (even D, batch norm required)");
+    hipStream_t s = (hipStream_t)stream;
+    DevPool pool;
+    auto body = [&]() -> int {
+        const int Dp = round_up(D, 32), CoutP = round_up(Cout, 32);
+        std::vector<int> inmap = phys_map(D, Dp), outmap = phys_map(Cout, CoutP);
+        ConvW cw;
+        SSDCHK(pack_conv(nullptr, pool, w_host, 1, D, Cout, inmap, outmap, cw));
+        BnHost b;
+        for (int p : outmap) { b.mean.push_back(p < 0 ? 0.f : bn_mean_host[p]); b.sf.push_back(p < 0 ? 0.f : bn_sf_host[p]); b.beta.push_back(p < 0 ? 0.f : bn_beta_host[p]); }
+        SSDCHK(upload_bn(pool, b, cw));
+        // one allocation [x | y], both in physical channel order
+        const long long tbytes = rows * Dp * 4;
+        if (!pw_gather_supports(Dp, CoutP, rows, Dp * 4, 2 * tbytes, rows * CoutP * 4))
+            return ssd_fail(SSD_ERR_INVALID, "ssd_shuffle_conv1x1: shape not supported by the gathering kernel (D <= 512, tensors below 2 GiB)");
+        float *xy, *tout;
+        SSDCHK(pool.alloc((void **)&xy, (size_t)(2 * tbytes)));
+        SSDCHK(pool.alloc((void **)&tout, (size_t)rows * CoutP * 4));
+        HIPCHK(launch_permute_channels(x_dev, rows, D, Dp, 1, xy, s));
+        HIPCHK(launch_permute_channels(y_dev, rows, D, Dp, 1, xy + rows * Dp, s));
+        // new x = z[0 : D] of z[2d] = x[d], z[2d + 1] = y[d]: input channel k comes from (k & 1 ? y : x)[k >> 1]
+        std::vector<int> src(Dp, -1);
+        for (int k = 0; k < D; ++k)
+            src[ssd_phys_of_logical(k)] = (int)((k & 1 ? tbytes : 0) + (long long)ssd_phys_of_logical(k >> 1) * 4);
+        int *src_dev;
+        SSDCHK(pool.upload(&src_dev, src));
+        Op op = make_pw_gather_op(cw, xy, 2 * tbytes, src_dev, Dp * 4, rows, act, tout);
+        HIPCHK(op.run(s));
+        HIPCHK(launch_permute_channels(tout, rows, Cout, CoutP, 0, out_dev, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return SSD_OK;
+    };
+    int rc = body();
+    (void)hipStreamSynchronize(s);
+    pool.free_all();
+    return rc;
+}
+
 extern "C" size_t ssd_postprocess_workspace_bytes(int32_t B, int32_t N, int32_t C, int32_t mp)
 {
     if (B < 1 || N < 1 || C < 1 || mp < 1) return 0;

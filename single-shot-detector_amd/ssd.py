@@ -200,6 +200,25 @@ def concat_shuffle_split(x, y):
     return xo, yo
 
 
+def shuffle_conv1x1(x, y, w, bn, act="relu"):
+    """concat_shuffle_split(x, y) -> conv1x1_before on the new x half (shufflenet_v2.py:94-115,119) as one kernel.
+    x, y [..., D] cuda f32; w [1,1,D,Cout] numpy; bn = (mean, sf, beta)."""
+    torch = _torch()
+    _check_dev(torch, x, torch.float32, "x")
+    _check_dev(torch, y, torch.float32, "y")
+    if x.shape != y.shape:
+        raise ValueError("x and y must have the same shape")
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    D, Cout = x.shape[-1], w.shape[3]
+    if w.shape[:3] != (1, 1, D):
+        raise ValueError("kernel must be [1,1,D,Cout]")
+    out = torch.empty(tuple(x.shape[:-1]) + (Cout,), dtype=torch.float32, device=x.device)
+    keep = [_fp(v) for v in bn]
+    check(lib().ssd_shuffle_conv1x1(_ptr(x), _ptr(y), x.numel() // D, D, w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), Cout,
+                                    keep[0][1], keep[1][1], keep[2][1], ACT[act], _ptr(out), _stream(torch)))
+    return out
+
+
 class AnchorGenerator:
     """detector/anchor_generator.py:12-120: any strides / scales / scale multipliers / aspect ratios (ssd_anchors_ex; the
     defaults are the values model.py:37-42 fixes for the exported graph)."""

@@ -411,6 +411,36 @@ def test_maxpool_and_shuffle(cuda, ssd, oracle_ops):
     assert np.array_equal(xo.cpu().numpy(), rx) and np.array_equal(yo.cpu().numpy(), ry)
 
 
+@pytest.mark.parametrize("shape,D,Cout,act", [((2, 40, 40), 116, 116, "relu"), ((3, 5, 7), 58, 58, "relu"), ((1, 1, 2), 24, 24, "relu"),
+                                              ((1, 13, 5), 232, 232, "relu"), ((2, 9, 9), 58, 40, None), ((1, 1, 67), 32, 8, "relu6"),
+                                              ((1, 3, 43), 244, 244, "relu"), ((4, 80, 80), 58, 58, "relu"), ((1, 1, 1), 58, 58, "relu"), ((1, 1, 3), 116, 116, "relu")])
+def test_shuffle_conv1x1(cuda, ssd, oracle_ops, shape, D, Cout, act):
+    """sn_pw.hip through its stage entry point: concat_shuffle_split folded into conv1x1_before's loads (shufflenet_v2.py:94-115,119).
+    Row counts that are no multiple of the 64-row tile (2, 65, 129, 105, 162, 67), one / two / four / eight K slices, channel
+    counts that end inside an octet (58, 116, 244), narrow outputs -- bit-identical to the oracle's shuffle -> conv -> batch norm and
+    to the library's own two-step form."""
+    rng = np.random.default_rng(D * 1000 + Cout + shape[1])
+    x = rng.standard_normal(shape + (D,)).astype(np.float32)
+    y = rng.standard_normal(shape + (D,)).astype(np.float32)
+    w = (rng.standard_normal((1, 1, D, Cout)) * np.sqrt(2.0 / D)).astype(np.float32)
+    g, b, m, v = bn_params(rng, Cout)
+    sf = oracle_ops.bn_scale(g, v)
+    xs, _ = oracle_ops.concat_shuffle_split(x, y)
+    ref = oracle_ops.bn_act(oracle_ops.conv2d(xs, w, 1, "SAME"), g, b, m, v, act)
+    got = ssd.ssd.shuffle_conv1x1(dev(cuda, x), dev(cuda, y), w, (m, sf, b), act).cpu().numpy()
+    assert close(got, ref, "shuffle_conv1x1 %s D=%d" % (shape, D)) == 1.0
+    xo, _ = ssd.ssd.concat_shuffle_split(dev(cuda, x), dev(cuda, y))
+    two = ssd.ssd.conv2d(xo, w, 1, "SAME", bn=(m, sf, b), act=act).cpu().numpy()
+    assert np.array_equal(got, two)
+    # NaN / inf in the inputs propagate exactly as through the two-step form (the zero-filled pad channels must not turn them into NaN elsewhere)
+    x[0, 0, 0, 1] = np.inf
+    y[-1, -1, -1, 0] = np.nan
+    got = ssd.ssd.shuffle_conv1x1(dev(cuda, x), dev(cuda, y), w, (m, sf, b), act).cpu().numpy()
+    xo, _ = ssd.ssd.concat_shuffle_split(dev(cuda, x), dev(cuda, y))
+    two = ssd.ssd.conv2d(xo, w, 1, "SAME", bn=(m, sf, b), act=act).cpu().numpy()
+    assert np.array_equal(got, two, equal_nan=True)
+
+
 # --------------------------------------------------------------------------- post-processing
 def synth_heads(rng, B, N, C, frac=0.002, base=-4.6):
     """codes ~ N(0,1); logits = base + sparse positives U[-1.5, 3]."""
