@@ -9,5 +9,9 @@ from ssd_amd import _lib
 path = os.path.abspath(sys.argv[1])
 assert os.path.exists(path), path
 _lib.build = lambda *a, **k: path          # no freshness check: the named file is what gets loaded
+import ctypes
+_other = ctypes.CDLL(path)                 # an older build may lack entry points the tree has since added: bind what it has
+for name in [n for n in _lib.SIGNATURES if not hasattr(_other, n)]:
+    del _lib.SIGNATURES[name]
 import bench
 sys.exit(bench.main(sys.argv[2:]))
