@@ -75,6 +75,11 @@ def test_forward_vs_oracle_small(cuda, ssd, oracle_graph, backbone, H, W, B):
     compare_outputs(out, ref, backbone + " small")
     assert ref["num_boxes"].min() > 0
     assert worst == 1.0, "stages within tolerance but not bit-identical to the oracle"
+    # the device-side fetch (ssd_get_tensor_dev: one permute launch, no host copy) returns the same logical tensors -- for ShuffleNet
+    # c3 / c4 out of the stage outputs' two-part rows
+    for n in ("c3", "c4", "c5", "p3", "encoded_boxes"):
+        host = eng.get_tensor(n)
+        assert np.array_equal(eng.get_tensor_dev(n, host.shape).cpu().numpy(), host), n
     # a second call with another batch size re-plans the arena and stays correct
     out1 = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(img[:1].copy()).cuda())]
     for a, b in zip(out, out1):
