@@ -98,7 +98,8 @@ def test_forward_vs_oracle_small(cuda, ssd, oracle_graph, backbone, H, W, B):
 
 
 @pytest.mark.parametrize("backbone,dm,classes,H,W", [("mobilenet", 0.5, 20, 128, 256), ("mobilenet", 0.75, 3, 256, 128),
-                                                     ("shufflenet", 0.5, 20, 128, 128), ("shufflenet", 1.5, 80, 128, 256)])
+                                                     ("shufflenet", 0.5, 20, 128, 128), ("shufflenet", 1.5, 80, 128, 256),
+                                                     ("shufflenet", 2.0, 20, 128, 128)])
 def test_forward_other_widths_and_class_counts(cuda, ssd, oracle_graph, backbone, dm, classes, H, W):
     """depth_multiplier and num_classes are part of the config surface (model.py:22-30): narrow
     backbones exercise the channel padding (16 -> 32, 24 -> 32, 88 -> 96 ...), other class counts
