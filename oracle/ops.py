@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libssd_oracle.so")
+# SSD_ORACLE_LIB: another build of the same source (the AddressSanitizer + UBSan build of `make san`, scripts/oracle_sanitize.sh)
+_LIB_PATH = os.environ.get("SSD_ORACLE_LIB") or os.path.join(_HERE, "libssd_oracle.so")
 _lib = None
 
 _f = ctypes.POINTER(ctypes.c_float)
