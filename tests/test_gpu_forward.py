@@ -118,11 +118,13 @@ def test_forward_other_widths_and_class_counts(cuda, ssd, oracle_graph, backbone
     eng.close()
 
 
-def test_sub_batch_plans(cuda, ssd, oracle_graph, libopt):
+@pytest.mark.parametrize("backbone", ["mobilenet", "shufflenet"])
+def test_sub_batch_plans(cuda, ssd, oracle_graph, libopt, backbone):
     """option nsub forces the consecutive sub-batch plans that a batch past 2 GiB of activations takes (uneven split
-    5 = 2+2+1): same results, same retained tensors."""
+    5 = 2+2+1): same results, same retained tensors (ShuffleNet: every plan has its own stage allocations and two-part rows,
+    and ssd_get_tensor assembles a stage from all of them)."""
     libopt(nsub=3)
-    params = {"backbone": "mobilenet", "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
+    params = {"backbone": backbone, "depth_multiplier": 1.0, "num_classes": 80, "score_threshold": 0.15,
               "iou_threshold": 0.6, "max_boxes_per_class": 25, "min_dimension": 128}
     Wt = ssd.synthetic_weights(params, seed=12, logits_bias=-4.0)
     img = np.random.default_rng(6).integers(0, 256, (5, 128, 128, 3), dtype=np.uint8)
@@ -130,8 +132,8 @@ def test_sub_batch_plans(cuda, ssd, oracle_graph, libopt):
     ref = oracle_graph.forward(img, Wt, params, keep)
     eng = ssd.Engine(params, Wt)
     out = [t.cpu().numpy() for t in eng.forward(cuda.from_numpy(img).cuda())]
-    assert stage_check(eng, keep, STAGES, "nsub3") == 1.0
-    compare_outputs(out, ref, "sub-batch plans")
+    assert stage_check(eng, keep, STAGES, "nsub3 " + backbone) == 1.0
+    compare_outputs(out, ref, "sub-batch plans " + backbone)
     eng.close()
 
 
