@@ -112,6 +112,53 @@ def latency_batch1(detector):
             "detections_over_0.5": int(len(scores))}
 
 
+# (height, width) of frequent COCO val2017 frames, portrait and landscape, plus one at the network's own size
+# (inference/evaluate_on_COCO.ipynb:125-150 feeds such a mix through ONE Detector)
+MIXED_SIZES = [(480, 640), (640, 480), (427, 640), (640, 427), (375, 500), (500, 375), (360, 640), (333, 500),
+               (640, 428), (612, 612), (426, 640), (500, 333), (640, 896)]
+
+
+def latency_mixed_sizes(detector, cycles=8, alone_calls=20):
+    """Detector.__call__ over a cyclic mix of image sizes (every call another size than the one before) next to the same
+    sizes each timed alone.  The library keeps one layer plan per NETWORK shape (the size after resize_keeping_aspect_ratio),
+    so after the first pass no call builds anything: `plan_cache` carries the hits / misses / evictions of the timed part."""
+    rng = np.random.default_rng(0)
+    frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in MIXED_SIZES]
+    eng = detector.engine
+    alone = {}
+    for (h, w), f in zip(MIXED_SIZES, frames):
+        for _ in range(3):
+            detector(f, score_threshold=0.5)
+        t = []
+        for _ in range(alone_calls):
+            t0 = time.perf_counter()
+            detector(f, score_threshold=0.5)
+            t.append((time.perf_counter() - t0) * 1e3)
+        nh, nw, _ = ssd_amd.network_input_size(h, w, PARAMS["min_dimension"])
+        alone["%dx%d" % (h, w)] = {"network": [nh, nw], "p50_ms": float(np.percentile(t, 50))}
+    for f in frames:
+        detector(f, score_threshold=0.5)
+    s0 = eng.plan_cache_stats()
+    t = []
+    for _ in range(cycles):
+        for f in frames:
+            t0 = time.perf_counter()
+            detector(f, score_threshold=0.5)
+            t.append((time.perf_counter() - t0) * 1e3)
+    s1 = eng.plan_cache_stats()
+    alone_mean = float(np.mean([v["p50_ms"] for v in alone.values()]))
+    return {"p50_ms": float(np.percentile(t, 50)), "p95_ms": float(np.percentile(t, 95)), "mean_ms": float(np.mean(t)), "calls": len(t),
+            "source_sizes": len(MIXED_SIZES), "network_shapes_seen": sorted({tuple(v["network"]) for v in alone.values()}),
+            "alone_p50_ms": alone, "alone_mean_of_p50_ms": alone_mean,
+            # every size appears equally often in the mix: the mean over the mix against the mean of the sizes' own p50s
+            "mixed_mean_over_alone_mean": float(np.mean(t)) / alone_mean,
+            "plan_cache": {"plans": s1["plans"], "arena_mb": s1["arena_bytes"] / 2 ** 20, "budget_mb": s1["budget_bytes"] / 2 ** 20,
+                           "hits_in_timed_part": s1["hits"] - s0["hits"], "misses_in_timed_part": s1["misses"] - s0["misses"],
+                           "evictions_in_timed_part": s1["evictions"] - s0["evictions"]},
+            "protocol": "Detector.__call__(host ndarray, 0.5); %d source sizes x %d cycles, each call another size than the one before; "
+                        "alone = %d calls of one size after 3 warm-up calls" % (len(MIXED_SIZES), cycles, alone_calls)}
+
+
 def latency_segments(detector):
     """Where a batch-1 Detector call spends its time (attribution: every segment followed by a synchronisation, so the
     sum exceeds the pipelined call -- ssd_forward_host stages and uploads the image in pieces, the upload of one under the
@@ -120,12 +167,14 @@ def latency_segments(detector):
     img = np.random.default_rng(0).integers(0, 256, (H, W, 3), dtype=np.uint8)
     for _ in range(5):
         detector(img, score_threshold=0.5)
-    slot = e._slot((1, H, W, 3))
+    slot = e._out_slot(1)
+    _, dev_in, pin_in = e._in_slot((1, H, W, 3), index=3, pinned=True)
+    pin_in_np = pin_in.numpy()
     seg = {k: [] for k in ("copyto_pinned", "h2d", "forward_zero_copy_out", "filter")}
     for _ in range(50):
-        t0 = time.perf_counter(); np.copyto(slot["pin_in_np"], img[None]); t1 = time.perf_counter()
-        slot["dev_in"].copy_(slot["pin_in"], non_blocking=True); torch.cuda.synchronize(); t2 = time.perf_counter()
-        e.forward(slot["dev_in"], records=slot["pin_out"]); torch.cuda.synchronize(); t3 = time.perf_counter()
+        t0 = time.perf_counter(); np.copyto(pin_in_np, img[None]); t1 = time.perf_counter()
+        dev_in.copy_(pin_in, non_blocking=True); torch.cuda.synchronize(); t2 = time.perf_counter()
+        e.forward(dev_in, records=slot["pin_out"]); torch.cuda.synchronize(); t3 = time.perf_counter()
         b, l, s, n = slot["host"]; k = s[0][:n[0]] > 0.5; _ = b[0][:n[0]][k], l[0][:n[0]][k], s[0][:n[0]][k]; t4 = time.perf_counter()
         for name, a, c in zip(seg, (t0, t1, t2, t3), (t1, t2, t3, t4)):
             seg[name].append((c - a) * 1e6)
@@ -222,11 +271,50 @@ class Timed:
         dt = time.perf_counter() - t0
         engine.profile_enable(False)
         prof = engine.profile_read()
-        if self.use_dist:       # MAX over ranks
+        self.per_rank_s = [dt]
+        if self.use_dist:       # MAX over ranks (the contract's time); every rank's own time kept beside it
             t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            allt = torch.empty((self.world,), dtype=torch.float64, device=self.dev)
+            self.dist.all_gather_into_tensor(allt, t)
+            self.per_rank_s = [float(v) for v in allt.cpu()]
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, out, prof
+
+    def breakdown(self, step_with_mark, steps, stub):
+        """A few extra steps (not the timed ones) with a mark between the engine's forward and the all-gather: per rank
+        the time from a step's start to the mark (compute) and from the mark to the step's end (the collective, incl. its
+        wait for the slowest rank), ms per step; lists over ranks."""
+        self.fence()
+        marks = []
+        if stub:
+            now = time.perf_counter
+            for _ in range(steps):
+                a = now()
+                m = []
+                step_with_mark(lambda: m.append(now()))
+                marks.append((a, m[0], now()))
+            comp = sum(b - a for a, b, c in marks) / steps * 1e3
+            coll = sum(c - b for a, b, c in marks) / steps * 1e3
+        else:
+            for _ in range(steps):
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                e[0].record()
+                step_with_mark(e[1].record)
+                e[2].record()
+                marks.append(e)
+            self.sync()
+            comp = sum(e[0].elapsed_time(e[1]) for e in marks) / steps
+            coll = sum(e[1].elapsed_time(e[2]) for e in marks) / steps
+        self.fence()
+        comp_l, coll_l = [comp], [coll]
+        if self.use_dist:
+            t = torch.tensor([comp, coll], dtype=torch.float64, device=self.dev)
+            allt = torch.empty((self.world * 2,), dtype=torch.float64, device=self.dev)
+            self.dist.all_gather_into_tensor(allt, t)
+            comp_l = [float(v) for v in allt[0::2].cpu()]
+            coll_l = [float(v) for v in allt[1::2].cpu()]
+        return comp_l, coll_l
 
 
 def _sysfs_probe(device):
@@ -439,6 +527,7 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
         if world > 1 or args.force_dist or "WORLD_SIZE" in os.environ:
             engine.forward(torch.zeros((1, Hh, Ww, 3), dtype=torch.uint8, device=dev))
             sync()
+    first_forward_before_pg = bool(not stub and (world > 1 or args.force_dist or "WORLD_SIZE" in os.environ))
     ranks_seen = [0]
     # inside a torch.distributed.run launch (WORLD_SIZE set, also = 1) or with --force-dist the collective path runs
     use_dist = world > 1 or args.force_dist or "WORLD_SIZE" in os.environ
@@ -466,6 +555,11 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
     dt, out, prof = timed.run(engine, step, args.steps, args.warmup)
     assert out[0].shape[0] == total, (out[0].shape, total)
     det_per_image = float(out[3].float().mean().item())
+    per_rank_ms = [t / args.steps * 1e3 for t in timed.per_rank_s]
+    # where a step goes, per rank: compute up to the engine's last kernel, then the all-gather (with its wait for the slowest rank)
+    out = [t.clone() for t in out]
+    comp_ms, coll_ms = timed.breakdown(lambda mark: ssd_amd.detect_sharded(engine, frames, total=total, force=use_dist, on_forward_done=mark),
+                                       min(5, max(2, args.steps)), stub)
     def status_all_ranks():
         """bit 0: an f16x3 activation left the fp16 range on SOME rank since the last call (0 in mode f32)."""
         v = engine.status()
@@ -533,6 +627,19 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
             "precision": args.precision, "status_word": status_value,
             "data": "synthetic" if not stub else "STAND-IN ENGINE (launcher test, no GPU work)",
             "ranks_seen": ranks_seen, "collective_path": bool(use_dist), "numa_node_bound": numa_node,
+            # what a scaling loss would be made of (SCALE_rNN.json is the driver's; this line must explain it): every rank's own
+            # time for the K timed steps (ms_per_step is their MAX), and from a few extra steps with an event between the engine's
+            # forward and the collective: compute and all-gather per rank.  A rank whose compute is short waits in ITS all-gather
+            # for the slowest one: rank skew shows as a spread in per_rank_compute_ms_per_step, the collective's own cost as
+            # min(per_rank_allgather_ms_per_step).
+            "per_rank_ms_per_step": per_rank_ms,
+            "per_rank_compute_ms_per_step": comp_ms, "per_rank_allgather_ms_per_step": coll_ms,
+            "compute_ms_per_step": max(comp_ms), "allgather_ms_per_step": max(coll_ms),
+            "allgather_ms_per_step_min_over_ranks": min(coll_ms),
+            "allgather_bytes_per_rank": (hi - lo) * (6 * params["num_classes"] * params["max_boxes_per_class"] + 1) * 4,
+            "engine_first_forward_before_process_group": first_forward_before_pg,
+            "hardware_queue_note": "the engine's internal streams are created by its first forward; run before RCCL creates its streams "
+                                   "they get hardware queues of their own (788 vs 822 img/s the other way round, csrc/plan.hip)",
             "config": {"workload": ("MobileNet-v1 + FPN + RetinaNet heads + decode + per-class NMS, 640x896 (HxW) "
                                     "uint8 frames, %d per GPU (BASELINE config 5 shard; config 2 = same graph at batch 1, "
                                     "see latency_batch1; config 4 = the shufflenet_config4 object)" % B) if net == "mobilenet" else
@@ -570,10 +677,12 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
                 res["latency_batch1"] = dict(lat[args.precision], precision=args.precision,
                                              roofline_ms=ROOFLINE_MS["mobilenet"], by_precision=lat,
                                              segments_p50_us=latency_segments(detector))
+                if args.precision == "f32":
+                    res["latency_mixed_sizes"] = latency_mixed_sizes(detector)
             if world == 1 and not args.no_shufflenet:
                 engine.close()
                 res["shufflenet_config4"] = shufflenet_leg(local, timed, max(3, args.steps // 2), 2, 64)
-            if world == 1 and not args.no_cpu_baseline:
+            if not args.no_cpu_baseline:          # (rank 0 at any world size: ~12 s of host time while the other ranks wait at the barrier)
                 res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
         sys.stdout.flush()

@@ -20,17 +20,25 @@
  *   - return value: 0 (SSD_OK) or a negative code; ssd_last_error() gives the text for
  *     the calling thread.  Nothing throws across the ABI.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  ssd_postprocess only
- *     enqueues work.  ssd_forward only enqueues work for a (B,H,W) it has a layer plan for; the
- *     FIRST call with a new (B,H,W) -- and the first call after ssd_set_precision -- builds that
- *     plan: it waits for the device (hipDeviceSynchronize), frees the previous arena, allocates
- *     and uploads (anchor table), then enqueues.  A serving loop sees this once per shape.
+ *     enqueues work.  ssd_forward only enqueues work for a shape it has a layer plan for.  Plans
+ *     are keyed on what the NETWORK sees -- batch, the resized + padded height and width -- and a
+ *     handle KEEPS the plans of every shape it has served (the reference's graph takes any image
+ *     size in one session, detector/ssd.py:27-31, create_pb.py:24,40; its accuracy harness feeds
+ *     val2017's mix of sizes through one Detector, inference/evaluate_on_COCO.ipynb:125-150): the
+ *     FIRST call that lands on a new network shape -- and the first after ssd_set_precision or a
+ *     handle option change -- builds that shape's plan beside the others (allocates its arena,
+ *     uploads the anchor table; no device-wide wait), later calls of any source size that resizes
+ *     to it call no HIP API but kernel launches.  The plans' arenas are bounded by option
+ *     "plan_cache_mb"; passing it evicts the least recently used plans, which drains the device
+ *     (only then).  ssd_plan_cache_stats reports the cache.
  *     ssd_status, ssd_get_tensor and ssd_set_precision synchronise (documented at each).  The
  *     stage entry points that take host weights (ssd_conv2d, ssd_depthwise3x3, ssd_dw_pw,
  *     ssd_first_conv, ssd_concat_shuffle_split, ssd_shuffle_conv1x1) are test conveniences and synchronise before
  *     returning.
  *   - one handle per device.  Every entry point that takes a handle holds the handle's mutex, so concurrent calls on
  *     one handle are serialised by the library, and a forward enqueued on another stream than the previous one first
- *     waits for that one's last kernel (the arena is one per handle): two host threads may share a handle the way they
+ *     waits for that one's last kernel (a shape's arena is one, and the plans share the library's internal streams): two host
+ *     threads may share a handle the way they
  *     may share a tf.Session (inference/detector.py:34,52).  The OUTPUT buffers belong to the caller, who must not let
  *     two in-flight forwards write the same ones.
  */
@@ -112,10 +120,14 @@ int ssd_get_precision(ssd_handle *h);
  *                     Conv2d_{i+1}; ShuffleNet: non-zero = every unit)                                        (-1)
  *   "backbone_split"  0 auto | 1 .. 4 (ShuffleNet: 1 | 2): backbone chains (two half-batch chains on two streams from 4 images on) (0)
  *   "event_fence"     0 | 1: the library's stream-ordering events with the default flags (system-scope fence per record) (0)
+ *   "plan_cache_mb"   0 auto (a quarter of the device's memory) | n: MiB of arena the handle's cached layer plans may hold;
+ *                     the least recently used go first, the plan of the running shape always stays.  Setting it on a handle
+ *                     evicts down to the new budget and does NOT drop the other plans                          (0)
  * Test hooks -- they pin a kernel variant or a plan shape so that the parity tests see every shape on it:
- *   "igemm_tile"      0 auto | 128 | 64 pin the tile of the 128x128-class launches | 20..27 pin a tile of the latency form
+ *   "igemm_tile"      0 auto | 128 | 64 pin the tile of the 128x128-class launches | 20..27, 30 pin a tile of the latency form
  *                     wherever that form applies: 20..23 one wave per block (1x1, 1x2, 2x1, 2x2 sixteen-wide units), 24..27
- *                     two / four waves per block sharing the positions through LDS                            (0)
+ *                     two / four waves per block sharing the positions through LDS, 30 the one-wave tile with 16 K-steps of
+ *                     operands in flight (the auto choice for the smallest launches).  Any other value is refused  (0)
  *   "igemm_lat"       1 | 0: small exact-fp32 launches on the latency form (v_mfma_f32_16x16x4_f32) | 2: ... and 1x1 launches
  *                     up to 1 280 tiles | 3: as 1 without fpn p6 / p7 of the serving batches                  (1)
  *   "igemm_deep64"    -1 auto | 0 | 1: 64x64 tiles with operand loads three K-steps ahead                     (-1)
@@ -202,6 +214,14 @@ int ssd_get_tensor(ssd_handle *h, const char *name, float *host_dst, int64_t cap
  * on `stream` without synchronising (SSD.raw_predictions, ssd.py:37-40). */
 int ssd_get_tensor_dev(ssd_handle *h, const char *name, float *dst_dev, int64_t capacity_floats,
                        int32_t *dims_out, void *stream);
+
+/* The handle's cache of layer plans (conventions at the top of this file).  out[0..7] = cached plan sets, bytes of arena they
+ * hold, the budget in bytes (option "plan_cache_mb"), hits, misses, evictions since ssd_create, and the network shape (height,
+ * width) the last forward ran at.  A hit = a forward that found its shape's plan; a miss = one that built it. */
+int ssd_plan_cache_stats(ssd_handle *h, int64_t *out8);
+/* Drains the device and drops every cached plan (the next forward of each shape rebuilds it); also forgets the record
+ * pointers ssd_detect_host has verified. */
+int ssd_plan_cache_clear(ssd_handle *h);
 
 /* Per-kernel-class timing with HIP events on the forward's stream (bench.py roofline).
  * classes: 0 conv3x3 MFMA, 1 pointwise MFMA, 2 depthwise, 3 first conv, 4 postprocess,

@@ -11,7 +11,9 @@ e = det.engine
 img = np.random.default_rng(0).integers(0, 256, (640, 896, 3), dtype=np.uint8)
 for _ in range(10):
     det(img, score_threshold=0.5)
-slot = e._slot((1, 640, 896, 3))
+slot = dict(e._out_slot(1))
+_, slot["dev_in"], slot["pin_in"] = e._in_slot((1, 640, 896, 3), index=3, pinned=True)
+slot["pin_in_np"] = slot["pin_in"].numpy()
 sync = torch.cuda.synchronize
 seg = {k: [] for k in ("copyto_pinned", "h2d", "forward", "d2h", "filter")}
 for _ in range(50):

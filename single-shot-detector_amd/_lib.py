@@ -133,6 +133,8 @@ SIGNATURES = {
     "ssd_detect_host": (ctypes.c_int, [_vp, _vp, _i, _i, ctypes.c_float, _vp, _vp, _vp, _vp, _i, _i32p, _vp]),
     "ssd_get_tensor": (ctypes.c_int, [_vp, ctypes.c_char_p, _f, ctypes.c_int64, _i32p]),
     "ssd_get_tensor_dev": (ctypes.c_int, [_vp, ctypes.c_char_p, _vp, ctypes.c_int64, _i32p, _vp]),
+    "ssd_plan_cache_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
+    "ssd_plan_cache_clear": (ctypes.c_int, [_vp]),
     "ssd_profile_enable": (ctypes.c_int, [_vp, _i]),
     "ssd_profile_read": (ctypes.c_int, [_vp, _i, ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_int64),

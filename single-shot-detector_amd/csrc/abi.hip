@@ -16,7 +16,7 @@ extern "C" const char *ssd_last_error(void) { return g_err.c_str(); }
 // ----------------------------------------------------------------------------- options
 static Options g_opts;                 // process-wide values (ssd_set_option with a NULL handle)
 static std::mutex g_opts_mu;
-static const char *const OPT_NAMES[OPT_COUNT] = {"streams", "h2d_chunks", "front_fuse", "fuse_dw", "backbone_split", "event_fence",
+static const char *const OPT_NAMES[OPT_COUNT] = {"streams", "h2d_chunks", "front_fuse", "fuse_dw", "backbone_split", "event_fence", "plan_cache_mb",
                                                  "igemm_tile", "igemm16", "igemm_96", "igemm_lat", "igemm_deep64", "lateral_split", "fpn_group", "fpn_p7_group",
                                                  "fpn_early_lat", "nsub", "nms_fast_max", "debug_sync"};
 int ssd_opt_index(const char *key)
@@ -59,6 +59,10 @@ extern "C" int ssd_set_option(ssd_handle *h, const char *key, int32_t value)
 {
     const int k = ssd_opt_index(key);
     if (k < 0) return ssd_fail(SSD_ERR_INVALID, std::string("ssd_set_option: unknown option ") + (key ? key : "(null)"));
+    // (SSD_OPT_UNSET = INT32_MIN puts an option back to "not set")
+    if (k == OPT_IGEMM_TILE && !(value == SSD_OPT_UNSET || value == 0 || value == 64 || value == 128 || igemm_is_lat(value)))
+        return ssd_fail(SSD_ERR_INVALID, "ssd_set_option: igemm_tile must be 0 (auto), 128, 64 or a wave tile of igemm_lat.hip (20 .. 27, 30)");
+    if (k == OPT_PLAN_CACHE_MB && value < 0 && value != SSD_OPT_UNSET) return ssd_fail(SSD_ERR_INVALID, "ssd_set_option: plan_cache_mb must be >= 0");
     if (!h) {
         std::lock_guard<std::mutex> g(g_opts_mu);
         g_opts.v[k] = value;
@@ -67,8 +71,12 @@ extern "C" int ssd_set_option(ssd_handle *h, const char *key, int32_t value)
     std::lock_guard<std::mutex> g(h->mu);
     if (h->opts.v[k] == value) return SSD_OK;
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (k == OPT_PLAN_CACHE_MB) {   // the budget of the plan cache: nothing a plan depends on -- set it and evict down to it
+        h->opts.v[k] = value;
+        return trim_plan_cache(h, h->cur);
+    }
     HIPCHK(hipDeviceSynchronize());
-    free_plans(h);                  // the layer plan depends on the options
+    free_plans(h);                  // the layer plans depend on the options: every cached one goes
     h->opts.v[k] = value;
     if (k == OPT_EVENT_FENCE) SSDCHK(make_handle_events(h));      // the handle's own ordering events follow the option too
     return SSD_OK;
@@ -121,7 +129,7 @@ extern "C" int ssd_set_precision(ssd_handle *h, int32_t mode)
     if (mode == h->precision) return SSD_OK;
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipDeviceSynchronize());
-    free_plans(h);                  // the layer plan (tensor formats, kernels) depends on the mode
+    free_plans(h);                  // the layer plans (tensor formats, kernels) depend on the mode: every cached one goes
     h->precision = mode;
     return SSD_OK;
 }
@@ -192,19 +200,16 @@ extern "C" int ssd_finalize(ssd_handle *h)
     return SSD_OK;
 }
 
-// One forward on stream `s` with the handle's mutex held.  The arena is one per handle: when this forward is enqueued on
-// another stream than the previous one it first waits for that one's last kernel (two host threads sharing a Detector on
-// their own streams, as tf.Session.run allows, inference/detector.py:34,52).
+// One forward on stream `s` with the handle's mutex held.  The plans of a handle share the process's internal streams (and a
+// shape's arena is one): when this forward is enqueued on another stream than the previous one it first waits for that one's
+// last kernel (two host threads sharing a Detector on their own streams, as tf.Session.run allows, inference/detector.py:34,52).
 static int forward_locked(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
                           int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, long long out_stride, hipStream_t s)
 {
     HIPCHK(hipSetDevice(h->cfg.device));
-    if (B != h->pB || H != h->pH || W != h->pW) {
-        HIPCHK(hipDeviceSynchronize());
-        int rc = make_plans(h, B, H, W);
-        if (rc != SSD_OK) { free_plans(h); return rc; }
-    }
-    // one arena per handle: a forward on another stream than the previous one waits for it.  The event is recorded HERE, at the
+    // the plans of this shape: kept from an earlier call (no HIP call at all), or built now beside the others
+    SSDCHK(select_plans(h, B, H, W));
+    // a forward on another stream than the previous one waits for it.  The event is recorded HERE, at the
     // current tail of the previous stream (everything the previous forward enqueued there precedes it), not at the end of
     // every forward: a record behind the last kernel is one more packet the caller's synchronisation waits for.
     // Single-stream steady state (the usual caller): nothing is ever recorded.  The FIRST time a forward arrives on another
@@ -221,6 +226,13 @@ static int forward_locked(ssd_handle *h, const uint8_t *images_dev, int32_t B, i
                 HIPCHK(hipStreamWaitEvent(s, h->ev_last, 0));
             else { (void)hipGetLastError(); HIPCHK(hipDeviceSynchronize()); }      // (captured, destroyed or unknown stream)
         } else {
+            // (ev_last was recorded outside any capture: a stream the caller is capturing into a graph cannot wait for it -- and a
+            //  graph must not depend on work outside it.  Refused with a message instead of a HIP capture error mid-enqueue.)
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+            if (cs != hipStreamCaptureStatusNone)
+                return ssd_fail(SSD_ERR_STATE, "ssd_forward: this handle's previous forward ran on another stream; a capturing stream cannot wait "
+                                               "for it -- synchronise that stream (or use one handle per captured stream) before capturing");
             HIPCHK(hipStreamWaitEvent(s, h->ev_last, 0));
         }
         h->have_last = false;
@@ -311,13 +323,17 @@ extern "C" int ssd_forward_host(ssd_handle *h, const uint8_t *images_host, int32
         h->stage_busy = false;
     }
     if (bytes > h->stage_bytes) {
+        // grow-only, in powers of two from 2 MiB (a mix of image sizes settles after a few calls: a 640 x 480 frame is 0.9 MB,
+        // the largest COCO frame 1.2 MB); the device drains because the previous upload's buffers are freed
+        size_t cap = (size_t)2 << 20;
+        while (cap < bytes) cap <<= 1;
         HIPCHK(hipDeviceSynchronize());
         if (h->stage_pin) { (void)hipHostFree(h->stage_pin); h->stage_pin = nullptr; }
         if (h->stage_dev) { (void)hipFree(h->stage_dev); h->stage_dev = nullptr; }
         h->stage_bytes = 0;
-        HIPCHK(hipHostMalloc((void **)&h->stage_pin, bytes + 256, hipHostMallocDefault));
-        HIPCHK(hipMalloc((void **)&h->stage_dev, bytes + 256));
-        h->stage_bytes = bytes;
+        HIPCHK(hipHostMalloc((void **)&h->stage_pin, cap + 256, hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&h->stage_dev, cap + 256));
+        h->stage_bytes = cap;
     }
     int nchunk = ssd_opt(h, OPT_H2D_CHUNKS, 2);      // (measured: 1 / 2 / 3 / 4 / 6 / 8 pieces -> Detector p50 1.695 / 1.678 / 1.691 / 1.698 / 1.717 / 1.735 ms: a hipMemcpyAsync costs the host ~10 us)
     if (nchunk < 1) nchunk = 1;
@@ -343,10 +359,14 @@ extern "C" int ssd_detect_host(ssd_handle *h, const uint8_t *image_host, int32_t
 {
     if (!h || !record || !boxes_out || !labels_out || !scores_out || !n_out || capacity < 0) return ssd_fail(SSD_ERR_INVALID, "ssd_detect_host: bad arguments");
     {   // `record` is written by the GPU and read HERE, on the host: it must be pinned (or managed) host memory.  Checked once per
-        // pointer (hipPointerGetAttributes costs microseconds; a serving loop reuses its block), so a device pointer comes back
-        // as an error code instead of a fault inside the library.
+        // pointer (hipPointerGetAttributes costs microseconds; a serving loop reuses its blocks -- the last 8 verified ones are
+        // remembered), so a device pointer comes back as an error code instead of a fault inside the library.  A block that is
+        // freed and later re-allocated as another kind of memory at the same address must be announced: ssd_plan_cache_clear
+        // forgets the verified pointers too.
         std::lock_guard<std::mutex> g(h->mu);
-        if (h->detect_rec_ok != record) {
+        bool known = false;
+        for (int i = 0; i < h->n_rec_ok; ++i) known = known || h->detect_rec_ok[i] == record;
+        if (!known) {
             HIPCHK(hipSetDevice(h->cfg.device));
             hipPointerAttribute_t at;
             memset(&at, 0, sizeof(at));
@@ -356,7 +376,7 @@ extern "C" int ssd_detect_host(ssd_handle *h, const uint8_t *image_host, int32_t
             if (!host_visible)
                 return ssd_fail(SSD_ERR_INVALID, "ssd_detect_host: `record` must be pinned (hipHostMalloc / hipHostRegister) or managed host memory -- "
                                                  "a device pointer or pageable memory cannot be written by the GPU and read by this call");
-            h->detect_rec_ok = record;
+            h->detect_rec_ok[h->n_rec_ok < 8 ? h->n_rec_ok++ : (h->rec_ok_next++ & 7)] = record;
         }
     }
     int rc = ssd_forward_host(h, image_host, 1, H, W, record, stream);
@@ -385,12 +405,12 @@ extern "C" int ssd_get_tensor(ssd_handle *h, const char *name, float *dst, int64
 {
     if (!h || !name || !dst || !dims) return ssd_fail(SSD_ERR_INVALID, "ssd_get_tensor: null argument");
     std::lock_guard<std::mutex> g(h->mu);
-    if (h->plans.empty()) return ssd_fail(SSD_ERR_STATE, "ssd_get_tensor before ssd_forward");
+    if (!h->cur) return ssd_fail(SSD_ERR_STATE, "ssd_get_tensor before ssd_forward");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipDeviceSynchronize());
     long long done = 0;
     int Btot = 0;
-    for (Plan *pl : h->plans) {                  // sub-batches are consecutive images
+    for (Plan *pl : h->cur->plans) {             // sub-batches are consecutive images
         auto it = pl->retained.find(name);
         if (it == pl->retained.end()) return ssd_fail(SSD_ERR_INVALID, std::string("ssd_get_tensor: unknown tensor ") + name);
         const Retained &r = it->second;
@@ -422,11 +442,11 @@ extern "C" int ssd_get_tensor_dev(ssd_handle *h, const char *name, float *dst_de
 {
     if (!h || !name || !dst_dev || !dims) return ssd_fail(SSD_ERR_INVALID, "ssd_get_tensor_dev: null argument");
     std::lock_guard<std::mutex> g(h->mu);
-    if (h->plans.empty()) return ssd_fail(SSD_ERR_STATE, "ssd_get_tensor_dev before ssd_forward");
+    if (!h->cur) return ssd_fail(SSD_ERR_STATE, "ssd_get_tensor_dev before ssd_forward");
     HIPCHK(hipSetDevice(h->cfg.device));
     long long done = 0;
     int Btot = 0;
-    for (Plan *pl : h->plans) {
+    for (Plan *pl : h->cur->plans) {
         auto it = pl->retained.find(name);
         if (it == pl->retained.end()) return ssd_fail(SSD_ERR_INVALID, std::string("ssd_get_tensor_dev: unknown tensor ") + name);
         const Retained &r = it->second;
@@ -439,6 +459,38 @@ extern "C" int ssd_get_tensor_dev(ssd_handle *h, const char *name, float *dst_de
         dims[1] = r.H; dims[2] = r.W; dims[3] = r.C;
     }
     dims[0] = Btot;
+    return SSD_OK;
+}
+
+// ----------------------------------------------------------------------------- plan cache
+// out[0..7] = cached plan sets, their arena bytes, the budget in bytes, hits, misses, evictions, and the network shape
+// (height, width) of the set the last forward ran.
+extern "C" int ssd_plan_cache_stats(ssd_handle *h, int64_t *out)
+{
+    if (!h || !out) return ssd_fail(SSD_ERR_INVALID, "ssd_plan_cache_stats: null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    size_t total = 0;
+    for (const PlanSet *ps : h->cache) total += ps->bytes;
+    out[0] = (int64_t)h->cache.size();
+    out[1] = (int64_t)total;
+    out[2] = (int64_t)plan_cache_limit_bytes(h);
+    out[3] = h->cache_hits; out[4] = h->cache_misses; out[5] = h->cache_evictions;
+    out[6] = h->cur ? h->cur->key.netH : 0;
+    out[7] = h->cur ? h->cur->key.netW : 0;
+    return SSD_OK;
+}
+
+// Drops every cached plan (and the verified record pointers of ssd_detect_host) after draining the device; the counters stay.
+extern "C" int ssd_plan_cache_clear(ssd_handle *h)
+{
+    if (!h) return ssd_fail(SSD_ERR_INVALID, "ssd_plan_cache_clear: null handle");
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    h->cache_evictions += (long long)h->cache.size();
+    free_plans(h);
+    h->n_rec_ok = 0;
     return SSD_OK;
 }
 

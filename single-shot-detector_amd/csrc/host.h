@@ -41,6 +41,8 @@ enum SsdOpt {
     OPT_BACKBONE_SPLIT,     // 0 auto | 1 | 2: backbone chains (two half-batch chains from 4 images on)
     OPT_EVENT_FENCE,        // 0 (default): the library's ordering events carry no system-scope fence (hipEventDisableSystemFence: they order
                             // streams of ONE device) | 1: default event flags (a cache writeback per record: ~8-12 us per cross-stream edge)
+    OPT_PLAN_CACHE_MB,      // 0 auto (a quarter of the device's memory) | n: the layer plans a handle keeps (one per network shape it has
+                            // served) may hold up to n MiB of arena; the least recently used ones go first, the running one always stays
     // test hooks: pin a kernel variant / a plan shape so that the parity tests see every shape on it (none changes a result bit in mode f32)
     OPT_IGEMM_TILE,         // 0 auto | 128 | 64: pins the 128x128-vs-64x64 choice of the implicit-GEMM kernel | 20 .. 27: a wave tile of igemm_lat.hip
     OPT_IGEMM16,            // -1 auto | 0 | 1: f16x3 launches on the 256x256-tile kernel
@@ -71,12 +73,14 @@ struct Tensor {
 
 struct DevPool {
     std::vector<void *> ptrs;
-    int alloc(void **out, size_t bytes)
+    size_t bytes = 0;           // what the pool holds (the plan cache's budget counts these)
+    int alloc(void **out, size_t nbytes)
     {
         // 256 bytes of slack behind every tensor: igemm_lat.hip's 4-byte-shifted 16-byte loads touch (and never use)
         // the dword behind a tensor's last chunk
-        HIPCHK(hipMalloc(out, bytes + 256));
+        HIPCHK(hipMalloc(out, nbytes + 256));
         ptrs.push_back(*out);
+        bytes += nbytes + 256;
         return SSD_OK;
     }
     template <class T> int upload(T **out, const std::vector<T> &v)
@@ -91,6 +95,7 @@ struct DevPool {
     {
         for (void *p : ptrs) (void)hipFree(p);
         ptrs.clear();
+        bytes = 0;
     }
 };
 
@@ -174,8 +179,8 @@ Op make_dwpws_op(const DwW &d, const ConvW &cw, const float *in, int B, int H, i
                  float *out, int out_rs = 0 /* floats between output rows; 0: cw.CoutP */);
 // sn_pw.hip: 1x1 + batch norm + activation on rows gathered through `src` (device table, CinP entries) from `base`
 Op make_pw_gather_op(const ConvW &cw, const float *base, long long base_bytes, const int *src, int rs, long long M, int act, float *out);
-// front.hip: first convolution + Conv2d_1 in one launch; the frame pointer is the handle's cur_images + img_off at run time
-Op make_front_op(struct ssd_handle *h, size_t img_off, const DwW &f, int act0, const DwW &d, const ConvW &cw, int B, int H, int W, int dact, int act, float *out);
+// front.hip: first convolution + Conv2d_1 in one launch; the frame pointer is the handle's cur_images + img_index frames at run time
+Op make_front_op(struct ssd_handle *h, int img_index, const DwW &f, int act0, const DwW &d, const ConvW &cw, int B, int H, int W, int dact, int act, float *out);
 LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long in_off = 0, long long out_off = 0,
                       int param_off = 0, long long res_off = 0);
 float conservative_logit_bound(float thr);
@@ -208,6 +213,23 @@ struct Plan {
     bool need_begin = false;            // some chain starts on an internal stream without a dependency: it waits for ev_begin
 };
 
+// What a forward takes from the SOURCE frames (resize_keeping_aspect_ratio, pipeline.py:138-194; model.py:67-68): launch arguments
+// of the first kernel and of the pack kernel, set per call -- NOT part of a plan, which is keyed on what the network sees.
+struct SrcGeom { int srcH = 0, srcW = 0, nh = 0, nw = 0; float box_scaler[4] = {1, 1, 1, 1}; };
+
+// The plans of one network shape: key = (batch, the resized + padded size the network sees, whether the source already has that
+// size -- then the first layers are the fused front launch --, and the number of consecutive sub-batch plans).
+struct PlanKey {
+    int B = 0, netH = 0, netW = 0, ident = 0, nsub = 0;
+    bool operator==(const PlanKey &o) const { return B == o.B && netH == o.netH && netW == o.netW && ident == o.ident && nsub == o.nsub; }
+};
+struct PlanSet {
+    PlanKey key;
+    std::vector<Plan *> plans;          // one, or consecutive sub-batch plans
+    size_t bytes = 0;                   // arena of all of them
+    unsigned long long last_use = 0;    // the handle's use clock at the last forward that ran this set
+};
+
 struct ssd_handle {
     ssd_config cfg;
     std::mutex mu;                      // every entry point that takes the handle holds it: calls on one handle are serialised
@@ -227,16 +249,22 @@ struct ssd_handle {
     int c_split[3] = {0, 0, 0};         // > 0: c3 / c4 is a ShuffleNet stage output in two-part rows [x half | y half], this many channels each
     int precision = SSD_PRECISION_F32;  // ssd_set_precision
     int *flags_dev = nullptr;           // status word (bit 0: an S16 tensor was clamped to the fp16 range)
-    // plans
-    int pB = 0, pH = 0, pW = 0;
-    std::vector<Plan *> plans;
+    // Layer plans: one set per network shape this handle has served, each with an arena of its own, kept until the budget
+    // (option plan_cache_mb) or an option / precision change evicts it.  The reference's graph takes any image size in one
+    // session (detector/ssd.py:27-31, create_pb.py:24,40); a mix of sizes must not re-plan per call.
+    std::vector<PlanSet *> cache;
+    PlanSet *cur = nullptr;             // the set of the last forward (ssd_get_tensor reads its retained tensors)
+    unsigned long long use_clock = 0;
+    long long cache_hits = 0, cache_misses = 0, cache_evictions = 0;
     const uint8_t *cur_images = nullptr;
-    // the arena is one per handle: a forward enqueued on another stream than the previous one waits for it
+    SrcGeom src;                        // of the forward being enqueued (read by the ops' launch closures, like cur_images)
+    // the plans share the process's internal streams: a forward enqueued on another stream than the previous one waits for it
     hipStream_t last_stream = nullptr;
     bool have_last = false;
     bool multi_stream = false;          // forwards have arrived on more than one stream: ev_last is recorded behind every forward
     hipEvent_t ev_last = nullptr;
-    const void *detect_rec_ok = nullptr;     // ssd_detect_host: the record pointer last verified to be host-visible memory
+    const void *detect_rec_ok[8] = {nullptr};     // ssd_detect_host: record pointers verified to be host-visible memory
+    int n_rec_ok = 0, rec_ok_next = 0;
     // ssd_forward_host: pinned staging + device image, grown on demand; the stream whose copy last read the staging buffer
     uint8_t *stage_pin = nullptr, *stage_dev = nullptr;
     size_t stage_bytes = 0;
@@ -253,7 +281,9 @@ struct ssd_handle {
 };
 
 // plan.hip
-void free_plans(ssd_handle *h);
-int make_plans(ssd_handle *h, int B, int H, int W);
+void free_plans(ssd_handle *h);                         // every cached set (the device must be idle)
+int select_plans(ssd_handle *h, int B, int H, int W);   // h->cur = the set of this source shape: cache hit, or build (+ evict)
+int trim_plan_cache(ssd_handle *h, const PlanSet *keep);
+size_t plan_cache_limit_bytes(const ssd_handle *h);
 int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, int32_t *labels_dev, float *scores_dev,
                     int32_t *num_boxes_dev, long long out_stride, hipStream_t s);

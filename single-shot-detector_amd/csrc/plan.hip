@@ -1,6 +1,8 @@
-// The layer plan of one (B,H,W): the reference graph (create_pb.py + model.py PREDICT) as a flat list of kernel
-// launches on a few streams with explicit dependencies, no host synchronisation.  Built once per shape by
-// ssd_forward (abi.hip), enqueued per call.
+// The layer plan of one network shape (batch, resized + padded height and width): the reference graph (create_pb.py +
+// model.py PREDICT) as a flat list of kernel launches on a few streams with explicit dependencies, no host synchronisation.
+// Built once per shape by ssd_forward (abi.hip) and KEPT (select_plans below: one set of plans per shape a handle has served,
+// least recently used out first when the arena budget is passed), enqueued per call.  What a call takes from its SOURCE frames
+// -- their size, the resize's target, box_scaler -- are launch arguments read from the handle (SrcGeom), not part of a plan.
 #include "host.h"
 #include <chrono>
 
@@ -182,9 +184,9 @@ Op make_conv_op(const ssd_handle *h, const ConvW &cw, const float *in, float *ou
     return op;
 }
 
-void free_plans(ssd_handle *h)
+static void free_planset(PlanSet *ps)
 {
-    for (Plan *pl : h->plans) {
+    for (Plan *pl : ps->plans) {
         for (Op &op : pl->ops)
             if (op.done) (void)hipEventDestroy(op.done);
         pl->pool.free_all();
@@ -192,8 +194,14 @@ void free_plans(ssd_handle *h)
         if (pl->ev_begin) (void)hipEventDestroy(pl->ev_begin);
         delete pl;
     }
-    h->plans.clear();
-    h->pB = h->pH = h->pW = 0;
+    delete ps;
+}
+
+void free_plans(ssd_handle *h)
+{
+    for (PlanSet *ps : h->cache) free_planset(ps);
+    h->cache.clear();
+    h->cur = nullptr;
 }
 
 // ----------------------------------------------------------------------------- plan
@@ -289,7 +297,7 @@ Op make_pw_gather_op(const ConvW &cw, const float *base, long long base_bytes, c
 }
 
 // MobileNet's first convolution + Conv2d_1 as one launch (front.hip): the frames at the network's input size, 32 -> 32 -> 64
-Op make_front_op(ssd_handle *h, size_t img_off, const DwW &f, int act0, const DwW &d, const ConvW &cw, int B, int H, int W, int dact, int act, float *out)
+Op make_front_op(ssd_handle *h, int img_index, const DwW &f, int act0, const DwW &d, const ConvW &cw, int B, int H, int W, int dact, int act, float *out)
 {
     FrontArgs q;
     memset(&q, 0, sizeof(q));
@@ -303,9 +311,9 @@ Op make_front_op(ssd_handle *h, size_t img_off, const DwW &f, int act0, const Dw
     const double M = (double)B * (H / 2) * (W / 2);
     op.flops = (2.0 * 27 * cw.Cin_l + 2.0 * 9 * cw.Cin_l + 2.0 * cw.Cin_l * cw.Cout_l) * M;
     op.bytes = (double)B * H * W * 3 + M * cw.Cout_l * 4.0;
-    op.run = [q, h, img_off](hipStream_t s) {
+    op.run = [q, h, img_index, H, W](hipStream_t s) {
         FrontArgs r = q;
-        r.img = h->cur_images + img_off;
+        r.img = h->cur_images + (size_t)img_index * H * W * 3;       // (a plan with this op runs frames of the network's own size only)
         return launch_front(r, s);
     };
     return op;
@@ -324,14 +332,11 @@ LevelDesc dense_level(int H, int W, int OH, int OW, int CoutP, long long in_off,
     return d;
 }
 
-static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int img0)
+// H, W: the network's input size (multiples of 128); ident: the source frames already have it (no resize, no pad band)
+static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, int img0)
 {
     pl.B = B;
     pl.img0 = img0;
-    const size_t img_off = (size_t)img0 * srcH * srcW * 3;
-    const ResizeDims rd = resize_dims(srcH, srcW, h->cfg.min_dimension, 128);
-    const int H = rd.nh + rd.ph, W = rd.nw + rd.pw;     // network input size (multiples of 128)
-    const int rnh = rd.nh, rnw = rd.nw;
     DevPool &ap = pl.pool;
     auto falloc = [&](float **p, long long nfloats) { return ap.alloc((void **)p, (size_t)nfloats * sizeof(float)); };
 
@@ -393,7 +398,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
             SSDCHK(falloc(&Y, maxf));
             // first convolution + Conv2d_1 as ONE launch (front.hip) when the frames arrive at the network's input size and
             // the three layers have MobileNet-1.0's widths; option front_fuse = 0 / 1 pins it
-            bool front = srcH == H && srcW == W && rnh == H && rnw == W && ((fuse_mask >> 0) & 1) && h->first.mean && h->dw[0].pack &&
+            bool front = ident && ((fuse_mask >> 0) & 1) && h->first.mean && h->dw[0].pack &&
                          h->pw[0].taps == 1 && h->pw[0].mean && !h->pw[0].bias && front_supports(nb, H, W, h->firstCp, h->dw[0].Cp, h->pw[0].CoutP) &&
                          h->pw[0].CinP == 32 && MB_STRIDE[0] == 1;
             { const int pin = ssd_opt(h, OPT_FRONT_FUSE, -1); if (pin >= 0) front = front && pin != 0; }
@@ -405,9 +410,11 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 ssd_handle *hh = h;
                 const DwW f = h->first;
                 const int act = h->firstAct;
-                const size_t off = img_off + (size_t)b0 * srcH * srcW * 3;
-                op.run = [=](hipStream_t s) {
-                    return launch_first_conv(hh->cur_images + off, nb, srcH, srcW, rnh, rnw, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, X, s);
+                const int first_img = img0 + b0;
+                op.run = [=](hipStream_t s) {      // the source's size and the resize's target: this call's (SrcGeom), any that lands on H x W
+                    const SrcGeom &g = hh->src;
+                    return launch_first_conv(hh->cur_images + (size_t)first_img * g.srcH * g.srcW * 3, nb, g.srcH, g.srcW, g.nh, g.nw, H, W, f.w, f.Cp,
+                                             f.mean, f.sf, f.beta, act, X, s);
                 };
                 ops.push_back(op);
             }
@@ -418,7 +425,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 float *dwo = (cur == X) ? Y : X;
                 const ConvW &cw = h->pw[i];
                 if (i == 0 && front) {
-                    ops.push_back(make_front_op(h, img_off + (size_t)b0 * srcH * srcW * 3, h->first, h->firstAct, h->dw[0], cw, nb, H, W,
+                    ops.push_back(make_front_op(h, img0 + b0, h->first, h->firstAct, h->dw[0], cw, nb, H, W,
                                                 SSD_ACT_RELU6, SSD_ACT_RELU6, dwo));
                     cur = dwo;
                     continue;
@@ -465,7 +472,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         const int h4 = h2 / 2, w4 = w2 / 2;
         // first convolution + max pool as ONE launch (front.hip) when the frames arrive at the network's input size; option
         // front_fuse = 0 / 1 pins it
-        bool sn_front = srcH == H && srcW == W && rnh == H && rnw == W && h->first.mean && front_pool_supports(B, H, W, fc);
+        bool sn_front = ident && h->first.mean && front_pool_supports(B, H, W, fc);
         { const int pin = ssd_opt(h, OPT_FRONT_FUSE, -1); if (pin >= 0) sn_front = sn_front && pin != 0; }
         // ---- One or two half-batch chains (two from 4 images on, on the plan's two streams, as MobileNet's backbone above: the
         // backbone is ~45 short kernels far from any bound, one chain's load / store phases sit under the other's arithmetic);
@@ -481,7 +488,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
         //   * the stage output is kept in two-part rows [x half | y half] (weights.hip packs its consumers for that): the last
         //     unit stores its channels straight into the x half, the y half (channels no later unit touched) is one row gather.
         // Each stage is ONE allocation [producer tensors of chain 0 | ... of chain 1 | stage output S of the whole batch] under
-        // one buffer resource (make_plans keeps it below 2 GiB).
+        // one buffer resource (select_plans keeps it below 2 GiB).
         int nhalf = B >= 4 ? 2 : 1;
         { const int v = ssd_opt(h, OPT_BACKBONE_SPLIT, 0); if (v >= 1 && v <= 2 && v <= B) nhalf = v; }
         const int nb_of[2] = {nhalf == 2 ? B / 2 : B, nhalf == 2 ? B - B / 2 : 0};
@@ -546,20 +553,22 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
                 ssd_handle *hh = h;
                 const DwW f = h->first;
                 const int act = h->firstAct;
-                const size_t off = img_off + (size_t)b0 * srcH * srcW * 3;
+                const int first_img = img0 + b0;
                 Op op;
                 op.cls = 3;
                 op.flops = 2.0 * 27 * (double)nb * h2 * w2 * 24;
                 if (sn_front) {
                     // first convolution + max pool as one launch (front.hip): the half-resolution tensor stays in LDS
                     op.bytes = (double)nb * H * W * 3 + (double)nb * h4 * w4 * 24 * 4.0;
-                    op.run = [=](hipStream_t s) { return launch_front_pool(hh->cur_images + off, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, MP, s); };
+                    op.run = [=](hipStream_t s) { return launch_front_pool(hh->cur_images + (size_t)first_img * H * W * 3, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, MP, s); };
                     ops.push_back(op);
                 } else {
                     SSDCHK(falloc(&F, (long long)nb * h2 * w2 * fc));
                     op.bytes = (double)nb * H * W * 3 + (double)nb * h2 * w2 * 24 * 4.0;
                     op.run = [=](hipStream_t s) {
-                        return launch_first_conv(hh->cur_images + off, nb, srcH, srcW, rnh, rnw, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s);
+                        const SrcGeom &g = hh->src;
+                        return launch_first_conv(hh->cur_images + (size_t)first_img * g.srcH * g.srcW * 3, nb, g.srcH, g.srcW, g.nh, g.nw, H, W, f.w, f.Cp,
+                                                 f.mean, f.sf, f.beta, act, F, s);
                     };
                     ops.push_back(op);
                     Op mp;
@@ -803,7 +812,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int srcH, int srcW, int im
     p.score_thr = h->cfg.score_threshold; p.iou_thr = h->cfg.iou_threshold;
     p.max_per_class = h->cfg.max_boxes_per_class;
     p.fast_max = nms_fast_max(h);
-    for (int k = 0; k < 4; ++k) p.box_scaler[k] = rd.box_scaler[k];    // model.py:67-68
+    for (int k = 0; k < 4; ++k) p.box_scaler[k] = 1.0f;               // (model.py:67-68: this call's, set by enqueue_forward)
     post_carve(p, ws);
     HIPCHK(hipMemset(p.scan_bits, 0, post_scan_bitmap_bytes(B, (int)N, C)));
     HIPCHK(hipMemset(p.counts, 0, (size_t)B * C * sizeof(int)));      // the post-processing kernels leave these zeroed again
@@ -915,7 +924,7 @@ static hipError_t run_op(ssd_handle *h, const Op &op, hipStream_t s)
     return r;
 }
 
-// The plans' internal streams (one set per device and process, make_plans below).  HIP streams share a small pool of hardware queues (4 per process and priority level by
+// The plans' internal streams (one set per device and process, build_planset below).  HIP streams share a small pool of hardware queues (4 per process and priority level by
 // default), each new stream joining the least-loaded one, so WHICH queue the class tower's stream gets depends on what the
 // process created before: on the caller's queue it runs behind the box tower instead of beside it (bench.py under
 // torch.distributed, RCCL's streams first: 788 instead of 822 img/s; a second engine in one process: batch-1 forward +30 us).
@@ -924,9 +933,93 @@ static hipError_t run_op(ssd_handle *h, const Op &op, hipStream_t s)
 // (Measured and not adopted, profiles/r03_batch1_option_ab.log: streams of the highest priority, whose queues come from a pool
 // of their own -- robust against what the framework created, but a second engine's batch-1 forward took 2.4 ms instead of 1.64;
 // a CU-masked stream is a BLOCKING stream and would serialise with the legacy default stream.)
-int make_plans(ssd_handle *h, int B, int H, int W)
+// The arena budget of a handle's cached plans: option plan_cache_mb, default a quarter of the device's memory (a batch-1 plan of
+// MobileNet at 640 x 1024 holds ~0.35 GB, a 32-image one ~7 GB: the COCO mix of a dozen network shapes at batch 1 is ~4 GB).
+size_t plan_cache_limit_bytes(const ssd_handle *h)
 {
-    free_plans(h);
+    const int mb = ssd_opt(h, OPT_PLAN_CACHE_MB, 0);
+    if (mb > 0) return (size_t)mb << 20;
+    static std::mutex mu;
+    static std::map<int, size_t> total;                 // device -> a quarter of its memory (asked once per device)
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = total.find(h->cfg.device);
+    if (it != total.end()) return it->second;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); tot = (size_t)64 << 30; }
+    return total[h->cfg.device] = tot / 4;
+}
+
+// Evicts least-recently-used sets until the cache fits its budget (and holds at most 64 sets); `keep` (the set about to run) stays
+// whatever it weighs.  An eviction frees device memory the GPU may still be reading: the device is drained first -- the only
+// device-wide wait of the forward path, and only behind a cache MISS that overflowed the budget.
+int trim_plan_cache(ssd_handle *h, const PlanSet *keep)
+{
+    const size_t limit = plan_cache_limit_bytes(h);
+    bool drained = false;
+    for (;;) {
+        size_t total = 0;
+        for (const PlanSet *ps : h->cache) total += ps->bytes;
+        if ((total <= limit && h->cache.size() <= 64) || h->cache.size() <= 1) break;
+        size_t victim = h->cache.size();
+        for (size_t i = 0; i < h->cache.size(); ++i)
+            if (h->cache[i] != keep && (victim == h->cache.size() || h->cache[i]->last_use < h->cache[victim]->last_use)) victim = i;
+        if (victim == h->cache.size()) break;
+        if (!drained) { HIPCHK(hipDeviceSynchronize()); drained = true; }
+        if (h->cur == h->cache[victim]) h->cur = nullptr;
+        free_planset(h->cache[victim]);
+        h->cache.erase(h->cache.begin() + victim);
+        h->cache_evictions += 1;
+    }
+    return SSD_OK;
+}
+
+static int build_planset(ssd_handle *h, PlanSet &ps)
+{
+    const PlanKey &key = ps.key;
+    int img0 = 0;
+    for (int k = 0; k < key.nsub; ++k) {
+        const int bk = key.B / key.nsub + (k < key.B % key.nsub ? 1 : 0);
+        Plan *pl = new Plan();
+        ps.plans.push_back(pl);
+        {
+            // ONE set of internal streams per device and process, created by the first plan that needs them and shared by every
+            // handle and every plan after it (a handle's ops stay ordered per stream and across streams by their events;
+            // two handles that run at the same time merely take turns on them): a second engine -- bench.py's ShuffleNet leg behind
+            // the MobileNet one -- runs on the hardware queues the first one got, instead of on whatever is least loaded by then
+            // (measured: 1 113 instead of 1 200 img/s when its class-tower stream landed on the caller's queue).
+            static std::mutex pool_mu;
+            static std::map<int, std::vector<hipStream_t>> pool;       // device -> [second, third, fourth stream]
+            std::lock_guard<std::mutex> lk(pool_mu);
+            std::vector<hipStream_t> &pv = pool[h->cfg.device];
+            if (pv.size() < 3) pv.resize(3, nullptr);
+            for (int i = 0; i < 3; ++i)
+                if (!pv[i]) HIPCHK(hipStreamCreateWithFlags(&pv[i], hipStreamNonBlocking));
+            pl->s_aux = pv[0];
+            pl->s_bb[0] = pv[1];
+            pl->s_bb[1] = pv[2];
+        }
+        HIPCHK(hipEventCreateWithFlags(&pl->ev_join, ssd_sync_event_flags(h)));
+        HIPCHK(hipEventCreateWithFlags(&pl->ev_begin, ssd_sync_event_flags(h)));
+        SSDCHK(build_plan(h, *pl, bk, key.netH, key.netW, key.ident != 0, img0));
+        img0 += bk;
+        ps.bytes += pl->pool.bytes;
+    }
+    return SSD_OK;
+}
+
+// h->cur = the plans of source frames [B, H, W, 3].  Key: what the NETWORK sees -- B, the resized + padded size, whether the source
+// already has it -- so 480 x 640 and 375 x 500 (both -> 640 x 896) share one set, and a mix of image sizes through one handle
+// (inference/evaluate_on_COCO.ipynb:125-150) re-plans nothing after its first pass.  A HIT touches no HIP API at all; a MISS
+// allocates and fills a new arena beside the others (no device-wide wait: the running forwards use their own arenas) and may
+// then evict (trim_plan_cache).
+int select_plans(ssd_handle *h, int B, int H, int W)
+{
+    const ResizeDims rd = resize_dims(H, W, h->cfg.min_dimension, 128);
+    PlanKey key;
+    key.B = B;
+    key.netH = rd.nh + rd.ph;
+    key.netW = rd.nw + rd.pw;
+    key.ident = (H == key.netH && W == key.netW && rd.nh == H && rd.nw == W) ? 1 : 0;
     // ONE plan per forward (round 1: 1 / 2 / 4 / 8 staggered sub-batch plans -> 730 / 696 / 647 / 587 img/s: backbone kernels
     // beside head kernels take CU slots from them and stretch far more than the overlap returns).  Consecutive sub-batch plans
     // exist for one reason: every tensor a launch addresses with 32-bit byte offsets must stay < 2 GiB.  Per image: the largest
@@ -936,8 +1029,7 @@ int make_plans(ssd_handle *h, int B, int H, int W)
     int nsub = 1;
     { const int v = ssd_opt(h, OPT_NSUB, 0); if (v >= 1 && v <= 8) nsub = v; }
     {
-        const ResizeDims rd = resize_dims(H, W, h->cfg.min_dimension, 128);
-        const int nH = rd.nh + rd.ph, nW = rd.nw + rd.pw;
+        const int nH = key.netH, nW = key.netW;
         const int cmax = h->cfg.backbone == SSD_BACKBONE_MOBILENET && !h->pw.empty() ? std::max(h->firstCp, h->pw[0].CoutP) : h->firstCp;
         long long per_img = (long long)(nH / 2) * (nW / 2) * cmax * 4;
         const Pyr py1 = make_pyr(1, nH, nW, 256);
@@ -958,35 +1050,48 @@ int make_plans(ssd_handle *h, int B, int H, int W)
         if (need > nsub) nsub = need;
     }
     if (nsub > B) nsub = B;
-    int img0 = 0;
-    for (int k = 0; k < nsub; ++k) {
-        const int bk = B / nsub + (k < B % nsub ? 1 : 0);
-        Plan *pl = new Plan();
-        h->plans.push_back(pl);
-        {
-            // ONE set of internal streams per device and process, created by the first plan that needs them and shared by every
-            // handle and every sub-batch plan after it (a handle's ops stay ordered per stream and across streams by their events;
-            // two handles that run at the same time merely take turns on them): a second engine -- bench.py's ShuffleNet leg behind
-            // the MobileNet one -- runs on the hardware queues the first one got, instead of on whatever is least loaded by then
-            // (measured: 1 113 instead of 1 200 img/s when its class-tower stream landed on the caller's queue).
-            static std::mutex pool_mu;
-            static std::map<int, std::vector<hipStream_t>> pool;       // device -> [second, third, fourth stream]
-            std::lock_guard<std::mutex> lk(pool_mu);
-            std::vector<hipStream_t> &pv = pool[h->cfg.device];
-            if (pv.size() < 3) pv.resize(3, nullptr);
-            for (int i = 0; i < 3; ++i)
-                if (!pv[i]) HIPCHK(hipStreamCreateWithFlags(&pv[i], hipStreamNonBlocking));
-            pl->s_aux = pv[0];
-            pl->s_bb[0] = pv[1];
-            pl->s_bb[1] = pv[2];
-        }
-        HIPCHK(hipEventCreateWithFlags(&pl->ev_join, ssd_sync_event_flags(h)));
-        HIPCHK(hipEventCreateWithFlags(&pl->ev_begin, ssd_sync_event_flags(h)));
-        SSDCHK(build_plan(h, *pl, bk, H, W, img0));
-        img0 += bk;
+    key.nsub = nsub;
+    h->src.srcH = H; h->src.srcW = W; h->src.nh = rd.nh; h->src.nw = rd.nw;
+    for (int k = 0; k < 4; ++k) h->src.box_scaler[k] = rd.box_scaler[k];
+    h->use_clock += 1;
+    if (h->cur && h->cur->key == key) {                 // (the usual serving loop: same shape as the call before)
+        h->cur->last_use = h->use_clock;
+        h->cache_hits += 1;
+        return SSD_OK;
     }
-    h->pB = B; h->pH = H; h->pW = W;
-    return SSD_OK;
+    for (PlanSet *ps : h->cache)
+        if (ps->key == key) {
+            ps->last_use = h->use_clock;
+            h->cur = ps;
+            h->cache_hits += 1;
+            return SSD_OK;
+        }
+    h->cache_misses += 1;
+    PlanSet *ps = new PlanSet();
+    ps->key = key;
+    ps->last_use = h->use_clock;
+    int rc = build_planset(h, *ps);
+    if (rc == SSD_ERR_HIP && !h->cache.empty()) {
+        // (most likely out of device memory: drop every other set -- the device drained -- and try once more)
+        (void)hipGetLastError();
+        free_planset(ps);
+        HIPCHK(hipDeviceSynchronize());
+        h->cache_evictions += (long long)h->cache.size();
+        free_plans(h);
+        ps = new PlanSet();
+        ps->key = key;
+        ps->last_use = h->use_clock;
+        rc = build_planset(h, *ps);
+    }
+    if (rc != SSD_OK) {
+        const std::string msg = ssd_last_error();        // (the frees below do not touch it, but keep the first cause)
+        (void)hipDeviceSynchronize();
+        free_planset(ps);
+        return ssd_fail(rc, msg);
+    }
+    h->cache.push_back(ps);
+    h->cur = ps;
+    return trim_plan_cache(h, ps);
 }
 
 // Enqueues one forward on stream `s` (plus the plans' internal streams): kernels only, no host synchronisation.  Sub-batch plans
@@ -994,6 +1099,7 @@ int make_plans(ssd_handle *h, int B, int H, int W)
 int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, int32_t *labels_dev,
                            float *scores_dev, int32_t *num_boxes_dev, long long out_stride, hipStream_t s)
 {
+    if (!h->cur) return ssd_fail(SSD_ERR_STATE, "enqueue_forward: no plan selected");
     h->cur_images = images_dev;
     if (h->profiling) {
         hipEvent_t ref;
@@ -1002,8 +1108,9 @@ int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, 
         h->ref_evs.push_back(ref);
     }
     const int T = h->cfg.num_classes * h->cfg.max_boxes_per_class;
-    for (size_t k = 0; k < h->plans.size(); ++k) {
-        Plan &pl = *h->plans[k];
+    const std::vector<Plan *> &plans = h->cur->plans;
+    for (size_t k = 0; k < plans.size(); ++k) {
+        Plan &pl = *plans[k];
         // (k > 0: the previous plan's side streams were joined into `s` before its post-processing, and this plan's chains on
         //  them start behind ev_begin or behind an op of this plan: the shared streams need no further ordering)
         if (pl.need_begin) HIPCHK(hipEventRecord(pl.ev_begin, s));
@@ -1027,6 +1134,7 @@ int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, 
             HIPCHK(hipStreamWaitEvent(s, pl.ev_join, 0));
         }
         PostArgs p = pl.post;
+        for (int q = 0; q < 4; ++q) p.box_scaler[q] = h->src.box_scaler[q];       // model.py:67-68, of this call's source size
         p.out_stride = out_stride;
         p.boxes = boxes_dev + (out_stride ? (size_t)pl.img0 * out_stride : (size_t)pl.img0 * T * 4);
         p.labels = labels_dev + (out_stride ? (size_t)pl.img0 * out_stride : (size_t)pl.img0 * T);

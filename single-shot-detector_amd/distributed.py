@@ -115,7 +115,7 @@ def all_gather_detections(boxes, labels, scores, num, group=None, total=None, fo
 _gather_buffers = {}
 
 
-def detect_sharded(engine, images_local, group=None, total=None, force=False):
+def detect_sharded(engine, images_local, group=None, total=None, force=False, on_forward_done=None):
     """One data-parallel step: this rank's shard through the HIP path, then the all-gather.
     images_local: uint8 CUDA tensor [B_local,H,W,3]; `total`, `force`: see all_gather_detections.
     The engine writes its records straight into this rank's slice of the all-gather's receive buffer (ssd_forward_records),
@@ -130,13 +130,21 @@ def detect_sharded(engine, images_local, group=None, total=None, force=False):
 
     A failed collective propagates: after an RCCL error the communicator is aborted and a retry on the same process group
     can hang every rank, so nothing is retried here.  Whether the send buffer may sit inside the receive buffer is decided
-    once from the backend's name ('nccl' = RCCL: in place; anything else: one copy of this rank's slice)."""
+    once from the backend's name ('nccl' = RCCL: in place; anything else: one copy of this rank's slice).
+
+    `on_forward_done`: called (no arguments) between the engine's forward and the collective -- bench.py records an event
+    there to split a step into compute and all-gather."""
     use = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
     if not hasattr(engine, "record_words"):                # a stand-in engine (launcher tests): the generic path
         boxes, labels, scores, num = engine.forward(images_local)
+        if on_forward_done is not None:
+            on_forward_done()
         return all_gather_detections(boxes, labels, scores, num, group=group, total=total, force=force)
     if not use:
-        return engine.forward(images_local)
+        out = engine.forward(images_local)
+        if on_forward_done is not None:
+            on_forward_done()
+        return out
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     n = images_local.shape[0]
     per = n if (total is None or total % world == 0) else -(-total // world)
@@ -151,6 +159,8 @@ def detect_sharded(engine, images_local, group=None, total=None, force=False):
     buf = slot["bufs"][slot["turn"]]
     slot["turn"] ^= 1
     engine.forward(images_local, records=buf[rank, :n])
+    if on_forward_done is not None:
+        on_forward_done()
     inplace = dist.get_backend(group) == "nccl"
     got = gather_records(buf[rank] if inplace else buf[rank].clone(), group, out=buf.view(world * per, -1))
     if per == n and (total is None or total % world == 0):

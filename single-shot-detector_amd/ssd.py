@@ -362,7 +362,8 @@ class Engine:
 
     def set_option(self, key, value):
         """ssd_set_option on this engine's handle (include/ssd_hip.h lists the keys): a kernel / schedule selector that
-        does not change a result bit in mode f32.  Synchronises and drops the cached layer plan."""
+        does not change a result bit in mode f32.  Synchronises and drops the cached layer plans (except "plan_cache_mb",
+        which only evicts down to the new budget)."""
         with self.lock:
             _lib.set_option(key, value, self._h)
 
@@ -424,60 +425,79 @@ class Engine:
         block = self.new_records(B, dev)
         return block, self.record_views(block)
 
-    def _slot(self, key, index=0):
-        """Persistent serving buffers of one input shape: device image, pinned host staging for the image, the device record
-        block and its pinned host copy."""
+    def _out_slot(self, B, index=0):
+        """Persistent result buffers of one BATCH SIZE: the device record block, its pinned host copy and numpy / tensor views
+        of both.  Independent of the image size: a mix of sizes through one engine (inference/evaluate_on_COCO.ipynb:125-150)
+        reuses one slot."""
         torch = _torch()
-        slot = self._static.get((key, index))
+        slot = self._static.get(("out", B, index))
         if slot is None:
             dev = "cuda:%d" % self.device
-            B = key[0]
             block, views = self._new_outputs(torch, B, dev)
-            pin_in = torch.empty(key, dtype=torch.uint8).pin_memory()
             pin_out = torch.empty(block.shape, dtype=torch.int32).pin_memory()
-            slot = {"dev_in": torch.empty(key, dtype=torch.uint8, device=dev), "pin_in": pin_in, "pin_in_np": pin_in.numpy(),
-                    "block": block, "views": views, "pin_out": pin_out, "host": self.record_views(pin_out.numpy())}
-            while len(self._static) >= 8:
-                self._static.pop(next(iter(self._static)))
-            self._static[(key, index)] = slot
+            slot = {"block": block, "views": views, "pin_out": pin_out, "host": self.record_views(pin_out.numpy())}
+            while sum(1 for k in self._static if k[0] == "out") >= 8:
+                self._static.pop(next(k for k in self._static if k[0] == "out"))
+            self._static[("out", B, index)] = slot
         return slot
+
+    def _in_slot(self, shape, index=0, pinned=False):
+        """Persistent image buffers, grow-only and flat (powers of two from 2 MiB): (device image, pinned staging image or
+        None) viewed as `shape`.  A new image size allocates only when it is larger than every one before it."""
+        torch = _torch()
+        n = 1
+        for d in shape:
+            n *= int(d)
+        slot = self._static.setdefault(("in", index), {"cap": 0, "dev": None, "pin": None, "ev": None, "events": None})
+        if n > slot["cap"] or (pinned and slot["pin"] is None):
+            cap = max(slot["cap"], 2 << 20)
+            while cap < n:
+                cap <<= 1
+            # (whatever still reads the old buffers: this is the rare path)
+            torch.cuda.synchronize(self.device)
+            slot["dev"] = torch.empty((cap,), dtype=torch.uint8, device="cuda:%d" % self.device)
+            slot["pin"] = torch.empty((cap,), dtype=torch.uint8).pin_memory() if pinned or slot["pin"] is not None else None
+            slot["cap"] = cap
+        dev_in = slot["dev"][:n].view(shape)
+        pin_in = slot["pin"][:n].view(shape) if slot["pin"] is not None else None
+        return slot, dev_in, pin_in
 
     def forward_cached(self, images):
         """Serving form of `forward`: `images` (uint8 numpy array or tensor [B,H,W,3]) is copied
-        into a persistent device buffer and the outputs live in persistent buffers too, so every
-        call with the same shape presents the same pointers to ssd_forward (a hipGraph replay with
-        option graph = 1).  The returned tensors are overwritten by the next call: consume (e.g.
-        `.cpu()`) before calling again."""
+        into a persistent device buffer and the outputs live in persistent buffers too (one set per batch size), so
+        steady-state calls allocate nothing.  The returned tensors are overwritten by the next call with this batch
+        size: consume (e.g. `.cpu()`) before calling again."""
         torch = _torch()
         if isinstance(images, np.ndarray):
             images = torch.from_numpy(np.ascontiguousarray(images))
         if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[3] != 3:
             raise ValueError("images must be uint8 with shape [B,H,W,3]")
         with self.lock:
-            slot = self._slot(tuple(images.shape))
+            slot, dev_in, _ = self._in_slot(tuple(images.shape))
+            out = self._out_slot(int(images.shape[0]))
             cur = torch.cuda.current_stream()
-            if slot.get("ev") is not None:      # another thread's stream may still be using these buffers
+            if slot["ev"] is not None:          # another thread's stream may still be using these buffers
                 cur.wait_event(slot["ev"])
             else:
                 slot["ev"] = torch.cuda.Event()
-            slot["dev_in"].copy_(images, non_blocking=True)
-            out = self.forward(slot["dev_in"], records=slot["block"])
+            dev_in.copy_(images, non_blocking=True)
+            res = self.forward(dev_in, records=out["block"])
             slot["ev"].record(cur)
-            return out
+            return res
 
     def detect_host(self, images):
         """The boundary's own form (inference/detector.py:51-52: a host ndarray in, numpy out on every call), at its best
         case: host uint8 [B,H,W,3] -> pinned staging -> HBM, forward, ONE device-to-host copy of the packed outputs into
         pinned memory, one stream synchronisation.  Returns numpy VIEWS of that pinned block (boxes, labels, scores,
-        num_boxes), valid until the next call with this shape: copy or reduce them before calling again."""
+        num_boxes), valid until the next call with this batch size: copy or reduce them before calling again."""
         torch = _torch()
         images = np.asarray(images)
         if images.dtype != np.uint8 or images.ndim != 4 or images.shape[3] != 3:
             raise ValueError("images must be a uint8 array of shape [B, height, width, 3]")
         with self.lock:
-            slot = self._slot(tuple(images.shape))
             src = np.ascontiguousarray(images)
             B, H, W, _ = src.shape
+            slot = self._out_slot(B)
             # ssd_forward_host: staging copy + upload in pieces (one C loop) and the forward, on the current stream.  One image:
             # post_pack_kernel writes its 48 KB record into the pinned block itself (16-byte rows over PCIe) -- no
             # device-to-host copy behind the forward.  (Records are 48 004 bytes: those of further images are not 16-byte
@@ -492,11 +512,13 @@ class Engine:
 
     def detect_one(self, image, score_threshold):
         """inference/detector.py:33-58 for one host frame [H,W,3] as ONE library call (ssd_detect_host): staging copy + upload,
-        forward, the wait, and the score filter in C.  Returns fresh arrays boxes [n,4], labels [n], scores [n]."""
+        forward, the wait, and the score filter in C.  Returns fresh arrays boxes [n,4], labels [n], scores [n].  Nothing
+        here depends on the frame's size: the pinned record and the scratch arrays are the engine's, the layer plan of the
+        network shape the frame resizes to is the library's (kept per shape, ssd_hip.h)."""
         torch = _torch()
         H, W, _ = image.shape
         with self.lock:
-            slot = self._slot((1, H, W, 3))
+            slot = self._out_slot(1)
             src = np.ascontiguousarray(image)
             sc = slot.get("one")
             if sc is None:
@@ -509,25 +531,24 @@ class Engine:
             return sc[0][:n].copy(), sc[1][:n].copy(), sc[2][:n].copy()
 
     def detect_stream(self, batches):
-        """Host-fed steady-state serving: an iterable of host uint8 arrays [B,H,W,3] -> a generator of (boxes, labels,
-        scores, num_boxes) numpy arrays, in order.  Two sets of buffers and two copy streams: the host-to-device copy of
-        batch k+1 and the device-to-host copy of the packed outputs of batch k-1 run under the compute of batch k, so the
-        host feed costs (almost) nothing against frames already resident in HBM.  Results are bit-identical to
-        detect_host on the same batches (same kernels, same order)."""
+        """Host-fed steady-state serving: an iterable of host uint8 arrays [B,H,W,3] (any mix of sizes) -> a generator of
+        (boxes, labels, scores, num_boxes) numpy arrays, in order.  Two sets of buffers and two copy streams: the
+        host-to-device copy of batch k+1 and the device-to-host copy of the packed outputs of batch k-1 run under the
+        compute of batch k, so the host feed costs (almost) nothing against frames already resident in HBM.  Results are
+        bit-identical to detect_host on the same batches (same kernels, same order)."""
         torch = _torch()
         dev = torch.device("cuda", self.device)
         if self._copy_streams is None:
             self._copy_streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
         s_in, s_out = self._copy_streams
         s_c = torch.cuda.current_stream(dev)
-        ev = None
-        pending = None                       # (slot, B) of the batch whose outputs are still on their way
+        pending = None                       # (out slot, events) of the batch whose outputs are still on their way
         k = 0
 
         def collect(p):
-            slot, B, e = p
+            oslot, e = p
             e["d2h"].synchronize()
-            return tuple(np.array(v) for v in slot["host"])
+            return tuple(np.array(v) for v in oslot["host"])
 
         for images in batches:
             images = np.asarray(images)
@@ -535,32 +556,45 @@ class Engine:
                 raise ValueError("every batch must be a uint8 array of shape [B, height, width, 3]")
             key = tuple(images.shape)
             j = k & 1
-            slot = self._slot(key, index=1 + j)
-            e = slot.setdefault("events", None)
+            islot, dev_in, pin_in = self._in_slot(key, index=1 + j, pinned=True)
+            oslot = self._out_slot(key[0], index=1 + j)
+            e = islot["events"]
             if e is None:
-                e = slot["events"] = {n: torch.cuda.Event() for n in ("h2d", "cmp", "d2h")}
+                e = islot["events"] = {n: torch.cuda.Event() for n in ("h2d", "cmp", "d2h")}
                 for n in e:
                     e[n].record(s_c)
             e["h2d"].synchronize()           # the staging buffer's previous upload has left it
-            e["d2h"].synchronize()           # ... and the previous results of this slot have been collected below
-            np.copyto(slot["pin_in_np"], images)
+            e["d2h"].synchronize()           # ... and the previous results of this set have been collected below
+            np.copyto(pin_in.numpy(), images)
             with torch.cuda.stream(s_in):
                 s_in.wait_event(e["cmp"])    # the forward that read this device image two batches ago is over
-                slot["dev_in"].copy_(slot["pin_in"], non_blocking=True)
+                dev_in.copy_(pin_in, non_blocking=True)
                 e["h2d"].record(s_in)
             s_c.wait_event(e["h2d"])
-            self.forward(slot["dev_in"], records=slot["block"])
+            self.forward(dev_in, records=oslot["block"])
             e["cmp"].record(s_c)
             with torch.cuda.stream(s_out):
                 s_out.wait_event(e["cmp"])
-                slot["pin_out"].copy_(slot["block"], non_blocking=True)
+                oslot["pin_out"].copy_(oslot["block"], non_blocking=True)
                 e["d2h"].record(s_out)
             if pending is not None:
                 yield collect(pending)
-            pending = (slot, key[0], e)
+            pending = (oslot, e)
             k += 1
         if pending is not None:
             yield collect(pending)
+
+    def plan_cache_stats(self):
+        """ssd_plan_cache_stats: the library keeps one layer plan per network shape this engine has served."""
+        v = (ctypes.c_int64 * 8)()
+        with self.lock:
+            check(lib().ssd_plan_cache_stats(self._h, v))
+        return {"plans": v[0], "arena_bytes": v[1], "budget_bytes": v[2], "hits": v[3], "misses": v[4], "evictions": v[5],
+                "last_network_shape": [v[6], v[7]]}
+
+    def plan_cache_clear(self):
+        with self.lock:
+            check(lib().ssd_plan_cache_clear(self._h))
 
     def get_tensor(self, name):
         """Retained intermediate of the last forward as a numpy array [B,H,W,C]."""

@@ -23,6 +23,18 @@ def run(args):
     return json.loads(lines[0])
 
 
+def check_scaling_keys(res, world):
+    """The N > 1 line explains itself: every rank's own step time, compute and all-gather per rank from the
+    marked extra steps, the hardware-queue note."""
+    for k in ("per_rank_ms_per_step", "per_rank_compute_ms_per_step", "per_rank_allgather_ms_per_step"):
+        assert isinstance(res[k], list) and len(res[k]) == world and all(v >= 0 for v in res[k]), k
+    assert abs(max(res["per_rank_ms_per_step"]) - res["ms_per_step"]) < 1e-6 * max(1.0, res["ms_per_step"])
+    assert res["compute_ms_per_step"] == max(res["per_rank_compute_ms_per_step"])
+    assert res["allgather_ms_per_step"] == max(res["per_rank_allgather_ms_per_step"])
+    assert res["allgather_ms_per_step_min_over_ranks"] == min(res["per_rank_allgather_ms_per_step"])
+    assert res["allgather_bytes_per_rank"] > 0 and "engine_first_forward_before_process_group" in res and "hardware_queue_note" in res
+
+
 @pytest.mark.parametrize("extra,total,shards", [([], 6, [[0, 3], [3, 6]]), (["--global-batch", "5"], 5, [[0, 3], [3, 5]])])
 def test_self_launch_world2_gloo(extra, total, shards):
     res = run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "3"] + extra)
@@ -31,6 +43,7 @@ def test_self_launch_world2_gloo(extra, total, shards):
     assert res["steps"] == 2 and res["warmup"] == 1 and res["scaling"] == "weak"
     assert res["value"] > 0 and abs(res["value"] - total * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"]
     assert res["precision"] == "f32" and res["dtype"] == "f32"          # the reference's arithmetic is the headline
+    check_scaling_keys(res, 2)
 
 
 def test_self_launch_world8_gloo_uneven_global_batch():
@@ -46,6 +59,8 @@ def test_self_launch_world8_gloo_uneven_global_batch():
         lo += n
     assert res["config"]["global_batch"] == 250 and res["config"]["shards"] == exp and lo == 250
     assert res["value"] > 0 and abs(res["value"] - 250 * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"]
+    check_scaling_keys(res, 8)
+    assert res["allgather_bytes_per_rank"] == 32 * 48004          # rank 0's shard of the 250 images
     even = run(["--gpus", "8", "--steps", "1", "--warmup", "0", "--batch", "4"])
     assert even["config"]["global_batch"] == 32 and even["config"]["shards"][7] == [28, 32] and even["ranks_seen"] == list(range(8))
 
@@ -61,6 +76,7 @@ def test_force_dist_runs_the_collective_path_at_world_size_1():
     res = run(["--steps", "2", "--warmup", "1", "--batch", "3", "--force-dist"])
     assert res["n_gpus"] == 1 and res["ranks_seen"] == [0] and res["collective_path"] is True
     assert res["config"]["global_batch"] == 3 and res["config"]["shards"] == [[0, 3]]
+    check_scaling_keys(res, 1)
     plain = run(["--steps", "2", "--warmup", "1", "--batch", "3"])
     assert plain["collective_path"] is False
 

@@ -59,7 +59,8 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", ["128", "64", "20", "21", "22", "23", "24", "25", "26", "27", "28", "29", "30", "31", "32"])
+# (28, 29, 31, 32 exist in the diagnostics build only; the shipped library refuses them, test_gpu_multishape.py)
+@pytest.mark.parametrize("tile", ["128", "64", "20", "21", "22", "23", "24", "25", "26", "27", "30"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
 def test_conv2d(cuda, ssd, oracle_ops, case, tile, libopt):
     # the library picks 64x64 tiles for small problems and 128x128 for large ones: pin each

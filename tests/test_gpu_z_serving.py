@@ -69,6 +69,76 @@ def test_two_threads_share_one_detector(cuda, ssd):
         assert all(np.array_equal(a, b) for a, b in zip(r, ref))
 
 
+@pytest.mark.parametrize("fence", [0, 1])
+def test_forwards_alternating_between_two_streams_without_host_sync(cuda, ssd, fence):
+    """One Engine, forwards enqueued alternately on two NON-BLOCKING streams with no host synchronisation in between: the
+    library's own ordering (ev_last recorded behind every forward of a handle that has seen two streams, the next forward
+    waits for it) is all that keeps forward k + 1 from overwriting the arena forward k is still reading.  Same shape every
+    time (one plan, one arena); unrelated long work sits on the other stream in front of its next forward; with the default
+    ordering events and after ssd_set_option(event_fence)."""
+    W = ssd.synthetic_weights(TINY_PARAMS, seed=6, logits_bias=-3.0)
+    eng = ssd.Engine(dict(TINY_PARAMS), W)
+    if fence:
+        eng.set_option("event_fence", 1)
+    rng = np.random.default_rng(31)
+    imgs = [cuda.from_numpy(rng.integers(0, 256, (4, 128, 256, 3), dtype=np.uint8)).cuda() for _ in range(6)]
+    want = []
+    for im in imgs:                                  # single stream, synchronised: the reference results
+        want.append([t.cpu().numpy() for t in eng.forward(im)])
+    cuda.cuda.synchronize()
+    assert sum(int(w[3].sum()) for w in want) > 30
+    s = [cuda.cuda.Stream(), cuda.cuda.Stream()]
+    big = cuda.randn(4096, 4096, device="cuda")
+    recs = [eng.new_records(4, imgs[0].device) for _ in range(24)]
+    cuda.cuda.synchronize()
+    outs = []
+    for k in range(24):
+        st = s[k & 1]
+        with cuda.cuda.stream(st):
+            if k % 5 == 2:                           # unrelated long work queued on this stream in front of the forward
+                for _ in range(4):
+                    big = big @ big * 1e-4
+            outs.append(eng.forward(imgs[k % 6], records=recs[k]))
+    cuda.cuda.synchronize()                          # the first host wait
+    for k, o in enumerate(outs):
+        for a, b in zip(o, want[k % 6]):
+            assert np.array_equal(a.cpu().numpy(), b), (k, fence)
+    eng.close()
+
+
+def test_forward_on_a_capturing_stream_after_another_stream_is_refused(cuda, ssd):
+    """A handle whose previous forward ran on another stream cannot be captured into a caller's graph (the wait for that
+    forward's event would tie the graph to work outside it): the library says so instead of surfacing a HIP capture error
+    mid-enqueue; on a handle that only ever ran on the capturing stream, capture works (option streams = 1)."""
+    W = ssd.synthetic_weights(TINY_PARAMS, seed=6, logits_bias=-3.0)
+    eng = ssd.Engine(dict(TINY_PARAMS), W)
+    eng.set_option("streams", 1)
+    img = cuda.from_numpy(np.random.default_rng(2).integers(0, 256, (1, 128, 128, 3), dtype=np.uint8)).cuda()
+    want = [t.cpu().numpy() for t in eng.forward(img)]
+    s1, s2 = cuda.cuda.Stream(), cuda.cuda.Stream()
+    rec = eng.new_records(1, img.device)
+    with cuda.cuda.stream(s1):
+        eng.forward(img, records=rec)
+    with cuda.cuda.stream(s2):
+        eng.forward(img, records=rec)                # the handle has now seen two streams
+    with cuda.cuda.stream(s1):
+        eng.forward(img, records=rec)                # the previous forward is on s1
+    cuda.cuda.synchronize()
+    g = cuda.cuda.CUDAGraph()
+    refused = False
+    with cuda.cuda.graph(g, stream=s2):
+        try:
+            eng.forward(img, records=rec)
+        except ssd.SsdError as e:
+            refused = "capturing" in str(e)
+    assert refused
+    cuda.cuda.synchronize()
+    # ... and nothing is broken afterwards
+    got = [t.cpu().numpy() for t in eng.forward(img)]
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    eng.close()
+
+
 def test_detect_stream_equals_synchronous_calls_in_order(cuda, ssd):
     """Detector.detect_stream (two pinned staging buffers, copy streams: H2D of batch k+1 and D2H of batch k-1 under the
     compute of batch k) returns, in order, exactly what detect_batch returns for each batch -- including across a change of
@@ -171,6 +241,14 @@ def test_bench_collective_path_on_rccl_world_1(cuda):
     assert forced["n_gpus"] == 1 and forced["ranks_seen"] == [0] and forced["config"]["shards"] == [[0, 32]]
     assert forced["config"]["detections_per_image"] == plain["config"]["detections_per_image"] > 50
     assert forced["value"] > 0 and plain["value"] > 0
+    # the line explains a scaling loss by itself: per-rank step time, compute / all-gather split from events, the queue note
+    for line in (plain, forced):
+        for k in ("per_rank_ms_per_step", "per_rank_compute_ms_per_step", "per_rank_allgather_ms_per_step"):
+            assert isinstance(line[k], list) and len(line[k]) == 1, k
+        assert line["compute_ms_per_step"] > 0 and line["allgather_ms_per_step"] >= 0
+        assert line["compute_ms_per_step"] + line["allgather_ms_per_step"] < 1.5 * line["ms_per_step"]
+    assert forced["engine_first_forward_before_process_group"] is True and plain["engine_first_forward_before_process_group"] is False
+    assert forced["allgather_bytes_per_rank"] == 32 * 48004
     # the form the driver uses for N > 1, at N = 1: torch.distributed.run sets WORLD_SIZE=1
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"] + common[4:],

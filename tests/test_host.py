@@ -171,13 +171,22 @@ def test_library_reads_one_environment_variable_and_options_go_through_the_abi(s
                  b"SSD_LEVEL_SPLIT", b"SSD_BACKBONE_SPLIT", b"SSD_LATERAL_SPLIT", b"SSD_IGEMM_96"):
         assert gone not in blob, gone
     unset = -2 ** 31
-    for key in ("streams", "h2d_chunks", "front_fuse", "fuse_dw", "backbone_split", "event_fence", "igemm_tile", "igemm16", "igemm_96", "igemm_lat",
-                "igemm_deep64", "lateral_split", "fpn_group", "fpn_p7_group", "fpn_early_lat", "nsub", "nms_fast_max", "debug_sync"):
+    for key in ("streams", "h2d_chunks", "front_fuse", "fuse_dw", "backbone_split", "event_fence", "plan_cache_mb", "igemm_tile", "igemm16", "igemm_96",
+                "igemm_lat", "igemm_deep64", "lateral_split", "fpn_group", "fpn_p7_group", "fpn_early_lat", "nsub", "nms_fast_max", "debug_sync"):
+        v = 64 if key == "igemm_tile" else 3
         assert ssd.get_option(key) == unset
-        ssd.set_option(key, 3)
-        assert ssd.get_option(key) == 3
+        ssd.set_option(key, v)
+        assert ssd.get_option(key) == v
         ssd.set_option(key, unset)
         assert ssd.get_option(key) == unset
+    # values the build does not implement are refused, not ignored (igemm_tile 28, 29, 31, 32: diagnostics build only)
+    for bad in (3, 28, 29, 31, 32, 96, 256):
+        with pytest.raises(ssd.SsdError, match="igemm_tile"):
+            ssd.set_option("igemm_tile", bad)
+    for good in (128, 64, 20, 27, 30, 0, unset):
+        ssd.set_option("igemm_tile", good)
+    with pytest.raises(ssd.SsdError, match="plan_cache_mb"):
+        ssd.set_option("plan_cache_mb", -5)
     with pytest.raises(ssd.SsdError, match="unknown option"):
         ssd.set_option("no_such_switch", 1)
     # the schedule experiments of rounds 1-4 are out of the shipped library (scripts/experiments/README.md)
