@@ -305,8 +305,11 @@ __device__ __forceinline__ v4f wave_broadcast_box(v4f mine, bool found)
 // Greedy NMS of one (image, class) list by ONE wavefront with R candidates per lane in registers.  keys and boxes are
 // immutable; liveness is one bit per register slot.  (A version that zeroed key[r] under `key == best || iou > thr` was
 // miscompiled by hipcc 7.2: the kill of the IoU branch was dropped -- keep this form branch-free.)
+// kept0: boxes an earlier step already kept for this list (an exact prefix of its greedy NMS; this call continues behind them);
+// kb (LDS, or null): receives the boxes kept HERE, kb[0] = the first new one.
 template <int R>
-__device__ __forceinline__ int nms_one_wave(const PostArgs &p, const u64 *keys, const float *dec, int n, int lane, float *ob, float *os)
+__device__ __forceinline__ int nms_one_wave(const PostArgs &p, const u64 *keys, const float *dec, int n, int lane, float *ob, float *os,
+                                            int kept0 = 0, v4f *kb = nullptr)
 {
     u64 key[R];
     v4f box[R];
@@ -320,7 +323,7 @@ __device__ __forceinline__ int nms_one_wave(const PostArgs &p, const u64 *keys, 
         box[r] = *(const v4f *)(dec + (long long)(ok ? anchor : 0u) * 4);
         alive |= ok ? (1u << r) : 0u;
     }
-    int kept = 0;
+    int kept = kept0;
     while (kept < p.max_per_class) {
         u64 best = 0;
 #pragma unroll
@@ -336,6 +339,7 @@ __device__ __forceinline__ int nms_one_wave(const PostArgs &p, const u64 *keys, 
         if (lane == 0) {
             *(v4f *)(ob + kept * 4) = wb;
             os[kept] = __uint_as_float((unsigned)(best >> 32));
+            if (kb) kb[kept - kept0] = wb;
         }
         ++kept;
         unsigned kill = 0;
@@ -354,7 +358,7 @@ __device__ __forceinline__ int nms_one_wave(const PostArgs &p, const u64 *keys, 
 // (double-buffered by round parity).  Returns the number of boxes kept (block-uniform).
 template <int NT>
 __device__ __forceinline__ int nms_block(const PostArgs &p, const u64 *keys, const float *dec, int n, int tid, float *ob, float *os,
-                                         u64 (*wbest)[NT / 64], v4f (*wbox)[NT / 64])
+                                         u64 (*wbest)[NT / 64], v4f (*wbox)[NT / 64], int kept0 = 0)
 {
     const int lane = tid & 63, wave = tid >> 6;
     u64 key[NMS_R];
@@ -369,7 +373,7 @@ __device__ __forceinline__ int nms_block(const PostArgs &p, const u64 *keys, con
         box[r] = *(const v4f *)(dec + (long long)(ok ? anchor : 0u) * 4);
         alive |= ok ? (1u << r) : 0u;
     }
-    int kept = 0;
+    int kept = kept0;
     while (kept < p.max_per_class) {        // uniform trip count: `best` is block-uniform
         u64 best = 0;
 #pragma unroll
@@ -419,7 +423,7 @@ __device__ __forceinline__ int nms_block(const PostArgs &p, const u64 *keys, con
 // then as many rounds as the class has objects).  Thread t revisits only the slots it wrote itself.
 template <int NT>
 __device__ __forceinline__ int nms_global(const PostArgs &p, u64 *keys, const float *dec, int n, int tid, float *ob, float *os,
-                                          u64 (*wbest)[NT / 64])
+                                          u64 (*wbest)[NT / 64], int kept0 = 0)
 {
     const int lane = tid & 63, wave = tid >> 6;
     u64 best = 0;
@@ -427,7 +431,7 @@ __device__ __forceinline__ int nms_global(const PostArgs &p, u64 *keys, const fl
         const u64 k = keys[i];
         best = k > best ? k : best;
     }
-    int kept = 0;
+    int kept = kept0;
     while (kept < p.max_per_class) {        // uniform trip count: `best` is block-uniform after the reduction
         best = wave_max_u64(best);
         const int buf = kept & 1;
@@ -460,6 +464,67 @@ __device__ __forceinline__ int nms_global(const PostArgs &p, u64 *keys, const fl
     return kept;
 }
 
+// The pass that lets a long list go on behind a top-score trial (post_nms_kernel): drops the trial's candidates (score bin >= cut)
+// and every candidate one of the trial's kept boxes kb[0 .. nkb) suppresses, and compacts the rest in place; *new_n (LDS, zeroed by
+// the caller) receives the new length.  Chunks of NMS_MID x 16 keys through registers: a chunk's loads complete (barrier) before
+// any survivor is written, and a survivor's slot lies below the chunk's end, so nothing unread is overwritten.  (Register budget:
+// the kernel keeps two waves per SIMD at 226 VGPRs with 16 keys per thread and chunk inlined here; 32 keys, or this pass behind a
+// real call, or a loop that repeats the step, each took it past 256.)
+__device__ __forceinline__ void nms_suppress_compact(u64 *keys, const float *dec, int n, int tid, const v4f *kb, int nkb, int cut, unsigned lo_bits,
+                                                  int shift, float iou_thr, int *new_n)
+{
+    constexpr int KR = 16;
+    const int lane = tid & 63;
+#pragma unroll 1
+    for (int base = 0; base < n; base += NMS_MID * KR) {
+        u64 ck[KR];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const int i = base + tid + NMS_MID * r;
+            ck[r] = i < n ? keys[i] : 0ull;
+        }
+        __syncthreads();
+#pragma unroll 1                    // (one group of NMS_R boxes in registers at a time)
+        for (int g = 0; g < KR / NMS_R; ++g) {
+            u64 kg[NMS_R];              // keys g * NMS_R .. of the chunk, picked with compile-time register indices (no scratch)
+#pragma unroll
+            for (int r = 0; r < NMS_R; ++r) {
+                u64 v = ck[r];
+#pragma unroll
+                for (int q = 1; q < KR / NMS_R; ++q) v = g == q ? ck[q * NMS_R + r] : v;
+                kg[r] = v;
+            }
+            v4f bx[NMS_R];
+            unsigned rem = 0;
+#pragma unroll
+            for (int r = 0; r < NMS_R; ++r) {
+                const u64 kk = kg[r];
+                const bool below = kk != 0ull && (int)(((unsigned)(kk >> 32) - lo_bits) >> shift) < cut;
+                const unsigned anchor = below ? 0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFu) : 0u;
+                bx[r] = *(const v4f *)(dec + (long long)anchor * 4);
+                rem |= below ? (1u << r) : 0u;
+            }
+            unsigned sup = 0;
+            for (int j = 0; j < nkb; ++j) {
+                const v4f wb = kb[j];
+#pragma unroll
+                for (int r = 0; r < NMS_R; ++r) sup |= iou_greater(bx[r], wb, iou_thr) ? (1u << r) : 0u;
+            }
+            const unsigned live = rem & ~sup;
+#pragma unroll
+            for (int r = 0; r < NMS_R; ++r) {
+                const bool keepit = (live >> r) & 1u;
+                const unsigned long long m = __ballot(keepit);
+                int wbase = 0;
+                if (lane == 0 && m) wbase = atomicAdd(new_n, (int)__popcll(m));
+                wbase = __builtin_amdgcn_readfirstlane(wbase);
+                if (keepit) keys[wbase + (int)__popcll(m & ((1ull << lane) - 1ull))] = kg[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // K9c, one block of NMS_MID threads per (image, class) pair.
 //   n <= fast_max (64 * NMS_R)      wave 0 alone, everything in registers, no barrier (the other waves leave at once)
 //   n <= mid_max (NMS_MID * NMS_R)  the block's four waves (nms_block)
@@ -484,20 +549,30 @@ __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
         if (tid == 0) p.cls_counts[bc] = kept;
         return;
     }
-    if (n <= p.fast_max) {                  // block-uniform
-        if (wave != 0) return;
-        int kept = 0;
-        if (n > 0) kept = nms_one_wave<NMS_R>(p, keys, dec, n, lane, ob, os);
-        if (lane == 0) p.cls_counts[bc] = kept;
-        return;
-    }
+    int K = 0;                              // boxes kept so far (block-uniform): an exact prefix of the list's greedy NMS
+    if (n > p.fast_max) {                   // block-uniform
     // A long list: greedy NMS consumes candidates in descending score order and stops at max_per_class kept boxes, so first
     // try the TOP scores alone -- a score histogram picks the largest score cut that leaves at most 64 * NMS_R candidates,
     // those are compacted into LDS and wave 0 runs the one-wave rounds on them.  If that keeps max_per_class boxes the result
     // is exactly the full list's (every candidate below the cut has a strictly smaller key than every one above it, and the
-    // greedy order never reached them); otherwise -- massive ties or massive suppression -- the full list is processed below.
+    // greedy order never reached them).
     // (Bench frames: ONE class holds 4 085 of a frame's 6 503 candidates; on the 1 024-thread in-register kernel its 25 rounds
     //  took 98 us -- 8 IoU tests x 16 waves on one CU per round -- and decided the post-processing's time.)
+    //
+    // Otherwise -- massive suppression: the top scores all sit in a few clusters -- the trial's K kept boxes are still an EXACT
+    // PREFIX of the list's greedy NMS: every candidate above the cut was either kept or suppressed, and what greedy NMS does next
+    // is take the candidates below the cut in descending order, each suppressed by any box kept before it.  Lists beyond the four
+    // waves' registers go on from there instead of starting over (round 6): ONE pass over the list drops the candidates of the
+    // trial and those the new kept boxes suppress (the keys go through registers in chunks of NMS_MID x 32 -- every load of a chunk
+    // in flight together -- and the survivors are compacted in place), and the exact rounds below finish the shorter list from
+    // kept0 = K: the clustered lists that used to cost one dependent pass over global memory PER ROUND (8 160 candidates in
+    // 24 clusters: 389 us; 36 000: 1.4 ms) settle after one trial and one pass.  Where no trial ran (massive ties; more than
+    // NMS_KB boxes per class) the rounds below run on the whole list as before.
+    // (Repeating the step on the shorter list -- a loop around this block -- cost the kernel its second wave per SIMD: 342
+    //  registers against 227; one step covers the clustered case the path exists for.)
+    constexpr int NMS_KB = 64;
+    __shared__ v4f kb[NMS_KB];
+    __shared__ int new_n;
     {
         constexpr int TCAP = 64 * NMS_R, TCAP_S = 64 * 2, NBIN = 2048;
         __shared__ unsigned hist[NBIN];
@@ -559,7 +634,11 @@ __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
         }
         __syncthreads();
         // two trials: the top <= 128 candidates with 2 per lane (a round costs a quarter of an 8-per-lane round: on the bench
-        // frames the class that holds two thirds of a frame's candidates fills its 25 boxes from them), then the top <= 512
+        // frames the class that holds two thirds of a frame's candidates fills its 25 boxes from them), then the top <= 512.
+        // A list the block's registers hold (n <= mid_max) only runs a trial that can fill the class: its exact rounds below
+        // start over anyway; a longer list runs every trial, whose kept boxes it goes on from.
+        const bool progressive = n > p.mid_max && p.max_per_class <= NMS_KB;
+        int ran_cb = -1;                            // the cut of the last trial that ran (block-uniform), -1: none
 #pragma unroll 1
         for (int k = 0; k < 2; ++k) {
             const int cb = cut_bin[k];
@@ -580,12 +659,15 @@ __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
             }
             __syncthreads();
             const int nn = chunk_n;
-            if (nn >= p.max_per_class && cb > 0) {      // (fewer than the cap can never fill it; cb == 0: the cut kept everything)
+            // (fewer than the boxes still missing can never fill the class; cb == 0: the cut kept everything)
+            if (cb > 0 && nn > 0 && (nn >= p.max_per_class - K || progressive)) {
                 if (wave == 0) {
-                    const int kept = k == 0 ? nms_one_wave<2>(p, chunk, dec, nn, lane, ob, os) : nms_one_wave<NMS_R>(p, chunk, dec, nn, lane, ob, os);
+                    const int kept = k == 0 ? nms_one_wave<2>(p, chunk, dec, nn, lane, ob, os, K, kb)
+                                            : nms_one_wave<NMS_R>(p, chunk, dec, nn, lane, ob, os, K, kb);
                     if (lane == 0) trial_kept = kept;
                 }
                 __syncthreads();
+                ran_cb = cb;
                 if (trial_kept >= p.max_per_class) {    // block-uniform
                     if (tid == 0) p.cls_counts[bc] = trial_kept;
                     return;
@@ -593,11 +675,30 @@ __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
             }
             __syncthreads();
         }
+        if (progressive && ran_cb >= 0) {
+        // ---- the list goes on behind the trial: drop the trial's candidates (bin >= ran_cb) and everything one of its kept
+        // boxes kb[0 .. Kt - K) suppresses, compact the rest in place
+        const int Kt = trial_kept;
+        if (tid == 0) new_n = 0;
+        __syncthreads();
+        nms_suppress_compact(keys, dec, n, tid, kb, Kt - K, ran_cb, lo_bits, shift, p.iou_thr, &new_n);
+        n = new_n;                          // (the survivors' writes are visible to the block: the pass ends in a barrier)
+        K = Kt;
+        __syncthreads();
+        }
     }
+    }
+    // the exact rounds, from K kept boxes on: one wave's registers, the block's, or the list in global memory
     // (the 1 024-thread kernels that took such lists from a work list are gone: most forwards have none, and their launch --
     //  144 blocks that look at an empty list and leave -- cost its 5 us all the same)
-    const int kept = n > p.mid_max ? nms_global<NMS_MID>(p, keys, dec, n, tid, ob, os, wbest)
-                                   : nms_block<NMS_MID>(p, keys, dec, n, tid, ob, os, wbest, wbox);
+    int kept = K;
+    if (n <= p.fast_max) {                  // block-uniform
+        if (wave != 0) return;
+        if (n > 0) kept = nms_one_wave<NMS_R>(p, keys, dec, n, lane, ob, os, K);
+    } else {
+        kept = n > p.mid_max ? nms_global<NMS_MID>(p, keys, dec, n, tid, ob, os, wbest, K)
+                             : nms_block<NMS_MID>(p, keys, dec, n, tid, ob, os, wbest, wbox, K);
+    }
     if (tid == 0) p.cls_counts[bc] = kept;
 }
 

@@ -311,6 +311,12 @@ static int finalize_shufflenet(ssd_handle *h)
             std::string u = std::string(base) + "/unit_" + std::to_string(j);
             cw = ConvW();
             SSDCHK(load_conv(h, u + "/conv1x1_before/weights", u + "/conv1x1_before/batch_norm", 1, D, D, cw)); h->pw.push_back(cw);
+            // this layer exists ONLY as the gathering kernel (sn_pw.hip: concat_shuffle_split folded into its loads): a width that
+            // kernel does not take must fail HERE, with the layer's name, not at the first forward (the size-dependent limits -- 2 GiB
+            // per stage allocation -- are select_plans' sub-batch split)
+            if (!pw_gather_supports(cw.CinP, cw.CoutP, 1, cw.CinP * 4, cw.CinP * 4, cw.CoutP * 4))
+                return ssd_fail(SSD_ERR_INVALID, "ssd_finalize: " + u + "/conv1x1_before (" + std::to_string(D) + " -> " + std::to_string(D) +
+                                                 " channels) is not a shape of the gathering 1x1 kernel (sn_pw.hip: 32 <= padded input channels <= 512)");
             d = DwW();
             SSDCHK(load_dw(h, u + "/depthwise", "batch_norm", D, d)); h->dw.push_back(d);
             cw = ConvW();

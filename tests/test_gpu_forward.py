@@ -336,9 +336,9 @@ def test_missing_weight_fails_loudly(cuda, ssd):
 def test_batch_independence_full_batch(cuda, ssd, oracle_graph):
     """BASELINE config 5 shard size (32 images / GPU) at 640x896: every image of a batch
     gives exactly the result of its own batch-1 run, and permuting the batch permutes the
-    outputs (the path has no cross-image term).  Two images of the batch -- one per backbone
-    chain of the serving plan (128x128 tiles, two half-batch chains) -- are also compared with
-    the oracle directly: outputs and every retained stage, bit for bit."""
+    outputs (the path has no cross-image term).  Eight images of the batch -- four per backbone
+    chain of the serving plan (128x128 tiles, two half-batch chains), first and last of each --
+    are also compared with the oracle directly: outputs and every retained stage, bit for bit."""
     params = ssd.load_config(os.path.join(HERE, "golden", "config_mobilenet.json"))
     Wt = ssd.synthetic_weights(params, seed=0, logits_bias=-4.0)
     eng = ssd.Engine(params, Wt)
@@ -355,12 +355,14 @@ def test_batch_independence_full_batch(cuda, ssd, oracle_graph):
         assert np.array_equal(a[17:18], b)
     assert full[3].min() > 0
     # the serving plan against the oracle itself (not only against its own batch-1 run): the batch is forwarded again (the
-    # batch-1 run above re-planned the arena) and images 3 (first chain) and 29 (second chain) are checked
+    # batch-1 run above ran another plan; its arena is its own) and images 0, 3, 9, 15 (first chain) and 16, 22, 29, 31 (second
+    # chain) are checked
+    assert eng.plan_cache_stats()["plans"] == 2
     full2 = [t.cpu().numpy() for t in eng.forward(d)]
     for a, b in zip(full, full2):
         assert np.array_equal(a, b)
     stages = {n: eng.get_tensor(n) for n in STAGES}
-    for i in (3, 29):
+    for i in (0, 3, 9, 15, 16, 22, 29, 31):
         keep = {}
         ref = oracle_graph.forward(imgs[i:i + 1], Wt, params, keep)
         for a, k in zip(full2, ("boxes", "labels", "scores", "num_boxes")):

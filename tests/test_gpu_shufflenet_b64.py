@@ -34,13 +34,14 @@ def test_shufflenet_640_batch64(cuda, ssd, oracle_graph, precision):
     permd = [t.cpu().numpy() for t in eng.forward(d[cuda.from_numpy(perm).cuda()].contiguous())]
     for a, b in zip(full, permd):
         assert np.array_equal(a[perm], b)
-    # the CPU oracle on two images of the batch (first and last)
-    pick = [0, B - 1]
+    # the CPU oracle on eight images of the batch in mode f32 (four per half-batch backbone chain, first and last of each), two in
+    # the opt-in mode
+    pick = [0, 9, 20, 31, 32, 41, 52, B - 1] if precision == "f32" else [0, B - 1]
     keep = {}
     ref = oracle_graph.forward(imgs[pick], Wt, params, keep)
     got = [t[pick] for t in full]
     if precision == "f32":
-        compare_exact(got, ref, "shufflenet B=64 images 0/63 (f32)")
+        compare_exact(got, ref, "shufflenet B=64 images 0/9/20/31/32/41/52/63 (f32)")
         assert np.array_equal(got[0], ref["boxes"]) and np.array_equal(got[2], ref["scores"])       # bit-identical
         # every image of the batch = its own batch-1 run (other tile shapes, other kernels' launch geometry)
         one = [t.cpu().numpy() for t in eng.forward(d[17:18].contiguous())]
@@ -55,14 +56,15 @@ def test_shufflenet_640_batch64(cuda, ssd, oracle_graph, precision):
 
 
 def test_shufflenet_640_batch64_stages_vs_oracle(cuda, ssd, oracle_graph):
-    """Every retained stage of the B = 64 forward, on the two images the oracle also ran: bit-identical in mode f32."""
+    """Every retained stage of the B = 64 forward, on the eight images the oracle also ran: bit-identical in mode f32."""
     params, Wt, imgs = _setup(ssd, -4.0)
     eng = ssd.Engine(params, Wt, precision="f32")
     eng.forward(cuda.from_numpy(imgs).cuda())
     keep = {}
-    oracle_graph.forward(imgs[[0, B - 1]], Wt, params, keep)
+    pick = [0, 9, 20, 31, 32, 41, 52, B - 1]        # four per half-batch backbone chain
+    oracle_graph.forward(imgs[pick], Wt, params, keep)
     for n in STAGES:
-        got = eng.get_tensor(n)[[0, B - 1]]
+        got = eng.get_tensor(n)[pick]
         ref = keep[n].reshape(got.shape)
         assert np.array_equal(got, ref), n
     eng.close()
