@@ -620,7 +620,15 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
                 for (int j = 2; j <= n_units; ++j) {
                     const ConvW &b2 = h->pw[g.ipw + 3 + 2 * (j - 2)], &a2 = h->pw[g.ipw + 3 + 2 * (j - 2) + 1];
                     const DwW &dd = h->dw[g.idw + j];
+#ifdef SSD_DIAG
+                    // ablation (scripts/experiments/sn_unit_fusion_bound.py): drop conv1x1_before of the stages in the mask -- WRONG
+                    // results, the time of a step whose first 1x1 of every unit is free: what no whole-unit fusion can beat
+                    if (const char *e = getenv("SSD_ABL_SKIP_PWG")) { if ((atoi(e) >> st) & 1) goto skip_before; }
+#endif
                     ops.push_back(make_pw_gather_op(b2, sb, g.total, src_dev[j], Dp * 4, rows, SSD_ACT_RELU, U));
+#ifdef SSD_DIAG
+                skip_before:
+#endif
                     if (j < n_units) SSDCHK(pair(dd, a2, U, g.oh, g.ow, 1, sb + tensor_off(j) / 4, 0));
                     else SSDCHK(pair(dd, a2, U, g.oh, g.ow, 1, S_chain, 2 * Dp));
                 }

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(NMS_MID) void post_nms_kernel(const PostArgs p)
         // frames the class that holds two thirds of a frame's candidates fills its 25 boxes from them), then the top <= 512.
         // A list the block's registers hold (n <= mid_max) only runs a trial that can fill the class: its exact rounds below
         // start over anyway; a longer list runs every trial, whose kept boxes it goes on from.
-        const bool progressive = n > p.mid_max && p.max_per_class <= NMS_KB;
+        const bool progressive = p.max_per_class <= NMS_KB;
         int ran_cb = -1;                            // the cut of the last trial that ran (block-uniform), -1: none
 #pragma unroll 1
         for (int k = 0; k < 2; ++k) {
