@@ -159,6 +159,33 @@ def latency_mixed_sizes(detector, cycles=8, alone_calls=20):
                         "alone = %d calls of one size after 3 warm-up calls" % (len(MIXED_SIZES), cycles, alone_calls)}
 
 
+def throughput_mixed_sizes(detector, n_images=260, max_batch=32):
+    """A stream of `n_images` host frames of the 13 COCO-typical sizes in shuffled order through ONE Detector: one call per image (the
+    reference's loop, inference/evaluate_on_COCO.ipynb:125-150) against Detector.detect_many (frames grouped by the size the
+    network sees; frames of DIFFERENT source sizes in one batch, ssd_forward_mixed).  Same results, bit for bit (checked here)."""
+    rng = np.random.default_rng(1)
+    order = rng.permutation(np.repeat(np.arange(len(MIXED_SIZES)), -(-n_images // len(MIXED_SIZES))))[:n_images]
+    frames = [rng.integers(0, 256, MIXED_SIZES[i] + (3,), dtype=np.uint8) for i in order]
+    for f in frames[:26]:
+        detector(f, score_threshold=0.5)
+    t0 = time.perf_counter()
+    one = [detector(f, score_threshold=0.5) for f in frames]
+    t_one = time.perf_counter() - t0
+    detector.detect_many(frames, score_threshold=0.5, max_batch=max_batch)      # builds the batched plans
+    t0 = time.perf_counter()
+    many = detector.detect_many(frames, score_threshold=0.5, max_batch=max_batch)
+    t_many = time.perf_counter() - t0
+    same = all(np.array_equal(a, b) for x, y in zip(one, many) for a, b in zip(x, y))
+    groups = {}
+    for f in frames:
+        k = ssd_amd.network_input_size(f.shape[0], f.shape[1], PARAMS["min_dimension"])[:2]
+        groups[k] = groups.get(k, 0) + 1
+    return {"images": n_images, "source_sizes": len(MIXED_SIZES), "one_call_per_image_img_s": n_images / t_one,
+            "detect_many_img_s": n_images / t_many, "speedup": t_one / t_many, "max_batch": max_batch,
+            "results_identical": bool(same), "frames_per_network_shape": {"%dx%d" % k: v for k, v in sorted(groups.items())},
+            "note": "host frames in, filtered numpy detections out, both ways; never `value` (that is 32 resident frames of the network's own size)"}
+
+
 def latency_segments(detector):
     """Where a batch-1 Detector call spends its time (attribution: every segment followed by a synchronisation, so the
     sum exceeds the pipelined call -- ssd_forward_host stages and uploads the image in pieces, the upload of one under the
@@ -679,6 +706,7 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
                                              segments_p50_us=latency_segments(detector))
                 if args.precision == "f32":
                     res["latency_mixed_sizes"] = latency_mixed_sizes(detector)
+                    res["throughput_mixed_sizes"] = throughput_mixed_sizes(detector)
             if world == 1 and not args.no_shufflenet:
                 engine.close()
                 res["shufflenet_config4"] = shufflenet_leg(local, timed, max(3, args.steps // 2), 2, 64)

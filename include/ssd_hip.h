@@ -193,6 +193,25 @@ int ssd_forward_records(ssd_handle *h, const uint8_t *images_dev, int32_t B, int
 int ssd_forward_host(ssd_handle *h, const uint8_t *images_host, int32_t B, int32_t H, int32_t W,
                      void *records, void *stream);
 
+/* Frames of DIFFERENT sizes as ONE batch.  The reference's graph is fed one image per call because a tensor has one height and
+ * width (create_pb.py:40); what the network sees, though, is the size AFTER resize_keeping_aspect_ratio (pipeline.py:138-194), and
+ * frames of many source sizes share it (480x640, 375x500, 333x500 -> 640x896).  ssd_forward_mixed runs B <= 64 such frames through the
+ * ordinary batched plan of that network shape: the first kernel reads every frame through its own geometry (passed in its
+ * arguments: nothing is uploaded), the pack kernel divides every image's boxes by its own box_scaler (model.py:67-68).  Record b
+ * is bit for bit what frame b gives alone.
+ *   images_dev   base pointer of the frames, uint8; frame b = [hw_host[2b], hw_host[2b+1], 3] at byte offset offsets_host[b]
+ *                (offsets_host == NULL: back to back, every frame on the next 16-byte boundary); all within 2 GiB of the base
+ *   records_dev  B records as for ssd_forward_records (device or pinned host memory)
+ * Every frame must resize to the same network shape (ssd_network_shape tells a caller which: group by it), else SSD_ERR_INVALID.
+ * Asynchronous on `stream`; hw_host / offsets_host may be reused on return. */
+int ssd_network_shape(ssd_handle *h, int32_t height, int32_t width, int32_t *net_hw_out /* [2] */);
+int ssd_forward_mixed(ssd_handle *h, const uint8_t *images_dev, int32_t B, const int32_t *hw_host, const int64_t *offsets_host,
+                      void *records_dev, void *stream);
+/* ... fed from host memory: frames_host[b] points to frame b (pageable memory is fine); staged through the handle's pinned buffer,
+ * one upload per frame (frame b crosses the bus under the host copy of frame b + 1).  On return the frames may be reused. */
+int ssd_forward_mixed_host(ssd_handle *h, const uint8_t *const *frames_host, int32_t B, const int32_t *hw_host, void *records,
+                           void *stream);
+
 /* inference/detector.py:33-58 (Detector.__call__) for ONE frame as one call: ssd_forward_host with B = 1, the wait for
  * `stream`, and the score filter `scores > score_threshold` over the frame's num_boxes rows (order kept) from the record
  * into the caller's host arrays boxes_out [capacity,4], labels_out / scores_out [capacity]; *n_out = rows kept.

@@ -130,6 +130,9 @@ SIGNATURES = {
     "ssd_record_words": (ctypes.c_int32, [_vp]),
     "ssd_forward_records": (ctypes.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ssd_forward_host": (ctypes.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ssd_network_shape": (ctypes.c_int, [_vp, _i, _i, _i32p]),
+    "ssd_forward_mixed": (ctypes.c_int, [_vp, _vp, _i, _i32p, ctypes.POINTER(ctypes.c_int64), _vp, _vp]),
+    "ssd_forward_mixed_host": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_void_p), _i, _i32p, _vp, _vp]),
     "ssd_detect_host": (ctypes.c_int, [_vp, _vp, _i, _i, ctypes.c_float, _vp, _vp, _vp, _vp, _i, _i32p, _vp]),
     "ssd_get_tensor": (ctypes.c_int, [_vp, ctypes.c_char_p, _f, ctypes.c_int64, _i32p]),
     "ssd_get_tensor_dev": (ctypes.c_int, [_vp, ctypes.c_char_p, _vp, ctypes.c_int64, _i32p, _vp]),

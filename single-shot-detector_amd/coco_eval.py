@@ -31,11 +31,12 @@ def integer_to_coco_id(categories):
     return {labels[c["name"]]: c["id"] for c in categories}
 
 
-def detection_records(detector, image, image_id, label_to_coco_id, score_threshold=0.15):
+def detection_records(detector, image, image_id, label_to_coco_id, score_threshold=0.15, detections=None):
     """One image -> COCO result dicts, exactly as cell 10: boxes scaled to pixels of the
-    ORIGINAL image, x, y = int(xmin), int(ymin); w, h = int(xmax - xmin), int(ymax - ymin)."""
+    ORIGINAL image, x, y = int(xmin), int(ymin); w, h = int(xmax - xmin), int(ymax - ymin).
+    `detections` = (boxes, labels, scores) already computed for this image (a batched run), else the detector is called."""
     height, width, _ = image.shape
-    boxes, labels, scores = detector(image, score_threshold=score_threshold)
+    boxes, labels, scores = detections if detections is not None else detector(image, score_threshold=score_threshold)
     scaler = np.array([height, width, height, width], dtype="float32")
     boxes = boxes * scaler
     out = []
@@ -48,6 +49,17 @@ def detection_records(detector, image, image_id, label_to_coco_id, score_thresho
     return out
 
 
+def detection_records_many(detector, images, image_ids, label_to_coco_id, score_threshold=0.15, max_batch=32):
+    """The same for a list of images of any sizes, with the detector's batched form when it has one (Detector.detect_many: images
+    grouped by the size the network sees, frames of different source sizes in one batch; each result bit for bit the single call's)."""
+    many = getattr(detector, "detect_many", None)
+    dets = many(images, score_threshold=score_threshold, max_batch=max_batch) if many else [None] * len(images)
+    out = []
+    for image, image_id, d in zip(images, image_ids, dets):
+        out += detection_records(detector, image, image_id, label_to_coco_id, score_threshold, detections=d)
+    return out
+
+
 def evaluate(detector, annotations_json, images_dir, read_image, predictions_json="coco_predictions.json"):
     """Cells 4-17 end to end; `read_image(path) -> uint8 RGB ndarray`.  Needs pycocotools."""
     import os
@@ -57,10 +69,11 @@ def evaluate(detector, annotations_json, images_dir, read_image, predictions_jso
     mapping = integer_to_coco_id(coco.loadCats(coco.getCatIds()))
     img_ids = coco.getImgIds()
     results = []
-    for image_id in img_ids:
-        meta = coco.loadImgs(image_id)[0]
-        image = read_image(os.path.join(images_dir, meta["file_name"]))
-        results += detection_records(detector, image, meta["id"], mapping)
+    chunk = 256           # images read, then detected as batches grouped by network shape (the notebook's loop, one image per sess.run, at batch throughput)
+    for k in range(0, len(img_ids), chunk):
+        metas = [coco.loadImgs(i)[0] for i in img_ids[k:k + chunk]]
+        images = [read_image(os.path.join(images_dir, m["file_name"])) for m in metas]
+        results += detection_records_many(detector, images, [m["id"] for m in metas], mapping)
     with open(predictions_json, "w") as f:
         json.dump(results, f)
     ev = COCOeval(cocoGt=coco, cocoDt=coco.loadRes(predictions_json), iouType="bbox")

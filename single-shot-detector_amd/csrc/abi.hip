@@ -203,12 +203,17 @@ extern "C" int ssd_finalize(ssd_handle *h)
 // One forward on stream `s` with the handle's mutex held.  The plans of a handle share the process's internal streams (and a
 // shape's arena is one): when this forward is enqueued on another stream than the previous one it first waits for that one's
 // last kernel (two host threads sharing a Detector on their own streams, as tf.Session.run allows, inference/detector.py:34,52).
+// (a mixed-size batch: `mx` = its per-frame geometry, the network shape all frames resize to, its largest frame's bytes)
+struct MixedSel { const MixedCall *mx; int netH, netW; long long max_bytes; };
+
 static int forward_locked(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
-                          int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, long long out_stride, hipStream_t s)
+                          int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, long long out_stride, hipStream_t s,
+                          const MixedSel *ms = nullptr)
 {
     HIPCHK(hipSetDevice(h->cfg.device));
     // the plans of this shape: kept from an earlier call (no HIP call at all), or built now beside the others
-    SSDCHK(select_plans(h, B, H, W));
+    if (ms) SSDCHK(select_plans_net(h, B, ms->netH, ms->netW, 0, ms->max_bytes));
+    else SSDCHK(select_plans(h, B, H, W));
     // a forward on another stream than the previous one waits for it.  The event is recorded HERE, at the
     // current tail of the previous stream (everything the previous forward enqueued there precedes it), not at the end of
     // every forward: a record behind the last kernel is one more packet the caller's synchronisation waits for.
@@ -239,12 +244,16 @@ static int forward_locked(ssd_handle *h, const uint8_t *images_dev, int32_t B, i
     }
     // (hipGraph replay of a repeating forward was measured in rounds 1-2 -- batch 1: replay 2.49 ms against eager 2.33, the forward
     //  is GPU-bound -- and is not part of the library.)
-    return enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, out_stride, s);
+    h->mixed = ms ? ms->mx : nullptr;
+    const int rc = enqueue_forward(h, images_dev, boxes_dev, labels_dev, scores_dev, num_boxes_dev, out_stride, s);
+    h->mixed = nullptr;
+    return rc;
 }
 
 // (the caller holds h->mu)
 static int forward_checked_locked(ssd_handle *h, const uint8_t *images_dev, int32_t B, int32_t H, int32_t W, float *boxes_dev,
-                                  int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, long long out_stride, void *stream)
+                                  int32_t *labels_dev, float *scores_dev, int32_t *num_boxes_dev, long long out_stride, void *stream,
+                                  const MixedSel *ms = nullptr)
 {
     if (!h->finalized) return ssd_fail(SSD_ERR_STATE, "ssd_forward before ssd_finalize");
     if (B < 1 || H < 1 || W < 1 || h->cfg.min_dimension < 128 || h->cfg.min_dimension % 128)
@@ -255,7 +264,7 @@ static int forward_checked_locked(ssd_handle *h, const uint8_t *images_dev, int3
             return ssd_fail(SSD_ERR_INVALID, "ssd_forward: aspect ratio too extreme (resized image exceeds 64 Mpixel)");
     }
     hipStream_t s = (hipStream_t)stream;
-    const int rc = forward_locked(h, images_dev, B, H, W, boxes_dev, labels_dev, scores_dev, num_boxes_dev, out_stride, s);
+    const int rc = forward_locked(h, images_dev, B, H, W, boxes_dev, labels_dev, scores_dev, num_boxes_dev, out_stride, s, ms);
     if (rc == SSD_OK) {
         // (not while a caller captures `s` into a graph of its own: the stream then is not a queue of the device's)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -303,6 +312,24 @@ extern "C" int ssd_forward_records(ssd_handle *h, const uint8_t *images_dev, int
     return forward_checked(h, images_dev, B, H, W, (float *)r, r + 5 * T, (float *)(r + 4 * T), r + 6 * T, 6 * T + 1, stream);
 }
 
+// The handle's staging pair (pinned host + device image): grow-only, in powers of two from 2 MiB (a mix of image sizes settles after
+// a few calls: a 640 x 480 frame is 0.9 MB, the largest COCO frame 1.2 MB); the device drains because the previous upload's buffers
+// are freed.
+static int grow_stage(ssd_handle *h, size_t bytes)
+{
+    if (bytes <= h->stage_bytes) return SSD_OK;
+    size_t cap = (size_t)2 << 20;
+    while (cap < bytes) cap <<= 1;
+    HIPCHK(hipDeviceSynchronize());
+    if (h->stage_pin) { (void)hipHostFree(h->stage_pin); h->stage_pin = nullptr; }
+    if (h->stage_dev) { (void)hipFree(h->stage_dev); h->stage_dev = nullptr; }
+    h->stage_bytes = 0;
+    HIPCHK(hipHostMalloc((void **)&h->stage_pin, cap + 256, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&h->stage_dev, cap + 256));
+    h->stage_bytes = cap;
+    return SSD_OK;
+}
+
 // The boundary's own form (inference/detector.py:51-52: a HOST image in on every call): pageable host memory -> the handle's
 // pinned staging buffer -> its device image, in `h2d_chunks` pieces so that piece k crosses the bus under the host copy of
 // piece k + 1 -- one C loop instead of a Python one (two numpy / torch calls per piece cost more than a piece's copy) --
@@ -322,19 +349,7 @@ extern "C" int ssd_forward_host(ssd_handle *h, const uint8_t *images_host, int32
         if (hipStreamSynchronize(h->stage_stream) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipDeviceSynchronize()); }   // (the caller destroyed that stream)
         h->stage_busy = false;
     }
-    if (bytes > h->stage_bytes) {
-        // grow-only, in powers of two from 2 MiB (a mix of image sizes settles after a few calls: a 640 x 480 frame is 0.9 MB,
-        // the largest COCO frame 1.2 MB); the device drains because the previous upload's buffers are freed
-        size_t cap = (size_t)2 << 20;
-        while (cap < bytes) cap <<= 1;
-        HIPCHK(hipDeviceSynchronize());
-        if (h->stage_pin) { (void)hipHostFree(h->stage_pin); h->stage_pin = nullptr; }
-        if (h->stage_dev) { (void)hipFree(h->stage_dev); h->stage_dev = nullptr; }
-        h->stage_bytes = 0;
-        HIPCHK(hipHostMalloc((void **)&h->stage_pin, cap + 256, hipHostMallocDefault));
-        HIPCHK(hipMalloc((void **)&h->stage_dev, cap + 256));
-        h->stage_bytes = cap;
-    }
+    SSDCHK(grow_stage(h, bytes));
     int nchunk = ssd_opt(h, OPT_H2D_CHUNKS, 2);      // (measured: 1 / 2 / 3 / 4 / 6 / 8 pieces -> Detector p50 1.695 / 1.678 / 1.691 / 1.698 / 1.717 / 1.735 ms: a hipMemcpyAsync costs the host ~10 us)
     if (nchunk < 1) nchunk = 1;
     if (nchunk > 16) nchunk = 16;
@@ -350,6 +365,102 @@ extern "C" int ssd_forward_host(ssd_handle *h, const uint8_t *images_host, int32
     const long long T = (long long)h->cfg.num_classes * h->cfg.max_boxes_per_class;
     int32_t *r = (int32_t *)records;
     return forward_checked_locked(h, h->stage_dev, B, H, W, (float *)r, r + 5 * T, (float *)(r + 4 * T), r + 6 * T, 6 * T + 1, stream);
+}
+
+// Frames of DIFFERENT sizes as ONE batch (round 6).  The reference's graph is fed one image at a time because a tensor has one
+// height and width (create_pb.py:40: [None, None, None, 3]); what the network sees, though, is the size AFTER
+// resize_keeping_aspect_ratio (pipeline.py:138-194), and frames of many source sizes share it (480 x 640, 375 x 500, 333 x 500 ->
+// 640 x 896): their first kernel reads every frame through its own geometry, everything behind it is the ordinary batched plan of
+// that network shape, and the pack kernel divides every image's boxes by its own box_scaler (model.py:67-68).  Image b of the
+// result is bit for bit what the frame gives alone.
+// Fills h->mixed_store from hw [B][2] (+ offsets, NULL = frames back to back) and the selector; every frame must resize to one shape.
+static int prepare_mixed(ssd_handle *h, int32_t B, const int32_t *hw, const int64_t *offsets, MixedSel *ms, const char *who)
+{
+    if (B < 1 || B > SSD_MIXED_MAX)
+        return ssd_fail(SSD_ERR_INVALID, std::string(who) + ": 1 .. " + std::to_string(SSD_MIXED_MAX) + " frames per mixed-size batch");
+    if (h->cfg.min_dimension < 128 || h->cfg.min_dimension % 128) return ssd_fail(SSD_ERR_INVALID, std::string(who) + ": min_dimension must be a multiple of 128");
+    MixedCall &mc = h->mixed_store;
+    long long off = 0, max_bytes = 0;
+    ms->mx = &mc; ms->netH = ms->netW = 0;
+    for (int b = 0; b < B; ++b) {
+        const int H = hw[2 * b], W = hw[2 * b + 1];
+        if (H < 1 || W < 1) return ssd_fail(SSD_ERR_INVALID, std::string(who) + ": frame sizes must be positive");
+        const ResizeDims rd = resize_dims(H, W, h->cfg.min_dimension, 128);
+        const int nH = rd.nh + rd.ph, nW = rd.nw + rd.pw;
+        if ((long long)nH * nW > (1LL << 26)) return ssd_fail(SSD_ERR_INVALID, std::string(who) + ": aspect ratio too extreme (resized image exceeds 64 Mpixel)");
+        if (b == 0) { ms->netH = nH; ms->netW = nW; }
+        else if (nH != ms->netH || nW != ms->netW)
+            return ssd_fail(SSD_ERR_INVALID, std::string(who) + ": frame " + std::to_string(b) + " (" + std::to_string(H) + " x " + std::to_string(W) + ") resizes to " +
+                                             std::to_string(nH) + " x " + std::to_string(nW) + ", frame 0 to " + std::to_string(ms->netH) + " x " +
+                                             std::to_string(ms->netW) + ": the frames of one batch must share the network shape (group them by ssd_network_shape)");
+        const long long bytes = (long long)H * W * 3;
+        const long long o = offsets ? offsets[b] : off;
+        if (o < 0 || o + bytes >= (1LL << 31)) return ssd_fail(SSD_ERR_INVALID, std::string(who) + ": the frames of a batch must lie within 2 GiB of the base pointer");
+        FrameGeom &g = mc.geom.f[b];
+        g.off = (unsigned)o; g.srcH = H; g.srcW = W; g.nh = rd.nh; g.nw = rd.nw;
+        g.hs = (float)H / (float)rd.nh; g.ws = (float)W / (float)rd.nw;       // (launch_first_conv's own expressions)
+        mc.scaler[b][0] = rd.box_scaler[0]; mc.scaler[b][1] = rd.box_scaler[1];
+        off = o + ((bytes + 15) & ~15LL);                                    // back to back: every frame on a 16-byte boundary
+        max_bytes = bytes > max_bytes ? bytes : max_bytes;
+    }
+    ms->max_bytes = max_bytes;
+    return SSD_OK;
+}
+
+// The network's input size of a [height, width] frame (resize_keeping_aspect_ratio with this handle's min_dimension, padded to
+// multiples of 128): what a caller groups frames by before ssd_forward_mixed.
+extern "C" int ssd_network_shape(ssd_handle *h, int32_t height, int32_t width, int32_t *net_hw)
+{
+    if (!h || !net_hw || height < 1 || width < 1) return ssd_fail(SSD_ERR_INVALID, "ssd_network_shape: bad arguments");
+    if (h->cfg.min_dimension < 128 || h->cfg.min_dimension % 128) return ssd_fail(SSD_ERR_INVALID, "ssd_network_shape: min_dimension must be a multiple of 128");
+    const ResizeDims rd = resize_dims(height, width, h->cfg.min_dimension, 128);
+    net_hw[0] = rd.nh + rd.ph; net_hw[1] = rd.nw + rd.pw;
+    return SSD_OK;
+}
+
+extern "C" int ssd_forward_mixed(ssd_handle *h, const uint8_t *images_dev, int32_t B, const int32_t *hw_host, const int64_t *offsets_host,
+                                 void *records_dev, void *stream)
+{
+    if (!h || !images_dev || !hw_host || !records_dev) return ssd_fail(SSD_ERR_INVALID, "ssd_forward_mixed: null argument");
+    if ((reinterpret_cast<uintptr_t>(records_dev) & 3) != 0) return ssd_fail(SSD_ERR_INVALID, "ssd_forward_mixed: records must be 4-byte aligned");
+    std::lock_guard<std::mutex> g(h->mu);
+    MixedSel ms;
+    SSDCHK(prepare_mixed(h, B, hw_host, offsets_host, &ms, "ssd_forward_mixed"));
+    const long long T = (long long)h->cfg.num_classes * h->cfg.max_boxes_per_class;
+    int32_t *r = (int32_t *)records_dev;
+    return forward_checked_locked(h, images_dev, B, hw_host[0], hw_host[1], (float *)r, r + 5 * T, (float *)(r + 4 * T), r + 6 * T, 6 * T + 1, stream, &ms);
+}
+
+// ... fed from host memory: frames_host[b] = frame b, uint8 [hw[b][0], hw[b][1], 3].  The frames are staged back to back (16-byte
+// aligned) through the handle's pinned buffer and uploaded in one piece per frame, then ssd_forward_mixed on the same stream.
+extern "C" int ssd_forward_mixed_host(ssd_handle *h, const uint8_t *const *frames_host, int32_t B, const int32_t *hw_host, void *records, void *stream)
+{
+    if (!h || !frames_host || !hw_host || !records) return ssd_fail(SSD_ERR_INVALID, "ssd_forward_mixed_host: null argument");
+    if ((reinterpret_cast<uintptr_t>(records) & 3) != 0) return ssd_fail(SSD_ERR_INVALID, "ssd_forward_mixed_host: records must be 4-byte aligned");
+    std::lock_guard<std::mutex> g(h->mu);
+    MixedSel ms;
+    SSDCHK(prepare_mixed(h, B, hw_host, nullptr, &ms, "ssd_forward_mixed_host"));
+    for (int b = 0; b < B; ++b)
+        if (!frames_host[b]) return ssd_fail(SSD_ERR_INVALID, "ssd_forward_mixed_host: null frame pointer");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    const MixedCall &mc = h->mixed_store;
+    const size_t bytes = (size_t)mc.geom.f[B - 1].off + (size_t)hw_host[2 * (B - 1)] * hw_host[2 * (B - 1) + 1] * 3;
+    if (h->stage_busy) {
+        if (hipStreamSynchronize(h->stage_stream) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipDeviceSynchronize()); }
+        h->stage_busy = false;
+    }
+    SSDCHK(grow_stage(h, bytes));
+    for (int b = 0; b < B; ++b) {           // frame b crosses the bus under the host copy of frame b + 1
+        const size_t n = (size_t)hw_host[2 * b] * hw_host[2 * b + 1] * 3, lo = mc.geom.f[b].off;
+        memcpy(h->stage_pin + lo, frames_host[b], n);
+        HIPCHK(hipMemcpyAsync(h->stage_dev + lo, h->stage_pin + lo, n, hipMemcpyHostToDevice, s));
+    }
+    h->stage_stream = s;
+    h->stage_busy = true;
+    const long long T = (long long)h->cfg.num_classes * h->cfg.max_boxes_per_class;
+    int32_t *r = (int32_t *)records;
+    return forward_checked_locked(h, h->stage_dev, B, hw_host[0], hw_host[1], (float *)r, r + 5 * T, (float *)(r + 4 * T), r + 6 * T, 6 * T + 1, stream, &ms);
 }
 
 // inference/detector.py:33-58 as ONE call for one frame: ssd_forward_host, the wait for `stream`, and the score filter

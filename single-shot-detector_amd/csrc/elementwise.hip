@@ -251,6 +251,76 @@ __global__ __launch_bounds__(256) void first_conv_px_kernel(const uint8_t *__res
     }
 }
 
+// K1c: K1 (the general, non-identity form) for a batch whose frames have DIFFERENT source sizes and resize to the same [H,W]:
+// frame b reads its geometry from the argument table.  The arithmetic per output is K1's, value for value: the same index rule
+// (floorf((float)dst * scale), clamped), the same (ky,kx,ci)-ordered fmaf chain.
+__global__ __launch_bounds__(256, 2) void first_conv_mixed_kernel(const uint8_t *__restrict__ img, const MixedGeom mg, int first, int B, int H, int W,
+                                                                  const float *__restrict__ w, int Cout, const float *mean, const float *sf,
+                                                                  const float *beta, int act, float *__restrict__ out)
+{
+    extern __shared__ float wl[];   // 27*Cout
+    for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) wl[i] = w[i];
+    __syncthreads();
+    const int OH = H >> 1, OW = W >> 1, C4 = Cout >> 2;
+    const long long total = (long long)B * OH * OW * C4;
+    const float inv255 = (float)(1.0 / 255.0);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        long long pix = idx / C4;
+        const int ox = (int)(pix % OW);
+        pix /= OW;
+        const int oy = (int)(pix % OH);
+        const int b = (int)(pix / OH);
+        const FrameGeom g = mg.f[first + b];
+        const uint8_t *src = img + g.off;
+        v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy + ky;
+            int sy = (int)floorf((float)iy * g.hs);
+            sy = sy < g.srcH - 1 ? sy : g.srcH - 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox + kx;
+                int sx = (int)floorf((float)ix * g.ws);
+                sx = sx < g.srcW - 1 ? sx : g.srcW - 1;
+                const bool inside = iy < H && ix < W;          // else: zero padding of the convolution
+                const bool inimg = iy < g.nh && ix < g.nw;     // else (but inside): the resize's zero pad band
+                const uint8_t *p = src + ((long long)(inimg ? sy : 0) * g.srcW + (inimg ? sx : 0)) * 3;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    float x = inimg ? (float)p[ci] : 0.0f;
+                    x = x * inv255;
+                    x = 2.0f * x - 1.0f;
+                    if (!inside) x = 0.0f;
+                    const v4f wv = *(const v4f *)(wl + ((ky * 3 + kx) * 3 + ci) * Cout + c4 * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(x, wv[i], acc[i]);
+                }
+            }
+        }
+        acc = bn_act4(acc, mean, sf, beta, c4 * 4, act);
+        *(v4f *)(out + idx * 4) = acc;
+    }
+}
+
+hipError_t launch_first_conv_mixed(const uint8_t *img, const MixedGeom &mg, int first, int B, int H, int W, const float *w, int Cout,
+                                   const float *mean, const float *sf, const float *beta, int act, float *out, hipStream_t s)
+{
+    if (B < 1 || first < 0 || first + B > SSD_MIXED_MAX || Cout % 4 || (H & 1) || (W & 1) || 27 * Cout * 4 > 65536) return hipErrorInvalidValue;
+    for (int b = first; b < first + B; ++b) {
+        const FrameGeom &g = mg.f[b];
+        if (g.srcH < 1 || g.srcW < 1 || g.nh < 1 || g.nw < 1 || g.nh > H || g.nw > W) return hipErrorInvalidValue;
+        if ((unsigned long long)g.off + (unsigned long long)g.srcH * g.srcW * 3 >= (1ull << 31)) return hipErrorInvalidValue;
+    }
+    const long long total = (long long)B * (H / 2) * (W / 2) * (Cout / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(first_conv_mixed_kernel, dim3((unsigned)blocks), dim3(256), 27 * Cout * sizeof(float), s, img, mg, first, B, H, W, w, Cout,
+                       mean, sf, beta, act, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int nh, int nw, int H, int W,
                              const float *w, int Cout, const float *mean, const float *sf, const float *beta, int act,
                              float *out, hipStream_t s)

@@ -217,6 +217,10 @@ struct Plan {
 // of the first kernel and of the pack kernel, set per call -- NOT part of a plan, which is keyed on what the network sees.
 struct SrcGeom { int srcH = 0, srcW = 0, nh = 0, nw = 0; float box_scaler[4] = {1, 1, 1, 1}; };
 
+// A batch of frames of DIFFERENT sizes that resize to one network shape (ssd_forward_mixed): per frame its geometry for the first
+// kernel and its box_scaler {y, x} for the pack kernel; valid while the forward is being enqueued (the handle's mutex is held).
+struct MixedCall { MixedGeom geom; float scaler[SSD_MIXED_MAX][2]; };
+
 // The plans of one network shape: key = (batch, the resized + padded size the network sees, whether the source already has that
 // size -- then the first layers are the fused front launch --, and the number of consecutive sub-batch plans).
 struct PlanKey {
@@ -258,6 +262,8 @@ struct ssd_handle {
     long long cache_hits = 0, cache_misses = 0, cache_evictions = 0;
     const uint8_t *cur_images = nullptr;
     SrcGeom src;                        // of the forward being enqueued (read by the ops' launch closures, like cur_images)
+    const MixedCall *mixed = nullptr;   // non-null while a mixed-size batch is being enqueued: per-frame geometry instead of `src`
+    MixedCall mixed_store;
     // the plans share the process's internal streams: a forward enqueued on another stream than the previous one waits for it
     hipStream_t last_stream = nullptr;
     bool have_last = false;
@@ -283,6 +289,8 @@ struct ssd_handle {
 // plan.hip
 void free_plans(ssd_handle *h);                         // every cached set (the device must be idle)
 int select_plans(ssd_handle *h, int B, int H, int W);   // h->cur = the set of this source shape: cache hit, or build (+ evict)
+// ... of a network shape directly (a mixed-size batch: ident = 0, max_src_bytes = its largest frame)
+int select_plans_net(ssd_handle *h, int B, int netH, int netW, int ident, long long max_src_bytes);
 int trim_plan_cache(ssd_handle *h, const PlanSet *keep);
 size_t plan_cache_limit_bytes(const ssd_handle *h);
 int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, int32_t *labels_dev, float *scores_dev,

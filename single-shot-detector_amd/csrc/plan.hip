@@ -412,6 +412,8 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
                 const int act = h->firstAct;
                 const int first_img = img0 + b0;
                 op.run = [=](hipStream_t s) {      // the source's size and the resize's target: this call's (SrcGeom), any that lands on H x W
+                    if (hh->mixed)                 // ... or every frame's own (a batch of frames of different sizes)
+                        return launch_first_conv_mixed(hh->cur_images, hh->mixed->geom, first_img, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, X, s);
                     const SrcGeom &g = hh->src;
                     return launch_first_conv(hh->cur_images + (size_t)first_img * g.srcH * g.srcW * 3, nb, g.srcH, g.srcW, g.nh, g.nw, H, W, f.w, f.Cp,
                                              f.mean, f.sf, f.beta, act, X, s);
@@ -566,6 +568,8 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
                     SSDCHK(falloc(&F, (long long)nb * h2 * w2 * fc));
                     op.bytes = (double)nb * H * W * 3 + (double)nb * h2 * w2 * 24 * 4.0;
                     op.run = [=](hipStream_t s) {
+                        if (hh->mixed)
+                            return launch_first_conv_mixed(hh->cur_images, hh->mixed->geom, first_img, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s);
                         const SrcGeom &g = hh->src;
                         return launch_first_conv(hh->cur_images + (size_t)first_img * g.srcH * g.srcW * 3, nb, g.srcH, g.srcW, g.nh, g.nw, H, W, f.w, f.Cp,
                                                  f.mean, f.sf, f.beta, act, F, s);
@@ -1023,11 +1027,20 @@ static int build_planset(ssd_handle *h, PlanSet &ps)
 int select_plans(ssd_handle *h, int B, int H, int W)
 {
     const ResizeDims rd = resize_dims(H, W, h->cfg.min_dimension, 128);
+    const int netH = rd.nh + rd.ph, netW = rd.nw + rd.pw;
+    const int ident = (H == netH && W == netW && rd.nh == H && rd.nw == W) ? 1 : 0;
+    h->src.srcH = H; h->src.srcW = W; h->src.nh = rd.nh; h->src.nw = rd.nw;
+    for (int k = 0; k < 4; ++k) h->src.box_scaler[k] = rd.box_scaler[k];
+    return select_plans_net(h, B, netH, netW, ident, (long long)H * W * 3);
+}
+
+int select_plans_net(ssd_handle *h, int B, int netH, int netW, int ident, long long max_src_bytes)
+{
     PlanKey key;
     key.B = B;
-    key.netH = rd.nh + rd.ph;
-    key.netW = rd.nw + rd.pw;
-    key.ident = (H == key.netH && W == key.netW && rd.nh == H && rd.nw == W) ? 1 : 0;
+    key.netH = netH;
+    key.netW = netW;
+    key.ident = ident;
     // ONE plan per forward (round 1: 1 / 2 / 4 / 8 staggered sub-batch plans -> 730 / 696 / 647 / 587 img/s: backbone kernels
     // beside head kernels take CU slots from them and stretch far more than the overlap returns).  Consecutive sub-batch plans
     // exist for one reason: every tensor a launch addresses with 32-bit byte offsets must stay < 2 GiB.  Per image: the largest
@@ -1043,7 +1056,7 @@ int select_plans(ssd_handle *h, int B, int H, int W)
         const Pyr py1 = make_pyr(1, nH, nW, 256);
         per_img = std::max(per_img, py1.total * 4);
         per_img = std::max(per_img, (long long)ssd_num_anchors(nH, nW) * std::max(h->cfg.num_classes, 4) * 4);
-        per_img = std::max(per_img, (long long)H * W * 3);
+        per_img = std::max(per_img, max_src_bytes);
         if (h->cfg.backbone == SSD_BACKBONE_SHUFFLENET) {        // a ShuffleNet stage is one allocation: its producers' tensors + its two-part output
             const int un[3] = {4, 8, 4};
             int ipw = 0, hh = nH / 8, ww = nW / 8;
@@ -1059,8 +1072,6 @@ int select_plans(ssd_handle *h, int B, int H, int W)
     }
     if (nsub > B) nsub = B;
     key.nsub = nsub;
-    h->src.srcH = H; h->src.srcW = W; h->src.nh = rd.nh; h->src.nw = rd.nw;
-    for (int k = 0; k < 4; ++k) h->src.box_scaler[k] = rd.box_scaler[k];
     h->use_clock += 1;
     if (h->cur && h->cur->key == key) {                 // (the usual serving loop: same shape as the call before)
         h->cur->last_use = h->use_clock;
@@ -1143,6 +1154,13 @@ int enqueue_forward(ssd_handle *h, const uint8_t *images_dev, float *boxes_dev, 
         }
         PostArgs p = pl.post;
         for (int q = 0; q < 4; ++q) p.box_scaler[q] = h->src.box_scaler[q];       // model.py:67-68, of this call's source size
+        if (h->mixed) {                                                          // ... or of every frame's own
+            p.per_image_scaler = 1;
+            for (int b = 0; b < pl.B && pl.img0 + b < SSD_MIXED_MAX; ++b) {
+                p.scaler_img[b][0] = h->mixed->scaler[pl.img0 + b][0];
+                p.scaler_img[b][1] = h->mixed->scaler[pl.img0 + b][1];
+            }
+        }
         p.out_stride = out_stride;
         p.boxes = boxes_dev + (out_stride ? (size_t)pl.img0 * out_stride : (size_t)pl.img0 * T * 4);
         p.labels = labels_dev + (out_stride ? (size_t)pl.img0 * out_stride : (size_t)pl.img0 * T);

@@ -729,6 +729,9 @@ __global__ __launch_bounds__(256) void post_pack_kernel(const PostArgs p)
         __syncthreads();
     }
     const long long rs = p.out_stride;                       // 0: dense tensors
+    // model.py:67-68 `boxes /= box_scaler`: the batch's, or -- frames of different sizes in one batch -- this image's
+    const float bsy = p.per_image_scaler ? p.scaler_img[b][0] : p.box_scaler[0], bsx = p.per_image_scaler ? p.scaler_img[b][1] : p.box_scaler[1];
+    const float bsy2 = p.per_image_scaler ? p.scaler_img[b][0] : p.box_scaler[2], bsx2 = p.per_image_scaler ? p.scaler_img[b][1] : p.box_scaler[3];
     if (tid == 0) { pre[C] = carry; p.num[rs ? b * rs : (long long)b] = carry; }
     __syncthreads();
     const int total = pre[C];
@@ -745,10 +748,10 @@ __global__ __launch_bounds__(256) void post_pack_kernel(const PostArgs p)
             const long long src = (long long)(b * C + c) * mp + j;
             if (vec) {
                 const v4f q = *(const v4f *)(p.cls_boxes + src * 4);
-                *(v4f *)(boxes + d * 4) = v4f{q[0] / p.box_scaler[0], q[1] / p.box_scaler[1], q[2] / p.box_scaler[2], q[3] / p.box_scaler[3]};
+                *(v4f *)(boxes + d * 4) = v4f{q[0] / bsy, q[1] / bsx, q[2] / bsy2, q[3] / bsx2};
             } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) boxes[d * 4 + k] = p.cls_boxes[src * 4 + k] / p.box_scaler[k];
+                for (int k = 0; k < 4; ++k) boxes[d * 4 + k] = p.cls_boxes[src * 4 + k] / (k == 0 ? bsy : (k == 1 ? bsx : (k == 2 ? bsy2 : bsx2)));
             }
             scores[d] = p.cls_scores[src];
             labels[d] = c;

@@ -199,6 +199,14 @@ hipError_t launch_front_pool(const uint8_t *img, int B, int H, int W, const floa
 hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int nh, int nw, int H, int W,
                              const float *w /*[27][Cout] phys-n*/, int Cout, const float *mean, const float *sf,
                              const float *beta, int act, float *out, hipStream_t s);
+// ... the same for a batch of frames of DIFFERENT sizes that resize to the same [H,W] (ssd_forward_mixed): frame b of the launch is
+// geometry entry first + b -- its byte offset in `img`, its size, its resize target and the two scale factors -- and the table
+// travels in the kernel's arguments (no upload, nothing to keep alive): at most SSD_MIXED_MAX frames per batch
+#define SSD_MIXED_MAX 64
+struct FrameGeom { unsigned off; int srcH, srcW, nh, nw; float hs, ws; };
+struct MixedGeom { FrameGeom f[SSD_MIXED_MAX]; };
+hipError_t launch_first_conv_mixed(const uint8_t *img, const MixedGeom &mg, int first, int B, int H, int W, const float *w, int Cout,
+                                   const float *mean, const float *sf, const float *beta, int act, float *out, hipStream_t s);
 hipError_t launch_depthwise(const float *in, int B, int H, int W, int C, const float *w /*[9][C]*/,
                             int stride, int pad, int OH, int OW, const float *mean, const float *sf,
                             const float *beta, int act, float *out, hipStream_t s, int out16 = 0 /* 1: S16 rows */,
@@ -229,6 +237,8 @@ struct PostArgs {
     int self_clean;        // 1: the workspace belongs to a layer plan that zeroed counts / scan_bits once; the kernels leave
                            // them zeroed for the next forward (no memset launches).  0: a caller's workspace, cleared per call
     float box_scaler[4];
+    int per_image_scaler;                       // 1: image b divides by scaler_img[b] = {y, x} (a batch of frames of different sizes)
+    float scaler_img[SSD_MIXED_MAX][2];
     float *boxes; int32_t *labels; float *scores; int32_t *num;
     long long out_stride;       // 32-bit words between the outputs of consecutive images, the same for all four pointers: 0 = the
                                 // four dense tensors (boxes T*4, labels / scores T, num 1), else the record stride (ssd_forward_records)

@@ -82,6 +82,34 @@ class Detector:
         with self.engine.lock:
             return tuple(np.array(v) for v in self._detect_views(images))
 
+    def detect_many(self, images, score_threshold=0.1, max_batch=32):
+        """`__call__` for a LIST of images of any sizes, batched: the images are grouped by the size the network sees for them
+        (resize_keeping_aspect_ratio, pipeline.py:138-194: 480x640, 375x500, 333x500 all become 640x896), every group runs as
+        batches of up to `max_batch` frames of DIFFERENT source sizes (ssd_forward_mixed_host: per-frame geometry in the first
+        kernel, per-image box_scaler in the last), and the results come back in the order of `images` as (boxes, labels, scores)
+        per image -- each bit for bit what `self(image, score_threshold)` returns.  The reference loops one `sess.run` per image
+        (inference/evaluate_on_COCO.ipynb:125-150); this is that loop at batch throughput.  Mode f32."""
+        if self.engine.precision != "f32":
+            return [self(im, score_threshold) for im in images]
+        imgs = [np.asarray(im) for im in images]
+        max_batch = max(1, min(int(max_batch), self.engine.MIXED_MAX))
+        groups = {}
+        for i, im in enumerate(imgs):
+            if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+                raise ValueError("every image must be a uint8 array of shape [height, width, 3]")
+            groups.setdefault(self.engine.network_shape(im.shape[0], im.shape[1]), []).append(i)
+        out = [None] * len(imgs)
+        with self.engine.lock:
+            for idx in groups.values():
+                for k in range(0, len(idx), max_batch):
+                    part = idx[k:k + max_batch]
+                    boxes, labels, scores, num = self.engine.detect_host_mixed([imgs[i] for i in part])
+                    for j, i in enumerate(part):
+                        n = int(num[j])
+                        keep = scores[j][:n] > score_threshold        # inference/detector.py:54-58
+                        out[i] = (boxes[j][:n][keep], labels[j][:n][keep], scores[j][:n][keep])
+        return out
+
     def detect_stream(self, batches):
         """Steady-state serving: an iterable of host uint8 batches [B,H,W,3] -> a generator of the graph outputs per
         batch, in order, with the host-to-device and device-to-host copies of neighbouring batches hidden under the

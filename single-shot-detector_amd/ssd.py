@@ -530,6 +530,67 @@ class Engine:
             n = sc[3].value
             return sc[0][:n].copy(), sc[1][:n].copy(), sc[2][:n].copy()
 
+    MIXED_MAX = 64       # frames per mixed-size batch (their geometry travels in the first kernel's arguments)
+
+    def network_shape(self, height, width):
+        """(height, width) the network sees for a frame of this size: what frames are grouped by for a mixed-size batch."""
+        return network_input_size(height, width, self.params["min_dimension"])[:2]
+
+    def forward_mixed(self, frames, records=None):
+        """Frames of DIFFERENT sizes that resize to one network shape, as ONE batch (ssd_forward_mixed).  `frames`: a list of
+        uint8 CUDA tensors [H_b, W_b, 3] (copied back to back into a persistent device buffer), or a tuple (flat uint8 CUDA
+        tensor, [(H_b, W_b)...], byte offsets or None) already laid out.  Returns (boxes [B,T,4], labels, scores, num_boxes) as
+        views of `records` (created when not given); image b is bit for bit what frame b gives alone.  Asynchronous on the
+        current stream."""
+        torch = _torch()
+        with self.lock:
+            if isinstance(frames, tuple):
+                flat, hw, offsets = frames
+                _check_dev(torch, flat, torch.uint8, "frames")
+            else:
+                hw = [(int(f.shape[0]), int(f.shape[1])) for f in frames]
+                offsets, total = [], 0
+                for h_, w_ in hw:
+                    offsets.append(total)
+                    total += (h_ * w_ * 3 + 15) & ~15
+                _, flat, _ = self._in_slot((max(total, 16),), index=4)
+                for f, o, (h_, w_) in zip(frames, offsets, hw):
+                    _check_dev(torch, f, torch.uint8, "frames")
+                    if f.dim() != 3 or f.shape[2] != 3:
+                        raise ValueError("every frame must have shape [H, W, 3]")
+                    flat[o:o + h_ * w_ * 3].view(h_, w_, 3).copy_(f, non_blocking=True)
+            B = len(hw)
+            if records is None:
+                records = self.new_records(B, flat.device)
+            if records.dtype != torch.int32 or tuple(records.shape) != (B, self.record_words) or not records.is_contiguous():
+                raise ValueError("records must be a contiguous int32 tensor [B, %d]" % self.record_words)
+            hw_c = (ctypes.c_int32 * (2 * B))(*[v for pair in hw for v in pair])
+            off_c = (ctypes.c_int64 * B)(*offsets) if offsets is not None else None
+            check(lib().ssd_forward_mixed(self._h, _ptr(flat), B, hw_c, off_c, _ptr(records), _stream(torch)))
+            return self.record_views(records)
+
+    def detect_host_mixed(self, images):
+        """A list of host uint8 arrays [H_b, W_b, 3] of different sizes that share a network shape -> numpy VIEWS of the pinned
+        result block (boxes, labels, scores, num_boxes), valid until the next call with this batch size: ONE call of
+        ssd_forward_mixed_host (staging + one upload per frame + the batched forward), one device-to-host copy, one wait."""
+        torch = _torch()
+        B = len(images)
+        with self.lock:
+            srcs = [np.ascontiguousarray(im) for im in images]
+            for im in srcs:
+                if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+                    raise ValueError("every image must be a uint8 array of shape [height, width, 3]")
+            slot = self._out_slot(B)
+            zc = B <= self.zero_copy_max_batch
+            rec = slot["pin_out"] if zc else slot["block"]
+            ptrs = (ctypes.c_void_p * B)(*[im.ctypes.data for im in srcs])
+            hw_c = (ctypes.c_int32 * (2 * B))(*[int(v) for im in srcs for v in im.shape[:2]])
+            check(lib().ssd_forward_mixed_host(self._h, ptrs, B, hw_c, _ptr(rec), _stream(torch)))
+            if not zc:
+                slot["pin_out"].copy_(slot["block"], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return slot["host"]
+
     def detect_stream(self, batches):
         """Host-fed steady-state serving: an iterable of host uint8 arrays [B,H,W,3] (any mix of sizes) -> a generator of
         (boxes, labels, scores, num_boxes) numpy arrays, in order.  Two sets of buffers and two copy streams: the

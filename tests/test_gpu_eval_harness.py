@@ -44,6 +44,16 @@ def test_coco_records_and_voc_ap_through_the_real_detector(cuda, ssd, oracle_gra
         b, l, s = det(image, 0.15)
         ev_gpu.add_image(gb, gl, b, l, s)
         ev_self.add_image(gb, gl, gb, gl, gs)
+    # the harness's batched form (Detector.detect_many: images grouped by network shape, frames of different sizes in one batch):
+    # the same records, in the same order, as one call per image -- for the GPU detector and for a detector without detect_many
+    shapes = [(128, 128, 3), (100, 151, 3), (300, 128, 3), (97, 203, 3), (128, 200, 3), (64, 100, 3), (100, 151, 3)]
+    images = [rng.integers(0, 256, sh, dtype=np.uint8) for sh in shapes]
+    ids = list(range(100, 100 + len(images)))
+    single = []
+    for im, i in zip(images, ids):
+        single += ssd.coco_eval.detection_records(det, im, i, mapping)
+    assert ssd.coco_eval.detection_records_many(det, images, ids, mapping, max_batch=4) == single and len(single) > 50
+    assert ssd.coco_eval.detection_records_many(ora, images[:2], ids[:2], mapping) == [r for r in single if r["image_id"] in ids[:2]]
     m_gpu, m_self = ev_gpu.evaluate(), ev_self.evaluate()
     assert total > 100
     assert m_self["mAP"] == np.mean([1.0 if len(ev_self.detections[c]) else 0.0 for c in range(80)])
