@@ -164,6 +164,7 @@ extern "C" void ssd_destroy(ssd_handle *h)
     for (auto r : h->ev_pool) (void)hipEventDestroy(r);
     free_plans(h);
     if (h->ev_last) (void)hipEventDestroy(h->ev_last);
+    if (h->ev_stage) (void)hipEventDestroy(h->ev_stage);
     if (h->stage_pin) (void)hipHostFree(h->stage_pin);
     if (h->stage_dev) (void)hipFree(h->stage_dev);
     if (h->flags_dev) (void)hipFree(h->flags_dev);
@@ -312,6 +313,35 @@ extern "C" int ssd_forward_records(ssd_handle *h, const uint8_t *images_dev, int
     return forward_checked(h, images_dev, B, H, W, (float *)r, r + 5 * T, (float *)(r + 4 * T), r + 6 * T, 6 * T + 1, stream);
 }
 
+// Before the host writes the pinned staging buffer again: the previous call's uploads must have read it.  Only the uploads -- not the
+// forward behind them (round 6: a caller that stages batch k + 1 while batch k computes, Detector.detect_many, is not held up; the
+// wait used to be for the whole stream).  A new stream's uploads queue behind nothing of the old one: drain the old one's event first.
+static int stage_acquire(ssd_handle *h)
+{
+    if (!h->stage_busy) return SSD_OK;
+    const hipError_t e = h->stage_by_event && h->ev_stage ? hipEventSynchronize(h->ev_stage) : hipStreamSynchronize(h->stage_stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipDeviceSynchronize()); }   // (the caller destroyed that stream)
+    h->stage_busy = false;
+    return SSD_OK;
+}
+// by_event = false: the caller drains `s` itself right after the forward (ssd_detect_host): nothing is recorded -- an event record
+// between the upload and the first kernel is one more packet on the critical path of a batch-1 call.
+static int stage_release(ssd_handle *h, hipStream_t s, bool by_event)
+{
+    if (by_event) {
+        if (!h->ev_stage) HIPCHK(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs == hipStreamCaptureStatusNone) HIPCHK(hipEventRecord(h->ev_stage, s));
+        else by_event = false;
+    }
+    h->stage_stream = s;
+    h->stage_stream_set = true;
+    h->stage_by_event = by_event;
+    h->stage_busy = true;
+    return SSD_OK;
+}
+
 // The handle's staging pair (pinned host + device image): grow-only, in powers of two from 2 MiB (a mix of image sizes settles after
 // a few calls: a 640 x 480 frame is 0.9 MB, the largest COCO frame 1.2 MB); the device drains because the previous upload's buffers
 // are freed.
@@ -335,7 +365,7 @@ static int grow_stage(ssd_handle *h, size_t bytes)
 // piece k + 1 -- one C loop instead of a Python one (two numpy / torch calls per piece cost more than a piece's copy) --
 // then ssd_forward_records on the same stream.  The host copy is synchronous (on return `images_host` may be reused), the rest
 // asynchronous on `stream`.
-extern "C" int ssd_forward_host(ssd_handle *h, const uint8_t *images_host, int32_t B, int32_t H, int32_t W, void *records, void *stream)
+static int forward_host_impl(ssd_handle *h, const uint8_t *images_host, int32_t B, int32_t H, int32_t W, void *records, void *stream, bool stage_event)
 {
     if (!h || !images_host || !records) return ssd_fail(SSD_ERR_INVALID, "ssd_forward_host: null argument");
     if (B < 1 || H < 1 || W < 1) return ssd_fail(SSD_ERR_INVALID, "ssd_forward_host: B, H, W must be positive");
@@ -345,9 +375,10 @@ extern "C" int ssd_forward_host(ssd_handle *h, const uint8_t *images_host, int32
     hipStream_t s = (hipStream_t)stream;
     const size_t bytes = (size_t)B * H * W * 3;
     // the previous call's upload may still be reading the staging buffer when the caller did not wait for it
-    if (h->stage_busy) {
-        if (hipStreamSynchronize(h->stage_stream) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipDeviceSynchronize()); }   // (the caller destroyed that stream)
-        h->stage_busy = false;
+    SSDCHK(stage_acquire(h));
+    if (h->stage_stream_set && h->stage_stream != s) {
+        // (another stream than last time: its uploads into the DEVICE image would not queue behind the forward that still reads it)
+        if (hipStreamSynchronize(h->stage_stream) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipDeviceSynchronize()); }
     }
     SSDCHK(grow_stage(h, bytes));
     int nchunk = ssd_opt(h, OPT_H2D_CHUNKS, 2);      // (measured: 1 / 2 / 3 / 4 / 6 / 8 pieces -> Detector p50 1.695 / 1.678 / 1.691 / 1.698 / 1.717 / 1.735 ms: a hipMemcpyAsync costs the host ~10 us)
@@ -360,11 +391,15 @@ extern "C" int ssd_forward_host(ssd_handle *h, const uint8_t *images_host, int32
         memcpy(h->stage_pin + lo, images_host + lo, n);
         HIPCHK(hipMemcpyAsync(h->stage_dev + lo, h->stage_pin + lo, n, hipMemcpyHostToDevice, s));
     }
-    h->stage_stream = s;
-    h->stage_busy = true;
+    SSDCHK(stage_release(h, s, stage_event));
     const long long T = (long long)h->cfg.num_classes * h->cfg.max_boxes_per_class;
     int32_t *r = (int32_t *)records;
     return forward_checked_locked(h, h->stage_dev, B, H, W, (float *)r, r + 5 * T, (float *)(r + 4 * T), r + 6 * T, 6 * T + 1, stream);
+}
+
+extern "C" int ssd_forward_host(ssd_handle *h, const uint8_t *images_host, int32_t B, int32_t H, int32_t W, void *records, void *stream)
+{
+    return forward_host_impl(h, images_host, B, H, W, records, stream, true);
 }
 
 // Frames of DIFFERENT sizes as ONE batch (round 6).  The reference's graph is fed one image at a time because a tensor has one
@@ -446,9 +481,9 @@ extern "C" int ssd_forward_mixed_host(ssd_handle *h, const uint8_t *const *frame
     hipStream_t s = (hipStream_t)stream;
     const MixedCall &mc = h->mixed_store;
     const size_t bytes = (size_t)mc.geom.f[B - 1].off + (size_t)hw_host[2 * (B - 1)] * hw_host[2 * (B - 1) + 1] * 3;
-    if (h->stage_busy) {
+    SSDCHK(stage_acquire(h));
+    if (h->stage_stream_set && h->stage_stream != s) {
         if (hipStreamSynchronize(h->stage_stream) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipDeviceSynchronize()); }
-        h->stage_busy = false;
     }
     SSDCHK(grow_stage(h, bytes));
     for (int b = 0; b < B; ++b) {           // frame b crosses the bus under the host copy of frame b + 1
@@ -456,8 +491,7 @@ extern "C" int ssd_forward_mixed_host(ssd_handle *h, const uint8_t *const *frame
         memcpy(h->stage_pin + lo, frames_host[b], n);
         HIPCHK(hipMemcpyAsync(h->stage_dev + lo, h->stage_pin + lo, n, hipMemcpyHostToDevice, s));
     }
-    h->stage_stream = s;
-    h->stage_busy = true;
+    SSDCHK(stage_release(h, s, true));
     const long long T = (long long)h->cfg.num_classes * h->cfg.max_boxes_per_class;
     int32_t *r = (int32_t *)records;
     return forward_checked_locked(h, h->stage_dev, B, hw_host[0], hw_host[1], (float *)r, r + 5 * T, (float *)(r + 4 * T), r + 6 * T, 6 * T + 1, stream, &ms);
@@ -490,7 +524,7 @@ extern "C" int ssd_detect_host(ssd_handle *h, const uint8_t *image_host, int32_t
             h->detect_rec_ok[h->n_rec_ok < 8 ? h->n_rec_ok++ : (h->rec_ok_next++ & 7)] = record;
         }
     }
-    int rc = ssd_forward_host(h, image_host, 1, H, W, record, stream);
+    int rc = forward_host_impl(h, image_host, 1, H, W, record, stream, false);       // (this call drains `stream` itself, next line)
     if (rc != SSD_OK) return rc;
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     const long long T = (long long)h->cfg.num_classes * h->cfg.max_boxes_per_class;

@@ -275,7 +275,10 @@ struct ssd_handle {
     uint8_t *stage_pin = nullptr, *stage_dev = nullptr;
     size_t stage_bytes = 0;
     hipStream_t stage_stream = nullptr;
-    bool stage_busy = false;
+    bool stage_busy = false, stage_stream_set = false;      // (the NULL stream is a stream too)
+    bool stage_by_event = false;         // the busy staging buffer is released by ev_stage (else: by draining stage_stream, ssd_detect_host)
+    hipEvent_t ev_stage = nullptr;       // recorded behind the last upload of a call: the PINNED buffer is free again once it has passed
+                                         // (the device image is protected by stream order: the next upload queues behind the forward that reads it)
     // profiling
     bool profiling = false;
     std::vector<EvPair> evs;

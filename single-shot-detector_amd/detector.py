@@ -88,26 +88,51 @@ class Detector:
         batches of up to `max_batch` frames of DIFFERENT source sizes (ssd_forward_mixed_host: per-frame geometry in the first
         kernel, per-image box_scaler in the last), and the results come back in the order of `images` as (boxes, labels, scores)
         per image -- each bit for bit what `self(image, score_threshold)` returns.  The reference loops one `sess.run` per image
-        (inference/evaluate_on_COCO.ipynb:125-150); this is that loop at batch throughput.  Mode f32."""
+        (inference/evaluate_on_COCO.ipynb:125-150); this is that loop at batch throughput.  Mode f32.
+        Batch sizes are `max_batch` and its halvings only (a group of 56 at max_batch 32 runs as 32 + 16 + 8): the library keeps
+        one layer plan per (network shape, batch size), and a stream of arbitrary remainders must not build one for every size.
+        Two batches are in flight: batch k + 1 is staged and uploaded while batch k computes."""
         if self.engine.precision != "f32":
             return [self(im, score_threshold) for im in images]
         imgs = [np.asarray(im) for im in images]
         max_batch = max(1, min(int(max_batch), self.engine.MIXED_MAX))
+        sizes = []
+        b = max_batch
+        while b >= 1:
+            sizes.append(b)
+            b //= 2
         groups = {}
         for i, im in enumerate(imgs):
             if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
                 raise ValueError("every image must be a uint8 array of shape [height, width, 3]")
             groups.setdefault(self.engine.network_shape(im.shape[0], im.shape[1]), []).append(i)
+        parts = []
+        for idx in groups.values():
+            k = 0
+            for b in sizes:
+                while len(idx) - k >= b:
+                    parts.append(idx[k:k + b])
+                    k += b
         out = [None] * len(imgs)
+
+        def consume(pending):
+            slot, part = pending
+            slot["done"].synchronize()
+            boxes, labels, scores, num = slot["host"]
+            for j, i in enumerate(part):
+                n = int(num[j])
+                keep = scores[j][:n] > score_threshold        # inference/detector.py:54-58
+                out[i] = (boxes[j][:n][keep], labels[j][:n][keep], scores[j][:n][keep])
+
         with self.engine.lock:
-            for idx in groups.values():
-                for k in range(0, len(idx), max_batch):
-                    part = idx[k:k + max_batch]
-                    boxes, labels, scores, num = self.engine.detect_host_mixed([imgs[i] for i in part])
-                    for j, i in enumerate(part):
-                        n = int(num[j])
-                        keep = scores[j][:n] > score_threshold        # inference/detector.py:54-58
-                        out[i] = (boxes[j][:n][keep], labels[j][:n][keep], scores[j][:n][keep])
+            pending = None
+            for n, part in enumerate(parts):
+                slot = self.engine.detect_host_mixed([imgs[i] for i in part], wait=False, index=5 + (n & 1))
+                if pending is not None:
+                    consume(pending)
+                pending = (slot, part)
+            if pending is not None:
+                consume(pending)
         return out
 
     def detect_stream(self, batches):

@@ -436,7 +436,7 @@ class Engine:
             block, views = self._new_outputs(torch, B, dev)
             pin_out = torch.empty(block.shape, dtype=torch.int32).pin_memory()
             slot = {"block": block, "views": views, "pin_out": pin_out, "host": self.record_views(pin_out.numpy())}
-            while sum(1 for k in self._static if k[0] == "out") >= 8:
+            while sum(1 for k in self._static if k[0] == "out") >= 32:
                 self._static.pop(next(k for k in self._static if k[0] == "out"))
             self._static[("out", B, index)] = slot
         return slot
@@ -569,10 +569,13 @@ class Engine:
             check(lib().ssd_forward_mixed(self._h, _ptr(flat), B, hw_c, off_c, _ptr(records), _stream(torch)))
             return self.record_views(records)
 
-    def detect_host_mixed(self, images):
+    def detect_host_mixed(self, images, wait=True, index=0):
         """A list of host uint8 arrays [H_b, W_b, 3] of different sizes that share a network shape -> numpy VIEWS of the pinned
         result block (boxes, labels, scores, num_boxes), valid until the next call with this batch size: ONE call of
-        ssd_forward_mixed_host (staging + one upload per frame + the batched forward), one device-to-host copy, one wait."""
+        ssd_forward_mixed_host (staging + one upload per frame + the batched forward), one device-to-host copy, one wait.
+        wait=False: returns the result slot right after enqueuing (slot["done"]: an event behind the copy, slot["host"]: the views
+        it makes valid) -- the caller stages the next batch while this one computes (Detector.detect_many; `index` picks one of
+        several result slots of this batch size)."""
         torch = _torch()
         B = len(images)
         with self.lock:
@@ -580,7 +583,7 @@ class Engine:
             for im in srcs:
                 if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
                     raise ValueError("every image must be a uint8 array of shape [height, width, 3]")
-            slot = self._out_slot(B)
+            slot = self._out_slot(B, index)
             zc = B <= self.zero_copy_max_batch
             rec = slot["pin_out"] if zc else slot["block"]
             ptrs = (ctypes.c_void_p * B)(*[im.ctypes.data for im in srcs])
@@ -588,6 +591,11 @@ class Engine:
             check(lib().ssd_forward_mixed_host(self._h, ptrs, B, hw_c, _ptr(rec), _stream(torch)))
             if not zc:
                 slot["pin_out"].copy_(slot["block"], non_blocking=True)
+            if not wait:
+                if slot.get("done") is None:
+                    slot["done"] = torch.cuda.Event()
+                slot["done"].record()
+                return slot
             torch.cuda.current_stream().synchronize()
             return slot["host"]
 
