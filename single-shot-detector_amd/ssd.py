@@ -603,7 +603,9 @@ class Engine:
         """Host-fed steady-state serving: an iterable of host uint8 arrays [B,H,W,3] (any mix of sizes) -> a generator of
         (boxes, labels, scores, num_boxes) numpy arrays, in order.  Two sets of buffers and two copy streams: the
         host-to-device copy of batch k+1 and the device-to-host copy of the packed outputs of batch k-1 run under the
-        compute of batch k, so the host feed costs (almost) nothing against frames already resident in HBM.  Results are
+        compute of batch k, so the host feed costs (almost) nothing against frames already resident in HBM.  The FIRST two
+        batches of a new batch shape pay for the buffer sets (pinning 2 x 32 MB of host memory takes ~0.3 s for 32 frames of
+        640 x 896): results of those batches arrive late; a serving process sees it once.  Results are
         bit-identical to detect_host on the same batches (same kernels, same order)."""
         torch = _torch()
         dev = torch.device("cuda", self.device)
