@@ -11,6 +11,8 @@ from .config import load_config, INFERENCE_KEYS                       # noqa: F4
 from .variables import (variable_shapes, synthetic_weights, save_weights,   # noqa: F401
                         load_weights)
 from .pb_import import read_frozen_graph, load_pb_weights             # noqa: F401
+from .ckpt_import import (read_checkpoint, read_checkpoint_index, resolve_checkpoint,   # noqa: F401
+                          load_ckpt_weights, crc32c)
 from ._lib import build, lib, lib_path, SsdError, set_option, get_option                       # noqa: F401
 from .ssd import (SSD, AnchorGenerator, RetinaNetFeatureExtractor, RetinaNetBoxPredictor,     # noqa: F401
                   batch_multiclass_non_max_suppression, network_input_size, Engine)

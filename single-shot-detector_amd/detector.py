@@ -4,9 +4,11 @@
     boxes, labels, scores = detector(image_uint8_HW3, score_threshold=0.1)
 
 Same constructor keywords, same return order (boxes, labels, scores), boxes normalised
-[ymin, xmin, ymax, xmax].  `model_path` is this build's weight container (a .npz keyed by
-the reference's TF variable names, see variables.py) instead of a frozen .pb; the JSON
-config is the reference's own file (config_mobilenet.json / config_shufflenet.json).
+[ymin, xmin, ymax, xmax].  `model_path` is the reference's frozen graph (`inference/model.pb`), one of the
+checkpoints its training leaves behind (a `model.ckpt-N` prefix, the `model_dir`, or the SavedModel directory of
+create_pb.py's export/ -- for a user who cannot run create_pb.py without TensorFlow), or this build's own weight
+container (a .npz keyed by the reference's TF variable names, see variables.py); the JSON config is the
+reference's own file (config_mobilenet.json / config_shufflenet.json).
 """
 import json
 import os
@@ -16,16 +18,19 @@ import numpy as np
 from .config import load_config
 from .ssd import Engine, _torch
 from .pb_import import load_pb_weights
+from .ckpt_import import load_ckpt_weights, resolve_checkpoint
 from .variables import load_weights
 
 
 class Detector:
     def __init__(self, model_path, gpu_memory_fraction=0.25, visible_device_list='0',
-                 config=None, precision=None):
+                 config=None, precision=None, use_ema=False):
         """
         Arguments:
-            model_path: path to the reference's frozen graph (.pb, read without TensorFlow),
-                to this build's weight file (.npz), or a dict {variable name: ndarray}.
+            model_path: path to the reference's frozen graph (.pb, read without TensorFlow), to a
+                TensorFlow checkpoint of the reference's training (prefix `model.ckpt-N`, its .index /
+                .data file, the model_dir with its `checkpoint` state file, or a SavedModel directory:
+                ckpt_import.py), to this build's weight file (.npz), or a dict {variable name: ndarray}.
             gpu_memory_fraction: accepted for compatibility and ignored (the library
                 allocates exactly the arena the network needs).
             visible_device_list: a string like the reference's; the first entry is the HIP
@@ -37,17 +42,24 @@ class Detector:
                 2.3x the throughput; should an activation ever leave the fp16 range the call is
                 transparently repeated in f32) or None = the library default (SSD_PRECISION
                 environment variable, else "f32").
+            use_ema: checkpoints only -- take the variables' exponential moving averages (what the
+                evaluation inside train.py restores, model.py:148-161) instead of the raw variables (what
+                create_pb.py freezes: export_savedmodel restores the checkpoint as it is).
         """
         if isinstance(model_path, dict):
             weights = model_path
             if config is None:
                 raise ValueError("config is required when weights are passed as a dict")
         else:
-            if not os.path.exists(model_path):
+            ckpt = None if str(model_path).endswith((".pb", ".npz")) else resolve_checkpoint(model_path)
+            if ckpt is None and not os.path.isfile(model_path):
                 raise FileNotFoundError(model_path)       # tf.gfile.GFile would raise too
             if config is None:
-                config = os.path.join(os.path.dirname(os.path.abspath(model_path)), "config.json")
-            if str(model_path).endswith(".pb"):            # the reference's frozen graph (create_pb.py:57-85)
+                where = model_path if os.path.isdir(model_path) else os.path.dirname(os.path.abspath(model_path))
+                config = os.path.join(where, "config.json")
+            if ckpt is not None:                           # train.py's model_dir / create_pb.py's export folder
+                weights = load_ckpt_weights(ckpt, load_config(config), use_ema=use_ema)
+            elif str(model_path).endswith(".pb"):          # the reference's frozen graph (create_pb.py:57-85)
                 weights = load_pb_weights(model_path, load_config(config))
             else:
                 weights = load_weights(model_path)

@@ -273,6 +273,29 @@ def test_detector_drop_in(cuda, ssd, oracle_graph, tmp_path):
     det_pb2 = ssd.Detector(str(tmp_path / "official.pb"), config=str(tmp_path / "config.json"))
     b4, l4, s4 = det_pb2(img, score_threshold=0.2)
     assert np.array_equal(b4, boxes) and np.array_equal(l4, labels) and np.array_equal(s4, scores)
+    # what the reference's TRAINING leaves behind, for a user without TensorFlow to run create_pb.py with: the model_dir
+    # (checkpoint state file -> model.ckpt-N.index / .data shards, the Saver's optimizer slots and moving averages beside
+    # the variables) and the SavedModel folder of create_pb.py:27-52 (ckpt_import.py)
+    from helpers.tf_bundle_writer import write_bundle, crc32c_bytewise
+    crc = (lambda raw: crc32c_bytewise(raw) if len(raw) < 32768 else ssd.crc32c(raw))
+    mdir = tmp_path / "run00"
+    mdir.mkdir()
+    ema = {k + "/ExponentialMovingAverage": (v * np.float32(1.25)) for k, v in Wt.items() if not k.endswith(("moving_mean", "moving_variance"))}
+    slots = {"optimizer/" + k + "/Adam": np.zeros_like(v) for k, v in list(Wt.items())[::25]}
+    write_bundle(str(mdir / "model.ckpt-1200"), {**Wt, **ema, **slots, "global_step": np.array(1200, np.int64)}, num_shards=2,
+                 block_size=2048, fast_crc=crc)
+    (mdir / "checkpoint").write_text('model_checkpoint_path: "model.ckpt-1200"\nall_model_checkpoint_paths: "model.ckpt-1200"\n')
+    with open(mdir / "config.json", "w") as f:
+        json.dump(params, f)
+    for where in (str(mdir), str(mdir / "model.ckpt-1200")):
+        det_ck = ssd.Detector(where)
+        b5, l5, s5 = det_ck(img, score_threshold=0.2)
+        assert np.array_equal(b5, boxes) and np.array_equal(l5, labels) and np.array_equal(s5, scores)
+    det_ema = ssd.Detector(str(mdir), use_ema=True)          # the averages are other weights: other detections
+    b6, l6, s6 = det_ema(img, score_threshold=0.2)
+    We = {k: ema.get(k + "/ExponentialMovingAverage", v) for k, v in Wt.items()}
+    rbe, rle, rse = oracle_graph.detector_call(oracle_graph.forward(img[None], We, ssd.load_config(params)), 0.2)
+    assert np.array_equal(l6, rle) and np.array_equal(s6, rse) and np.array_equal(b6, rbe) and not np.array_equal(s6, scores)
     # SSD mirror (ssd.py:10-69): raw predictions + get_predictions with other thresholds
     s = ssd.SSD(cuda.from_numpy(img[None].copy()).cuda(), det.engine)
     pred = s.get_predictions(score_threshold=0.3, iou_threshold=0.5, max_boxes_per_class=10)

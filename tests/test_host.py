@@ -113,6 +113,168 @@ def test_frozen_graph_reader_against_the_official_protobuf_encoder(ssd, unpacked
         ssd.read_frozen_graph(data[:len(data) // 3 + 1])
 
 
+def _train_like_checkpoint(ssd, W, rng):
+    """What a train.py run's Saver holds next to the model's variables: global_step (int64), Adam's slots and power
+    accumulators (model.py:115-118), the moving averages of the trainable variables (model.py:124-127)."""
+    extra = {"global_step": np.array(150000, np.int64), "optimizer/beta1_power": np.array(0.0, np.float32),
+             "optimizer/beta2_power": np.array(0.5, np.float32)}
+    ema = {}
+    for i, (k, v) in enumerate(W.items()):
+        leaf = k.rsplit("/", 1)[1]
+        if leaf not in ("moving_mean", "moving_variance"):
+            if v.size <= 4096 or i % 16 == 0:                # (slots of every small variable and of a sample of the large ones)
+                extra["optimizer/" + k + "/Adam"] = np.zeros_like(v)
+                extra["optimizer/" + k + "/Adam_1"] = np.zeros_like(v)
+            ema[k] = (v + np.float32(1e-3)).astype(np.float32)
+            extra[k + "/ExponentialMovingAverage"] = ema[k]
+    return extra, ema
+
+
+def _hybrid_crc(ssd):
+    """The writer's own byte loop for tensors below 32 KB (hundreds of batch-norm vectors and small kernels), the product's
+    many-lane CRC -- pinned against that byte loop in test_crc32c_known_answers -- for the large ones (5 MB/s would cost minutes)."""
+    from helpers.tf_bundle_writer import crc32c_bytewise
+    return lambda raw: crc32c_bytewise(raw) if len(raw) < 32768 else ssd.crc32c(raw)
+
+
+def test_crc32c_known_answers(ssd):
+    """CRC-32C (Castagnoli) check values: "123456789" and the iSCSI vectors of RFC 3720 B.4; the many-lane numpy path
+    against the byte loop on ragged lengths; continuation from a previous value."""
+    assert ssd.crc32c(b"123456789") == 0xE3069283 and ssd.crc32c(b"") == 0
+    assert ssd.crc32c(bytes(32)) == 0x8A9136AA and ssd.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert ssd.crc32c(bytes(range(32))) == 0x46DD794E and ssd.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
+    from helpers.tf_bundle_writer import crc32c_bytewise
+    rng = np.random.default_rng(0)
+    for n in (1, 16383, 16384, 16385, 70001, 262144 + 5):
+        d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert ssd.crc32c(d) == crc32c_bytewise(d), n
+        assert ssd.crc32c(d[n // 3:], ssd.crc32c(d[:n // 3])) == crc32c_bytewise(d)
+    a = rng.normal(size=(3, 3, 64, 96)).astype(np.float32)
+    assert ssd.crc32c(a) == crc32c_bytewise(a.tobytes())
+
+
+@pytest.mark.parametrize("num_shards,block_size,restart_interval", [(1, 4096, 16), (3, 300, 2), (2, 1 << 20, 16)])
+def test_checkpoint_reader(ssd, tmp_path, num_shards, block_size, restart_interval):
+    """A V2 checkpoint (tensor bundle) read without TensorFlow: the .index table in one block and in many (prefix-compressed
+    keys across restart points), one and several data shards, the Saver's other tensors stepped over, raw variables
+    (create_pb.py's choice) and moving averages (train.py's evaluation, model.py:148-161), the three places a user has
+    one: a prefix, the model_dir's `checkpoint` state file, a SavedModel directory."""
+    from helpers.tf_bundle_writer import write_bundle
+    p = {"backbone": "shufflenet", "depth_multiplier": 0.5, "num_classes": 2, "score_threshold": 0.1,
+         "iou_threshold": 0.5, "max_boxes_per_class": 5, "min_dimension": 128}
+    rng = np.random.default_rng(7)
+    W = ssd.synthetic_weights(p, seed=4)
+    extra, ema = _train_like_checkpoint(ssd, W, rng)
+    mdir = tmp_path / "run00"
+    mdir.mkdir()
+    prefix = str(mdir / "model.ckpt-150000")
+    nblocks = write_bundle(prefix, {**W, **extra}, num_shards=num_shards, block_size=block_size, restart_interval=restart_interval,
+                           strings=("_CHECKPOINTABLE_OBJECT_GRAPH",), sliced=("optimizer/beta2_power",), fast_crc=_hybrid_crc(ssd))
+    assert (nblocks > 20) == (block_size == 300)
+    header, entries = ssd.read_checkpoint_index(prefix)
+    assert header["num_shards"] == num_shards and set(entries) == set(W) | set(extra) | {"_CHECKPOINTABLE_OBJECT_GRAPH"}
+    e = entries["fpn/p6/kernel"]
+    assert e["dtype"] == 1 and e["shape"] == W["fpn/p6/kernel"].shape and e["size"] == W["fpn/p6/kernel"].nbytes
+    allv = ssd.read_checkpoint(prefix)
+    assert "_CHECKPOINTABLE_OBJECT_GRAPH" not in allv and "optimizer/beta2_power" not in allv
+    assert allv["global_step"].dtype == np.int64 and allv["global_step"].shape == () and int(allv["global_step"]) == 150000
+    L = ssd.load_ckpt_weights(prefix, p)
+    assert set(L) == set(W) and all(np.array_equal(W[k], L[k]) and L[k].dtype == np.float32 and L[k].flags.c_contiguous for k in W)
+    E = ssd.load_ckpt_weights(prefix, p, use_ema=True)
+    assert all(np.array_equal(E[k], ema.get(k, W[k])) for k in W) and any(not np.array_equal(E[k], W[k]) for k in ema)
+    # the places a checkpoint is found
+    (mdir / "checkpoint").write_text('model_checkpoint_path: "model.ckpt-150000"\nall_model_checkpoint_paths: "model.ckpt-100\n')
+    for where in (str(mdir), prefix + ".index", "%s.data-00000-of-%05d" % (prefix, num_shards)):
+        assert ssd.resolve_checkpoint(where) == prefix
+    assert ssd.resolve_checkpoint(str(tmp_path)) is None and ssd.resolve_checkpoint(str(tmp_path / "nothing")) is None
+    sm = tmp_path / "export" / "1546300800" / "variables"
+    sm.mkdir(parents=True)
+    write_bundle(str(sm / "variables"), W, block_size=block_size, fast_crc=_hybrid_crc(ssd))
+    for where in (str(tmp_path / "export"), str(tmp_path / "export" / "1546300800")):
+        assert ssd.resolve_checkpoint(where) == str(sm / "variables")
+        S = ssd.load_ckpt_weights(where, p)
+        assert all(np.array_equal(W[k], S[k]) for k in W)
+    with pytest.raises(KeyError):
+        ssd.read_checkpoint(prefix, ["no/such/variable"])
+    with pytest.raises(ValueError):
+        ssd.read_checkpoint(prefix, ["optimizer/beta2_power"])          # a partitioned variable's entry
+    missing = dict(W)
+    del missing["fpn/lateral4/kernel"]
+    write_bundle(str(tmp_path / "partial"), missing, fast_crc=_hybrid_crc(ssd))
+    with pytest.raises(KeyError):
+        ssd.load_ckpt_weights(str(tmp_path / "partial"), p)
+    with pytest.raises(FileNotFoundError):
+        ssd.load_ckpt_weights(str(tmp_path / "nothing"), p)
+
+
+def test_convert_any_container_to_npz(ssd, tmp_path):
+    """`python -m ssd_amd.convert` -- the place of create_pb.py: .pb / checkpoint / model_dir / .npz -> the .npz the Detector
+    loads, checked against the architecture the config names."""
+    import importlib
+    import json
+    import subprocess
+    from helpers.tf_bundle_writer import write_bundle
+    convert = importlib.import_module("ssd_amd.convert")
+    p = {"backbone": "mobilenet", "depth_multiplier": 0.25, "num_classes": 3, "score_threshold": 0.1,
+         "iou_threshold": 0.5, "max_boxes_per_class": 5, "min_dimension": 128}
+    W = ssd.synthetic_weights(p, seed=2)
+    json.dump(p, open(tmp_path / "config.json", "w"))
+    ema = {k + "/ExponentialMovingAverage": v + np.float32(0.5) for k, v in W.items() if k.endswith("gamma")}
+    write_bundle(str(tmp_path / "model.ckpt-9"), {**W, **ema}, fast_crc=_hybrid_crc(ssd))
+    write_frozen_graph(W, str(tmp_path / "model.pb"))
+    for src in ("model.ckpt-9", "model.pb"):
+        assert convert.main([str(tmp_path / src), str(tmp_path / "config.json"), str(tmp_path / "out.npz")]) == 0
+        L = ssd.load_weights(str(tmp_path / "out.npz"))
+        assert set(L) == set(W) and all(np.array_equal(L[k], W[k]) for k in W)
+    r = subprocess.run([sys.executable, "-m", "ssd_amd.convert", str(tmp_path / "model.ckpt-9"), str(tmp_path / "config.json"),
+                        str(tmp_path / "ema.npz"), "--ema"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0 and "variables" in r.stdout, r.stderr
+    E = ssd.load_weights(str(tmp_path / "ema.npz"))
+    assert all(np.array_equal(E[k], ema.get(k + "/ExponentialMovingAverage", W[k])) for k in W)
+    assert convert.main([str(tmp_path / "ema.npz"), str(tmp_path / "config.json"), str(tmp_path / "again.npz")]) == 0
+    assert convert.main([]) == 2
+    with pytest.raises(ValueError):
+        convert.load_any(str(tmp_path / "out.npz"), dict(p, num_classes=4))
+    with pytest.raises(FileNotFoundError):
+        convert.load_any(str(tmp_path / "nothing"), p)
+
+
+def test_checkpoint_reader_detects_damage(ssd, tmp_path):
+    """What TensorFlow's BundleReader reports as DataLoss: a flipped bit in an index block, in a tensor's bytes, a truncated
+    index, a missing shard, a file that is no table at all."""
+    from helpers.tf_bundle_writer import write_bundle, write_table
+    rng = np.random.default_rng(3)
+    T = {"a/weights": rng.normal(size=(3, 3, 8, 16)).astype(np.float32), "a/BatchNorm/beta": rng.normal(size=(16,)).astype(np.float32),
+         "b/kernel": rng.normal(size=(70000,)).astype(np.float32)}
+    prefix = str(tmp_path / "m")
+    write_bundle(prefix, T, block_size=64)
+    good = ssd.read_checkpoint(prefix)
+    assert all(np.array_equal(good[k], T[k]) for k in T)
+    idx = open(prefix + ".index", "rb").read()
+    bad = bytearray(idx)
+    bad[20] ^= 0x04
+    open(prefix + ".index", "wb").write(bytes(bad))
+    with pytest.raises(ValueError, match="checksum"):
+        ssd.read_checkpoint(prefix)
+    open(prefix + ".index", "wb").write(idx[:len(idx) - 9])
+    with pytest.raises(ValueError):
+        ssd.read_checkpoint(prefix)
+    open(prefix + ".index", "wb").write(idx)
+    data = bytearray(open(prefix + ".data-00000-of-00001", "rb").read())
+    data[len(data) // 2] ^= 0x10                                     # inside b/kernel (the lanes path of the CRC)
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
+    with pytest.raises(ValueError, match="b/kernel"):
+        ssd.read_checkpoint(prefix)
+    assert np.array_equal(ssd.read_checkpoint(prefix, ["a/weights"])["a/weights"], T["a/weights"])
+    assert not np.array_equal(ssd.read_checkpoint(prefix, verify=False)["b/kernel"], T["b/kernel"])
+    os.remove(prefix + ".data-00000-of-00001")
+    with pytest.raises(FileNotFoundError):
+        ssd.read_checkpoint(prefix)
+    open(str(tmp_path / "v1.index"), "wb").write(b"\x00" * 100)
+    with pytest.raises(ValueError, match="not a TensorFlow checkpoint index"):
+        ssd.read_checkpoint(str(tmp_path / "v1"))
+
+
 def test_coco_records(ssd):
     """evaluate_on_COCO.ipynb cell 10 record construction (no GPU: a stub detector)."""
     def det(image, score_threshold=0.15):
