@@ -101,15 +101,20 @@ def latency_batch1(detector):
     `Detector.__call__(image, score_threshold=0.5)` on one host uint8 image (pinned staging + H2D, graph, ONE packed
     D2H, score filter; numpy in -> numpy out), first 10 dropped."""
     img = np.random.default_rng(0).integers(0, 256, (H, W, 3), dtype=np.uint8)
-    times = []
-    for _ in range(110):
-        t0 = time.perf_counter()
-        boxes, labels, scores = detector(img, score_threshold=0.5)
-        times.append(time.perf_counter() - t0)
-    t = np.array(times[10:]) * 1e3
-    return {"p50_ms": float(np.percentile(t, 50)), "mean_ms": float(t.mean()), "std_ms": float(t.std()),
-            "protocol": "Detector.__call__, host ndarray in -> filtered numpy out, 110 calls, first 10 dropped",
-            "detections_over_0.5": int(len(scores))}
+    runs = []
+    for _ in range(3):          # the protocol three times: a busy host (another tenant's burst) shows as one run apart from the others
+        times = []
+        for _ in range(110):
+            t0 = time.perf_counter()
+            boxes, labels, scores = detector(img, score_threshold=0.5)
+            times.append(time.perf_counter() - t0)
+        t = np.array(times[10:]) * 1e3
+        runs.append({"p50_ms": float(np.percentile(t, 50)), "mean_ms": float(t.mean()), "std_ms": float(t.std())})
+    mid = sorted(runs, key=lambda r: r["p50_ms"])[1]
+    return dict(mid, runs_p50_ms=[r["p50_ms"] for r in runs],
+                protocol="Detector.__call__, host ndarray in -> filtered numpy out, 110 calls, first 10 dropped; the protocol run "
+                         "three times, the run with the median p50 reported (all three p50s in runs_p50_ms)",
+                **{"detections_over_0.5": int(len(scores))})
 
 
 # (height, width) of frequent COCO val2017 frames, portrait and landscape, plus one at the network's own size

@@ -17,5 +17,5 @@ from ._lib import build, lib, lib_path, SsdError, set_option, get_option        
 from .ssd import (SSD, AnchorGenerator, RetinaNetFeatureExtractor, RetinaNetBoxPredictor,     # noqa: F401
                   batch_multiclass_non_max_suppression, network_input_size, Engine)
 from .detector import Detector                                         # noqa: F401
-from . import coco_eval                                                # noqa: F401
+from . import coco_eval, coco_metric                                   # noqa: F401
 from .distributed import shard_range, all_gather_detections, detect_sharded, bind_to_gpu_numa_node  # noqa: F401

@@ -1,9 +1,9 @@
 """COCO val2017 evaluation harness around `Detector` -- the product-side mirror of the
 reference's inference/evaluate_on_COCO.ipynb (cells 6-17) -- and the VOC-style AP@IoU
 self-check of the reference's metrics.py:156-282 (`Evaluator`, `evaluate_detector`).
-No COCO images, annotations or pycocotools exist offline, so the tests exercise the record
-construction and the AP self-check on synthetic data; `evaluate` needs pycocotools and the
-dataset on disk.
+No COCO images or annotations exist offline, so the tests run the harness on synthetic scenes;
+`evaluate` needs the dataset on disk and nothing else: the COCO statistics of cell 17 come from
+coco_metric.py, this build's restatement of pycocotools' COCOeval for boxes.
 
 Label ids: the detector's integer label i is line i of the reference's data/coco_labels.txt,
 which is the standard 80-name COCO order (COCO_NAMES below); the official category ids come
@@ -60,29 +60,34 @@ def detection_records_many(detector, images, image_ids, label_to_coco_id, score_
     return out
 
 
-def evaluate(detector, annotations_json, images_dir, read_image, predictions_json="coco_predictions.json"):
-    """Cells 4-17 end to end; `read_image(path) -> uint8 RGB ndarray`.  Needs pycocotools."""
+def evaluate(detector, annotations_json, images_dir, read_image=None, predictions_json="coco_predictions.json", out=None,
+             score_threshold=0.15, max_batch=32):
+    """Cells 4-17 end to end: every image of the annotation file through the detector (score_threshold 0.15, cell 10), the
+    results written as `predictions_json` (cell 11), then the twelve COCO box statistics (cell 17: COCOeval over all image and
+    category ids) -- computed by coco_metric.py, this build's restatement of pycocotools' COCOeval (not installed here, not
+    vendored by the reference).  `annotations_json`: path of instances_val2017.json or its dict; `read_image(path) -> uint8 RGB
+    ndarray`, default PIL (the notebook reads with cv2 and converts BGR -> RGB: the same array for a JPEG); `out`: a stream for
+    the summary table.  Returns the statistics in coco_metric.STAT_NAMES order (AP, AP50, AP75, APs, APm, APl, AR1, ...)."""
     import os
-    from pycocotools.coco import COCO
-    from pycocotools.cocoeval import COCOeval
-    coco = COCO(annotations_json)
-    mapping = integer_to_coco_id(coco.loadCats(coco.getCatIds()))
-    img_ids = coco.getImgIds()
+    from . import coco_metric
+    if read_image is None:
+        from PIL import Image
+
+        def read_image(path):
+            return np.asarray(Image.open(path).convert("RGB"))
+    gt = json.load(open(annotations_json)) if isinstance(annotations_json, str) else annotations_json
+    mapping = integer_to_coco_id(gt["categories"])
+    metas = sorted(gt["images"], key=lambda m: m["id"])
     results = []
     chunk = 256           # images read, then detected as batches grouped by network shape (the notebook's loop, one image per sess.run, at batch throughput)
-    for k in range(0, len(img_ids), chunk):
-        metas = [coco.loadImgs(i)[0] for i in img_ids[k:k + chunk]]
-        images = [read_image(os.path.join(images_dir, m["file_name"])) for m in metas]
-        results += detection_records_many(detector, images, [m["id"] for m in metas], mapping)
-    with open(predictions_json, "w") as f:
-        json.dump(results, f)
-    ev = COCOeval(cocoGt=coco, cocoDt=coco.loadRes(predictions_json), iouType="bbox")
-    ev.params.imgIds = img_ids
-    ev.params.catIds = coco.getCatIds()
-    ev.evaluate()
-    ev.accumulate()
-    ev.summarize()
-    return ev.stats
+    for k in range(0, len(metas), chunk):
+        part = metas[k:k + chunk]
+        images = [read_image(os.path.join(images_dir, m["file_name"])) for m in part]
+        results += detection_records_many(detector, images, [m["id"] for m in part], mapping, score_threshold, max_batch)
+    if predictions_json:
+        with open(predictions_json, "w") as f:
+            json.dump(results, f)
+    return coco_metric.evaluate_boxes(gt, results, out=out)
 
 
 # ----------------------------------------------------------------------------- VOC-style AP self-check

@@ -65,6 +65,42 @@ def test_coco_records_and_voc_ap_through_the_real_detector(cuda, ssd, oracle_gra
             assert m_gpu[c]["AP"] > 0.0
 
 
+def test_coco_evaluation_end_to_end_without_pycocotools(cuda, ssd, oracle_graph, tmp_path):
+    """evaluate_on_COCO.ipynb cells 4-17 on a synthetic "dataset" on disk (images of five sizes as PNG, an annotation file whose
+    objects are the oracle's detections above 0.3): the real Detector through coco_eval.evaluate -- files read, batched by network
+    shape, records written, the twelve COCO statistics from coco_metric.py -- equals the same harness driven by the CPU oracle,
+    number for number; every annotated object is found ahead of every unannotated detection, so AP = AR@100 = 1."""
+    import json
+    from PIL import Image
+    Wt = ssd.synthetic_weights(PARAMS, seed=3, logits_bias=-4.0)
+    det = ssd.Detector(Wt, config=PARAMS)
+    ora = OracleDetector(oracle_graph, Wt, ssd.load_config(PARAMS))
+    cats = [{"id": i + 1 + (i > 10), "name": n} for i, n in enumerate(ssd.coco_eval.COCO_NAMES)]
+    mapping = ssd.coco_eval.integer_to_coco_id(cats)
+    rng = np.random.default_rng(23)
+    images, anns = [], []
+    for k, shape in enumerate([(128, 128, 3), (100, 151, 3), (300, 128, 3), (97, 203, 3), (128, 200, 3), (100, 151, 3)]):
+        im = rng.integers(0, 256, shape, dtype=np.uint8)
+        name = "%012d.png" % (k + 1)
+        Image.fromarray(im).save(str(tmp_path / name))
+        images.append({"id": 1000 + k, "file_name": name, "height": shape[0], "width": shape[1]})
+        for r in ssd.coco_eval.detection_records(ora, im, 1000 + k, mapping, score_threshold=0.3):
+            x, y, w, h = r["bbox"]
+            if w > 0 and h > 0:
+                anns.append({"id": len(anns) + 1, "image_id": r["image_id"], "category_id": r["category_id"], "bbox": r["bbox"],
+                             "area": float(w * h), "iscrowd": 0})
+    gt = {"images": images, "annotations": anns, "categories": cats}
+    with open(tmp_path / "instances.json", "w") as f:
+        json.dump(gt, f)
+    assert len(anns) > 30
+    st_gpu = ssd.coco_eval.evaluate(det, str(tmp_path / "instances.json"), str(tmp_path), predictions_json=str(tmp_path / "pred_gpu.json"), max_batch=4)
+    st_ora = ssd.coco_eval.evaluate(ora, gt, str(tmp_path), predictions_json=str(tmp_path / "pred_ora.json"))
+    assert np.array_equal(st_gpu, st_ora)
+    assert json.load(open(tmp_path / "pred_gpu.json")) == json.load(open(tmp_path / "pred_ora.json"))
+    # identical boxes of one category in one image (integer truncation) could only swap partners, never lose one
+    assert st_gpu[0] == 1.0 and st_gpu[1] == 1.0 and st_gpu[8] == 1.0, st_gpu
+
+
 def test_ssd_mirror_reference_signature_any_image_size(cuda, ssd, oracle_graph):
     """SSD(images, feature_extractor, anchor_generator, box_predictor, num_classes) (detector/ssd.py:10) on frames that the
     serving graph resizes and pads (100x151 -> 128x256): anchors for the NETWORK's size, predictions == the oracle's."""

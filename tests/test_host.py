@@ -288,6 +288,177 @@ def test_coco_records(ssd):
     assert recs[1]["bbox"] == [0, 0, 640, 480] and recs[1]["category_id"] == 81
 
 
+def _coco_gt(boxes_by_image_cat, crowd=(), areas=None):
+    """{(image, category): [xywh, ...]} -> an annotation-file dict (ids from 1, area = w * h unless given)."""
+    imgs = sorted({k[0] for k in boxes_by_image_cat})
+    cats = sorted({k[1] for k in boxes_by_image_cat})
+    anns = []
+    for (img, cat), boxes in sorted(boxes_by_image_cat.items()):
+        for j, b in enumerate(boxes):
+            aid = len(anns) + 1
+            anns.append({"id": aid, "image_id": img, "category_id": cat, "bbox": list(b), "iscrowd": int((img, cat, j) in crowd),
+                         "area": float(b[2] * b[3]) if areas is None else float(areas[(img, cat, j)])})
+    return {"images": [{"id": i} for i in imgs], "categories": [{"id": c, "name": str(c)} for c in cats], "annotations": anns}
+
+
+def test_coco_box_metric_known_answers(ssd):
+    """coco_metric.py (cocoapi's COCOeval for boxes, restated: evaluate_on_COCO.ipynb cell 17) on cases worked by hand."""
+    cm = ssd.coco_metric
+    assert np.allclose(cm.IOU_THRS, [0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8, 0.85, 0.9, 0.95]) and len(cm.REC_THRS) == 101
+    # IoU: xywh, no overlap -> 0, touching edges -> 0, crowd -> intersection / detection area
+    iou = cm.bbox_iou([[0, 0, 10, 10], [20, 20, 5, 5], [10, 0, 10, 10]], [[0, 0, 10, 5], [0, 0, 100, 100]], [0, 1])
+    assert np.allclose(iou, [[0.5, 1.0], [0.0, 1.0], [0.0, 1.0]])
+    # (1) two objects; detections: IoU 0.81 with the first (score .9), a false positive (.8), IoU 0.62 with the second (.7).
+    #     t <= 0.60: TP FP TP -> precision envelope 1, 2/3, 2/3 at recall .5, .5, 1 -> (51 + 50 * 2/3) / 101;
+    #     0.65 .. 0.80: TP FP FP -> 51 / 101;  0.85 ..: nothing matches -> 0
+    gt = _coco_gt({(1, 7): [[0, 0, 100, 100], [200, 0, 100, 100]]})
+    dt = [{"image_id": 1, "category_id": 7, "bbox": [0, 0, 100, 81], "score": 0.9},
+          {"image_id": 1, "category_id": 7, "bbox": [500, 500, 50, 50], "score": 0.8},
+          {"image_id": 1, "category_id": 7, "bbox": [200, 0, 100, 62], "score": 0.7}]
+    st = cm.evaluate_boxes(gt, dt)
+    lo, mid = (51 + 50 * 2 / 3) / 101, 51 / 101
+    assert np.isclose(st[0], (3 * lo + 4 * mid) / 10) and np.isclose(st[1], lo) and np.isclose(st[2], mid)
+    # both objects are "large" (area 10 000 > 96^2); in that range the stray 50 x 50 detection is out of range and unmatched, i.e.
+    # ignored: t <= 0.60 -> TP TP -> 1;  0.65 .. 0.80 -> TP FP -> 51 / 101
+    assert st[3] == -1 and st[4] == -1 and np.isclose(st[5], (3 * 1.0 + 4 * mid) / 10)
+    assert np.isclose(st[6], (7 * 0.5) / 10) and np.isclose(st[8], (3 * 1.0 + 4 * 0.5) / 10)     # AR@1: only the best detection counts
+    # the order of the result list does not matter, the scores do: with the false positive ranked first the precisions are
+    # 0, 1/2, 2/3 -- the envelope from the right lifts them all to 2/3, at every recall point
+    dt2 = [dict(dt[1], score=0.95), dt[2], dt[0]]
+    st2 = cm.evaluate_boxes(gt, dt2)
+    assert np.isclose(st2[1], 2 / 3) and st2[0] < st[0]
+    # (2) perfect detections over images / categories: every defined statistic is 1, the empty area ranges are -1
+    boxes = {(i, c): [[10 * c, 5 * i, 40, 50]] for i in (1, 2, 3) for c in (1, 2)}
+    gt = _coco_gt(boxes)
+    dt = [{"image_id": i, "category_id": c, "bbox": b[0], "score": 0.5 + 0.01 * i} for (i, c), b in boxes.items()]
+    st = cm.evaluate_boxes(gt, dt)
+    assert np.allclose(st[[0, 1, 2, 4, 6, 7, 8, 10]], 1.0) and np.all(st[[3, 5, 9, 11]] == -1)      # 40 x 50 = medium
+    # a category without groundtruth does not enter the mean; detections of it on its own would only be false positives
+    st3 = cm.evaluate_boxes(dict(gt, categories=gt["categories"] + [{"id": 9, "name": "9"}]), dt + [{"image_id": 1, "category_id": 9, "bbox": [0, 0, 5, 5], "score": 0.9}])
+    assert np.allclose(st3[[0, 1, 2]], 1.0)
+    # (3) a crowd region: detections inside it are neither true nor false positives, and it is not an object to find
+    gt = _coco_gt({(1, 1): [[0, 0, 50, 50], [100, 100, 200, 200]]}, crowd={(1, 1, 1)})
+    dt = [{"image_id": 1, "category_id": 1, "bbox": [120, 120, 30, 30], "score": 0.99},
+          {"image_id": 1, "category_id": 1, "bbox": [150, 150, 30, 30], "score": 0.98},
+          {"image_id": 1, "category_id": 1, "bbox": [0, 0, 50, 50], "score": 0.5},
+          {"image_id": 1, "category_id": 1, "bbox": [400, 400, 30, 30], "score": 0.4}]
+    st = cm.evaluate_boxes(gt, dt)
+    assert np.isclose(st[0], 1.0) and np.isclose(st[8], 1.0)
+    # (4) maxDets: three objects of one category in one image, three perfect detections: AR@1 = 1/3
+    gt = _coco_gt({(1, 1): [[0, 0, 40, 40], [100, 0, 40, 40], [200, 0, 40, 40]]})
+    dt = [{"image_id": 1, "category_id": 1, "bbox": a["bbox"], "score": sc} for a, sc in zip(gt["annotations"], (0.9, 0.8, 0.7))]
+    st = cm.evaluate_boxes(gt, dt)
+    assert np.isclose(st[6], 1 / 3) and np.isclose(st[7], 1.0) and np.isclose(st[0], 1.0)
+    # (5) area ranges: a small object (annotation area 900) and a large one; the detection of the large one is ignored in the
+    #     "small" range (unmatched there and itself out of range), the small object's detection is ignored in "large"
+    gt = _coco_gt({(1, 1): [[0, 0, 30, 30], [100, 100, 120, 120]]})
+    dt = [{"image_id": 1, "category_id": 1, "bbox": [0, 0, 30, 30], "score": 0.6}, {"image_id": 1, "category_id": 1, "bbox": [100, 100, 120, 120], "score": 0.9}]
+    st = cm.evaluate_boxes(gt, dt)
+    assert np.isclose(st[3], 1.0) and st[4] == -1 and np.isclose(st[5], 1.0) and np.isclose(st[0], 1.0)
+    # ... and a MISSED small object shows in APs / ARs only
+    st = cm.evaluate_boxes(gt, dt[1:])
+    assert np.isclose(st[3], 0.0) and np.isclose(st[9], 0.0) and np.isclose(st[5], 1.0) and np.isclose(st[8], 0.5)
+    with pytest.raises(ValueError):
+        cm.evaluate_boxes(gt, [{"image_id": 99, "category_id": 1, "bbox": [0, 0, 1, 1], "score": 1.0}])
+    import io
+    buf = io.StringIO()
+    cm.evaluate_boxes(gt, dt, out=buf)
+    assert buf.getvalue().count("\n") == 12 and "Average Precision  (AP) @[ IoU=0.50:0.95 | area=   all | maxDets=100 ] = 1.000" in buf.getvalue()
+
+
+def test_coco_evaluate_harness_reads_files_and_scores(ssd, tmp_path):
+    """coco_eval.evaluate (evaluate_on_COCO.ipynb cells 4-17) with a stand-in detector, no GPU: annotation file and images from
+    disk, label -> category id through the names, pixel xywh records, predictions file, the COCO statistics."""
+    import json
+    from PIL import Image
+    cats = [{"id": i + 1 + (i > 10), "name": n} for i, n in enumerate(ssd.coco_eval.COCO_NAMES)]
+    images = []
+    for k, (h, w) in enumerate([(100, 200), (80, 80)]):
+        Image.fromarray(np.full((h, w, 3), 10 * k, np.uint8)).save(str(tmp_path / ("%d.png" % k)))
+        images.append({"id": 5 + k, "file_name": "%d.png" % k, "height": h, "width": w})
+    anns = [{"id": 1, "image_id": 5, "category_id": 1, "bbox": [20, 10, 100, 50], "area": 5000.0, "iscrowd": 0},      # person
+            {"id": 2, "image_id": 6, "category_id": 18, "bbox": [8, 8, 40, 40], "area": 1600.0, "iscrowd": 0}]        # dog (label 16)
+    gt = {"images": images, "annotations": anns, "categories": cats}
+    seen = []
+
+    def det(image, score_threshold=0.15):
+        seen.append((image.shape, score_threshold, int(image[0, 0, 0])))
+        if image.shape[0] == 100:        # normalised ymin, xmin, ymax, xmax: the person exactly, plus a stray dog
+            return (np.array([[0.1, 0.1, 0.6, 0.6], [0.5, 0.5, 0.9, 0.9]], np.float32), np.array([0, 16], np.int32), np.array([0.9, 0.4], np.float32))
+        return (np.array([[0.1, 0.1, 0.6, 0.6]], np.float32), np.array([16], np.int32), np.array([0.3], np.float32))
+    st = ssd.coco_eval.evaluate(det, gt, str(tmp_path), predictions_json=str(tmp_path / "pred.json"))
+    assert seen == [((100, 200, 3), 0.15, 0), ((80, 80, 3), 0.15, 10)]
+    pred = json.load(open(tmp_path / "pred.json"))
+    assert pred[0] == {"image_id": 5, "category_id": 1, "bbox": [20, 10, 100, 50], "score": float(np.float32(0.9))}
+    assert pred[2]["category_id"] == 18 and pred[2]["bbox"] == [8, 8, 40, 40]
+    # person: AP 1.  dog: the stray (0.4) outranks the hit (0.3): precision 1/2 at every recall.  Mean over the two categories.
+    assert np.isclose(st[0], 0.75) and np.isclose(st[1], 0.75) and np.isclose(st[8], 1.0)
+
+
+def _brute_force_ap(gt, dt, thr):
+    """AP at one IoU threshold straight from the definition, written independently of coco_metric.py (no crowd, all areas,
+    fewer than 100 detections per image and category): detections in descending score take the free groundtruth box of highest
+    IoU >= thr in their image; AP = mean over the 101 recall points r of the best precision at any rank whose recall >= r;
+    mean over the categories that have groundtruth."""
+    def iou(a, b):
+        w = min(a[0] + a[2], b[0] + b[2]) - max(a[0], b[0])
+        h = min(a[1] + a[3], b[1] + b[3]) - max(a[1], b[1])
+        if w <= 0 or h <= 0:
+            return 0.0
+        return w * h / (a[2] * a[3] + b[2] * b[3] - w * h)
+    aps, recalls = [], []
+    for cat in sorted({c["id"] for c in gt["categories"]}):
+        g = [a for a in gt["annotations"] if a["category_id"] == cat]
+        if not g:
+            continue
+        taken = set()
+        hits = []
+        for d in sorted((d for d in dt if d["category_id"] == cat), key=lambda d: -d["score"]):
+            cands = [(iou(d["bbox"], a["bbox"]), a["id"]) for a in g if a["image_id"] == d["image_id"] and a["id"] not in taken]
+            cands = [c for c in cands if c[0] >= thr]
+            if cands:
+                taken.add(max(cands)[1])
+            hits.append(bool(cands))
+        tp = np.cumsum(hits)
+        prec = tp / (np.arange(len(hits)) + 1.0) if hits else np.zeros(0)
+        rec = tp / len(g) if hits else np.zeros(0)
+        aps.append(np.mean([max([p for p, r in zip(prec, rec) if r >= x], default=0.0) for x in np.linspace(0, 1, 101)]))
+        recalls.append(rec[-1] if hits else 0.0)
+    return float(np.mean(aps)), float(np.mean(recalls))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_coco_box_metric_against_a_brute_force_ap(ssd, seed):
+    """Random scenes (jittered copies of the objects as detections, duplicates, strays, missed objects, several categories and
+    images): AP50, AP75, AP and AR@100 of coco_metric.py equal the definition evaluated by brute force."""
+    cm = ssd.coco_metric
+    rng = np.random.default_rng(seed)
+    boxes, dt = {}, []
+    for img in range(1, 7):
+        for cat in (1, 2, 3):
+            n = int(rng.integers(0, 6))
+            bs = [[float(rng.uniform(0, 400)), float(rng.uniform(0, 400)), float(rng.uniform(20, 120)), float(rng.uniform(20, 120))] for _ in range(n)]
+            if bs:
+                boxes[(img, cat)] = bs
+            for b in bs:
+                for _ in range(int(rng.integers(0, 3))):             # 0 (missed), 1 or 2 (a duplicate) jittered detections
+                    j = rng.normal(0, 6, 4)
+                    dt.append({"image_id": img, "category_id": cat, "bbox": [b[0] + j[0], b[1] + j[1], max(b[2] + j[2], 4.0), max(b[3] + j[3], 4.0)],
+                               "score": float(rng.uniform(0.2, 1.0))})
+            for _ in range(int(rng.integers(0, 3))):                 # strays
+                dt.append({"image_id": img, "category_id": cat, "bbox": [float(rng.uniform(0, 450)), float(rng.uniform(0, 450)), 40.0, 40.0],
+                           "score": float(rng.uniform(0.1, 0.6))})
+    boxes.setdefault((7, 1), [[5.0, 5.0, 50.0, 50.0]])               # an image nobody detected anything in
+    gt = _coco_gt(boxes)
+    ev = cm.CocoBoxEval(gt, dt).evaluate().accumulate()
+    st = ev.summarize()
+    per_t = [_brute_force_ap(gt, dt, t) for t in cm.IOU_THRS]
+    assert np.isclose(st[1], per_t[0][0], atol=1e-12) and np.isclose(st[2], per_t[5][0], atol=1e-12)
+    assert np.isclose(st[0], np.mean([p[0] for p in per_t]), atol=1e-12)
+    assert np.isclose(st[8], np.mean([p[1] for p in per_t]), atol=1e-12)
+    assert 0.05 < st[0] < 0.95
+
+
 def test_abi_exports_every_declared_symbol(ssd):
     """The C-ABI library loads and exports every function include/ssd_hip.h declares."""
     hdr = open(os.path.join(ROOT, "include", "ssd_hip.h")).read()
