@@ -66,7 +66,8 @@ def evaluate(detector, annotations_json, images_dir, read_image=None, prediction
     results written as `predictions_json` (cell 11), then the twelve COCO box statistics (cell 17: COCOeval over all image and
     category ids) -- computed by coco_metric.py, this build's restatement of pycocotools' COCOeval (not installed here, not
     vendored by the reference).  `annotations_json`: path of instances_val2017.json or its dict; `read_image(path) -> uint8 RGB
-    ndarray`, default PIL (the notebook reads with cv2 and converts BGR -> RGB: the same array for a JPEG); `out`: a stream for
+    ndarray`, default PIL (the notebook reads with cv2 and converts BGR -> RGB: the same array when both decoders are built on the
+    same libjpeg, which is the usual case but nothing here can check; pass the notebook's reader to be sure); `out`: a stream for
     the summary table.  Returns the statistics in coco_metric.STAT_NAMES order (AP, AP50, AP75, APs, APm, APl, AR1, ...)."""
     import os
     from . import coco_metric

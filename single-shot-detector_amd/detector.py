@@ -68,6 +68,18 @@ class Detector:
         self.engine = Engine(self.params, weights, device=device, precision=precision)
         self.device = device
 
+    def close(self):
+        """Frees the engine's device memory (weights, every cached layer plan, staging buffers) now instead of at garbage
+        collection; the reference's Detector has no counterpart (its tf.Session lives as long as the object)."""
+        self.engine.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def _detect_views(self, images):
         """The graph outputs of one host batch as numpy VIEWS of the engine's pinned result block (valid until the next
         call); the caller holds self.engine.lock."""
