@@ -275,6 +275,29 @@ def test_checkpoint_reader_detects_damage(ssd, tmp_path):
         ssd.read_checkpoint(str(tmp_path / "v1"))
 
 
+def test_abi_refuses_null_arguments_without_crashing(ssd):
+    """Nothing throws or faults across the C ABI (include/ssd_hip.h: return codes + ssd_last_error): every entry point that takes
+    a handle, called with a null handle and null buffers -- no GPU needed, the checks come before any HIP call."""
+    L = ssd.lib()
+    f32 = ctypes.c_float
+    calls = {
+        "ssd_create": (None, None), "ssd_set_precision": (None, 0), "ssd_get_precision": (None,), "ssd_get_option": (None, b"streams", None),
+        "ssd_status": (None, None), "ssd_load_weight": (None, b"x", None, None, 0), "ssd_finalize": (None,),
+        "ssd_forward": (None, None, 1, 128, 128, None, None, None, None, None), "ssd_forward_records": (None, None, 1, 128, 128, None, None),
+        "ssd_forward_host": (None, None, 1, 128, 128, None, None), "ssd_network_shape": (None, 100, 100, None),
+        "ssd_forward_mixed": (None, None, 1, None, None, None, None), "ssd_forward_mixed_host": (None, None, 1, None, None, None),
+        "ssd_detect_host": (None, None, 128, 128, f32(0.1), None, None, None, None, 0, None, None),
+        "ssd_get_tensor": (None, b"p3", None, 0, None), "ssd_get_tensor_dev": (None, b"p3", None, 0, None, None),
+        "ssd_plan_cache_stats": (None, None), "ssd_plan_cache_clear": (None,), "ssd_profile_enable": (None, 1),
+        "ssd_profile_read": (None, 0, None, None, None, None), "ssd_profile_reset": (None,), "ssd_anchors": (128, 128, None)}
+    for name, args in calls.items():
+        rc = getattr(L, name)(*args)
+        assert rc < 0, (name, rc)
+        assert name == "ssd_get_precision" or len(L.ssd_last_error()) > 0, name
+    L.ssd_destroy(None)                                   # a no-op, like free(NULL)
+    assert L.ssd_record_words(None) == 0 and L.ssd_num_anchors(-5, 128) == 0
+
+
 def test_coco_records(ssd):
     """evaluate_on_COCO.ipynb cell 10 record construction (no GPU: a stub detector)."""
     def det(image, score_threshold=0.15):
