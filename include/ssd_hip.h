@@ -140,6 +140,8 @@ int ssd_get_precision(ssd_handle *h);
  *   "nsub"            0 auto | 1..8: at least this many consecutive sub-batch plans (the split a batch whose tensors would
  *                     pass 2 GiB takes)                                                                        (0)
  *   "nms_fast_max"    -1 default | n >= 0: candidate lists up to n stay in one wave's registers               (-1)
+ *   "first_conv_px"   1 | 0: the first convolution of RESIZED frames (any size that is not the network's own) on the
+ *                     lane-per-pixel kernel / on the thread-per-4-channels kernel of rounds 1-5                (1)
  *   "debug_sync"      0 | 1: announce every op on stderr, run it alone, wait for it, print its time           (0)
  * (Rounds 1-4 carried more switches -- schedule experiments that measured equal or slower: tower_group, head_serial,
  *  side_priority, level_split, fpn_p6_first, lat_one, dwpw_lat, graph, staggered sub-batch plans.  They are out of the library;

@@ -18,7 +18,7 @@ static Options g_opts;                 // process-wide values (ssd_set_option wi
 static std::mutex g_opts_mu;
 static const char *const OPT_NAMES[OPT_COUNT] = {"streams", "h2d_chunks", "front_fuse", "fuse_dw", "backbone_split", "event_fence", "plan_cache_mb",
                                                  "igemm_tile", "igemm16", "igemm_96", "igemm_lat", "igemm_deep64", "lateral_split", "fpn_group", "fpn_p7_group",
-                                                 "fpn_early_lat", "nsub", "nms_fast_max", "debug_sync"};
+                                                 "fpn_early_lat", "nsub", "nms_fast_max", "first_conv_px", "debug_sync"};
 int ssd_opt_index(const char *key)
 {
     for (int i = 0; i < OPT_COUNT; ++i)

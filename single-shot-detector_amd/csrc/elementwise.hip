@@ -251,6 +251,152 @@ __global__ __launch_bounds__(256) void first_conv_px_kernel(const uint8_t *__res
     }
 }
 
+// K1d (round 6): K1 / K1c -- the resize fused into the first convolution, frames of ANY size, one size per batch or one per
+// frame -- in K1b's form.  K1 gives 4 output channels of one pixel to a thread: the 8 (6) threads of a pixel each repeat the nine
+// index computations and the 27 byte loads, and the weights come from LDS per 16 B of output -- 0.99 ms per 32 frames of 480 x 640
+// against 0.17 ms for K1b on frames that need no resize, i.e. every COCO image paid 2.6 % of a 32-frame step for not being
+// 640 x 896 already.  Here one LANE = one output pixel, all channels: three source rows and three source columns per lane (the
+// index rule of K1, value for value: floorf((float)dst * scale), clamped to the last row / column), each of the nine source
+// pixels as two aligned dwords through a range-checked buffer resource + a byte alignment (a pixel's 3 bytes start at any byte),
+// then K1b's wave-uniform weights, chunks of accumulators and LDS transpose.  The same (ky,kx,ci)-ordered fmaf chain per output,
+// the same separately rounded normalisation: bit-identical to K1 / K1c (tests/test_gpu_multishape.py pins both kernels on every size).
+// GeomOf: frame b of the launch -> its FrameGeom (byte offset, source size, resize target, scales).
+template <int COUT, class GeomOf>
+__device__ __forceinline__ void first_conv_gen_body(const uint8_t *__restrict__ img, unsigned img_bytes4, GeomOf geom_of, int B, int H, int W,
+                                                    const float *__restrict__ w, int Cout_arg, const float *__restrict__ mean,
+                                                    const float *__restrict__ sf, const float *__restrict__ beta, int act, float *__restrict__ out,
+                                                    float *fc_tr)
+{
+    const int Cout = COUT ? COUT : Cout_arg;
+    const int OH = H >> 1, OW = W >> 1;
+    const long long total = (long long)B * OH * OW;
+    const float inv255 = (float)(1.0 / 255.0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr bool SWZ = COUT == 32;
+    const int rowf = SWZ ? 32 : Cout + FC_ROWPAD;
+    float *reg = fc_tr + (size_t)wave * 64 * rowf;
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, (int)img_bytes4, 0x00020000);
+    const long long nwave = (long long)gridDim.x * 4;
+    for (long long wbase = ((long long)blockIdx.x * 4 + wave) * 64; wbase < total; wbase += nwave * 64) {
+        const long long pix = wbase + lane;
+        const long long pp = pix < total ? pix : total - 1;
+        const int ox = (int)(pp % OW);
+        const long long rowi = pp / OW;
+        const int oy = (int)(rowi % OH);
+        const int b = (int)(rowi / OH);
+        const FrameGeom g = geom_of(b);
+        int roff[3], coff[3];
+        bool yin[3], xin[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int iy = 2 * oy + k, ix = 2 * ox + k;
+            int sy = (int)floorf((float)iy * g.hs), sx = (int)floorf((float)ix * g.ws);
+            sy = sy < g.srcH - 1 ? sy : g.srcH - 1;
+            sx = sx < g.srcW - 1 ? sx : g.srcW - 1;
+            yin[k] = iy < g.nh;                          // else: the resize's zero pad band (or beyond the padded frame)
+            xin[k] = ix < g.nw;
+            roff[k] = (yin[k] ? sy : 0) * g.srcW;
+            coff[k] = xin[k] ? sx : 0;
+        }
+        float x[27];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const bool yok = ky < 2 || 2 * oy + 2 < H;  // else: the convolution's zero padding ('SAME' on even sizes pads bottom / right only)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const bool xok = kx < 2 || 2 * ox + 2 < W;
+                const unsigned p = g.off + (unsigned)(roff[ky] + coff[kx]) * 3u;
+                const int a0 = (int)(p & ~3u), sh = (int)(p & 3u);
+                const unsigned w0 = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 0, 0);
+                const unsigned w1 = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 4, 0);
+                const unsigned d = __builtin_amdgcn_alignbyte(w1, w0, sh);
+                const bool inimg = yin[ky] && xin[kx];
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    float v = inimg ? (float)((d >> (8 * ci)) & 0xffu) : 0.0f;
+                    v = v * inv255;
+                    v = 2.0f * v - 1.0f;
+                    if (!(yok && xok)) v = 0.0f;
+                    x[(ky * 3 + kx) * 3 + ci] = v;
+                }
+            }
+        }
+        constexpr int CH = (COUT && COUT % 16 == 0) ? 16 : 8;
+#pragma unroll 1
+        for (int ch = 0; ch < Cout; ch += CH) {
+            float acc[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                const float *wr = w + t * Cout + ch;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) acc[i] = fmaf(x[t], wr[i], acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (mean) {
+                    const float tq = (acc[i] - mean[ch + i]) * sf[ch + i];
+                    acc[i] = tq + beta[ch + i];
+                }
+                acc[i] = act_apply(acc[i], act);
+            }
+#pragma unroll
+            for (int i = 0; i < CH; i += 4) {
+                const int c = SWZ ? ((((ch + i) >> 2) ^ (lane & 7)) << 2) : ch + i;
+                *(v4f *)(reg + lane * rowf + c) = (v4f){acc[i], acc[i + 1], acc[i + 2], acc[i + 3]};
+            }
+        }
+        const int LP = Cout >> 2;
+        const long long nlive = (total - wbase < 64 ? total - wbase : 64) * LP;
+        float *obase = out + wbase * Cout;
+        for (int q = lane; q < 64 * LP; q += 64) {
+            const int p = q / LP, c4 = q - p * LP;
+            const v4f v = *(const v4f *)(reg + p * rowf + (SWZ ? ((c4 ^ (p & 7)) << 2) : c4 * 4));
+            if (q < nlive) *(v4f *)(obase + (long long)q * 4) = v;
+        }
+    }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void first_conv_gen_kernel(const uint8_t *__restrict__ img, unsigned img_bytes4, const FrameGeom g1, int B, int H, int W,
+                                                              const float *__restrict__ w, int Cout_arg, const float *__restrict__ mean,
+                                                              const float *__restrict__ sf, const float *__restrict__ beta, int act, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float fc_tr[];
+    const unsigned frame = (unsigned)g1.srcH * (unsigned)g1.srcW * 3u;
+    first_conv_gen_body<COUT>(img, img_bytes4, [&](int b) { FrameGeom g = g1; g.off = g1.off + (unsigned)b * frame; return g; }, B, H, W, w, Cout_arg,
+                              mean, sf, beta, act, out, fc_tr);
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void first_conv_gen_mixed_kernel(const uint8_t *__restrict__ img, unsigned img_bytes4, const MixedGeom mg, int first, int B,
+                                                                    int H, int W, const float *__restrict__ w, int Cout_arg,
+                                                                    const float *__restrict__ mean, const float *__restrict__ sf,
+                                                                    const float *__restrict__ beta, int act, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float fc_tr[];
+    first_conv_gen_body<COUT>(img, img_bytes4, [&](int b) { return mg.f[first + b]; }, B, H, W, w, Cout_arg, mean, sf, beta, act, out, fc_tr);
+}
+
+// K1d's launch: false when this width has no instantiation (then K1 / K1c run).  The first layer's physical width is the logical
+// one rounded up to 32 (weights.hip load_first): 32 for every MobileNet-v1 up to depth multiplier 1.0 and every ShuffleNet-v2, 64 at
+// MobileNet 2.0 -- whose 68 KB of transpose rows would need the opt-in LDS size; that one stays on K1.
+static bool launch_first_conv_gen(const uint8_t *img, unsigned long long img_bytes, const FrameGeom *one, const MixedGeom *mg, int first, int B, int H, int W,
+                                  const float *w, int Cout, const float *mean, const float *sf, const float *beta, int act, float *out, hipStream_t s)
+{
+    if (Cout != 32 || img_bytes + 3 >= (1ull << 31)) return false;
+    const size_t lds = (size_t)256 * 32 * sizeof(float);
+    const unsigned bytes4 = (unsigned)((img_bytes + 3) & ~3ull);      // (a pixel's second dword may reach <= 3 bytes past a size that is no multiple of 4: the same word)
+    const long long px = (long long)B * (H / 2) * (W / 2);
+    long long blocks = (px + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    const dim3 grid((unsigned)blocks), blk(256);
+    if (one) hipLaunchKernelGGL(first_conv_gen_kernel<32>, grid, blk, lds, s, img, bytes4, *one, B, H, W, w, Cout, mean, sf, beta, act, out);
+    else hipLaunchKernelGGL(first_conv_gen_mixed_kernel<32>, grid, blk, lds, s, img, bytes4, *mg, first, B, H, W, w, Cout, mean, sf, beta, act, out);
+    return true;
+}
+
 // K1c: K1 (the general, non-identity form) for a batch whose frames have DIFFERENT source sizes and resize to the same [H,W]:
 // frame b reads its geometry from the argument table.  The arithmetic per output is K1's, value for value: the same index rule
 // (floorf((float)dst * scale), clamped), the same (ky,kx,ci)-ordered fmaf chain.
@@ -305,14 +451,17 @@ __global__ __launch_bounds__(256, 2) void first_conv_mixed_kernel(const uint8_t 
 }
 
 hipError_t launch_first_conv_mixed(const uint8_t *img, const MixedGeom &mg, int first, int B, int H, int W, const float *w, int Cout,
-                                   const float *mean, const float *sf, const float *beta, int act, float *out, hipStream_t s)
+                                   const float *mean, const float *sf, const float *beta, int act, float *out, hipStream_t s, int variant)
 {
     if (B < 1 || first < 0 || first + B > SSD_MIXED_MAX || Cout % 4 || (H & 1) || (W & 1) || 27 * Cout * 4 > 65536) return hipErrorInvalidValue;
+    unsigned long long end = 0;
     for (int b = first; b < first + B; ++b) {
         const FrameGeom &g = mg.f[b];
         if (g.srcH < 1 || g.srcW < 1 || g.nh < 1 || g.nw < 1 || g.nh > H || g.nw > W) return hipErrorInvalidValue;
         if ((unsigned long long)g.off + (unsigned long long)g.srcH * g.srcW * 3 >= (1ull << 31)) return hipErrorInvalidValue;
+        end = std::max(end, (unsigned long long)g.off + (unsigned long long)g.srcH * g.srcW * 3);
     }
+    if (variant != 1 && launch_first_conv_gen(img, end, nullptr, &mg, first, B, H, W, w, Cout, mean, sf, beta, act, out, s)) return hipGetLastError();
     const long long total = (long long)B * (H / 2) * (W / 2) * (Cout / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
@@ -323,7 +472,7 @@ hipError_t launch_first_conv_mixed(const uint8_t *img, const MixedGeom &mg, int 
 
 hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int nh, int nw, int H, int W,
                              const float *w, int Cout, const float *mean, const float *sf, const float *beta, int act,
-                             float *out, hipStream_t s)
+                             float *out, hipStream_t s, int variant)
 {
     if ((long long)B * srcH * srcW * 3 >= (1LL << 31)) return hipErrorInvalidValue;      // 32-bit byte offsets into the image
     if (Cout % 4 || (H & 1) || (W & 1) || 27 * Cout * 4 > 65536 || nh < 1 || nw < 1 || nh > H || nw > W || srcH < 1 || srcW < 1)
@@ -354,9 +503,13 @@ hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int 
     } else if (srcH == nh && nh == H && srcW == nw && nw == W)
         hipLaunchKernelGGL(first_conv_kernel<true>, dim3((unsigned)blocks), dim3(256), 27 * Cout * sizeof(float), s, img, B,
                            srcH, srcW, nh, nw, H, W, hs, ws, w, Cout, mean, sf, beta, act, out);
-    else
-        hipLaunchKernelGGL(first_conv_kernel<false>, dim3((unsigned)blocks), dim3(256), 27 * Cout * sizeof(float), s, img, B,
-                           srcH, srcW, nh, nw, H, W, hs, ws, w, Cout, mean, sf, beta, act, out);
+    else {
+        const FrameGeom g1 = {0u, srcH, srcW, nh, nw, hs, ws};
+        // K1d (one lane per output pixel) where the width has an instantiation; variant 1 pins K1 (tests, A/B)
+        if (variant == 1 || !launch_first_conv_gen(img, (unsigned long long)B * srcH * srcW * 3, &g1, nullptr, 0, B, H, W, w, Cout, mean, sf, beta, act, out, s))
+            hipLaunchKernelGGL(first_conv_kernel<false>, dim3((unsigned)blocks), dim3(256), 27 * Cout * sizeof(float), s, img, B,
+                               srcH, srcW, nh, nw, H, W, hs, ws, w, Cout, mean, sf, beta, act, out);
+    }
     return hipGetLastError();
 }
 

@@ -56,6 +56,7 @@ enum SsdOpt {
                             // layers, their top-down sums as one elementwise launch behind lateral5
     OPT_NSUB,               // 0 auto | 1..8: at least this many consecutive sub-batch plans (the split a > 2 GiB batch takes)
     OPT_NMS_FAST_MAX,       // -1 default | n >= 0: candidate lists up to n run in one wave's registers
+    OPT_FIRST_CONV_PX,      // 1 (default) | 0: resized frames' first convolution on the lane-per-pixel kernel (elementwise.hip K1d) / on K1, K1c
     OPT_DEBUG_SYNC,         // 0 | 1: announce every op, run it alone, wait for it (fault localisation)
     OPT_COUNT
 };

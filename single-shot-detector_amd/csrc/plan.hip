@@ -411,12 +411,13 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
                 const DwW f = h->first;
                 const int act = h->firstAct;
                 const int first_img = img0 + b0;
+                const int variant = ssd_opt(h, OPT_FIRST_CONV_PX, 1) == 0 ? 1 : 0;
                 op.run = [=](hipStream_t s) {      // the source's size and the resize's target: this call's (SrcGeom), any that lands on H x W
                     if (hh->mixed)                 // ... or every frame's own (a batch of frames of different sizes)
-                        return launch_first_conv_mixed(hh->cur_images, hh->mixed->geom, first_img, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, X, s);
+                        return launch_first_conv_mixed(hh->cur_images, hh->mixed->geom, first_img, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, X, s, variant);
                     const SrcGeom &g = hh->src;
                     return launch_first_conv(hh->cur_images + (size_t)first_img * g.srcH * g.srcW * 3, nb, g.srcH, g.srcW, g.nh, g.nw, H, W, f.w, f.Cp,
-                                             f.mean, f.sf, f.beta, act, X, s);
+                                             f.mean, f.sf, f.beta, act, X, s, variant);
                 };
                 ops.push_back(op);
             }
@@ -567,12 +568,13 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
                 } else {
                     SSDCHK(falloc(&F, (long long)nb * h2 * w2 * fc));
                     op.bytes = (double)nb * H * W * 3 + (double)nb * h2 * w2 * 24 * 4.0;
+                    const int variant = ssd_opt(h, OPT_FIRST_CONV_PX, 1) == 0 ? 1 : 0;
                     op.run = [=](hipStream_t s) {
                         if (hh->mixed)
-                            return launch_first_conv_mixed(hh->cur_images, hh->mixed->geom, first_img, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s);
+                            return launch_first_conv_mixed(hh->cur_images, hh->mixed->geom, first_img, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s, variant);
                         const SrcGeom &g = hh->src;
                         return launch_first_conv(hh->cur_images + (size_t)first_img * g.srcH * g.srcW * 3, nb, g.srcH, g.srcW, g.nh, g.nw, H, W, f.w, f.Cp,
-                                                 f.mean, f.sf, f.beta, act, F, s);
+                                                 f.mean, f.sf, f.beta, act, F, s, variant);
                     };
                     ops.push_back(op);
                     Op mp;

@@ -198,7 +198,8 @@ hipError_t launch_front_pool(const uint8_t *img, int B, int H, int W, const floa
 // source image [B,srcH,srcW,3] is NN-resized to [nh,nw], zero padded to [H,W] (even), normalised and convolved
 hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int nh, int nw, int H, int W,
                              const float *w /*[27][Cout] phys-n*/, int Cout, const float *mean, const float *sf,
-                             const float *beta, int act, float *out, hipStream_t s);
+                             const float *beta, int act, float *out, hipStream_t s,
+                             int variant = 0 /* resized frames: 0 auto (one lane per output pixel, K1d) | 1 the thread-per-4-channels kernel K1 */);
 // ... the same for a batch of frames of DIFFERENT sizes that resize to the same [H,W] (ssd_forward_mixed): frame b of the launch is
 // geometry entry first + b -- its byte offset in `img`, its size, its resize target and the two scale factors -- and the table
 // travels in the kernel's arguments (no upload, nothing to keep alive): at most SSD_MIXED_MAX frames per batch
@@ -206,7 +207,7 @@ hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int 
 struct FrameGeom { unsigned off; int srcH, srcW, nh, nw; float hs, ws; };
 struct MixedGeom { FrameGeom f[SSD_MIXED_MAX]; };
 hipError_t launch_first_conv_mixed(const uint8_t *img, const MixedGeom &mg, int first, int B, int H, int W, const float *w, int Cout,
-                                   const float *mean, const float *sf, const float *beta, int act, float *out, hipStream_t s);
+                                   const float *mean, const float *sf, const float *beta, int act, float *out, hipStream_t s, int variant = 0);
 hipError_t launch_depthwise(const float *in, int B, int H, int W, int C, const float *w /*[9][C]*/,
                             int stride, int pad, int OH, int OW, const float *mean, const float *sf,
                             const float *beta, int act, float *out, hipStream_t s, int out16 = 0 /* 1: S16 rows */,

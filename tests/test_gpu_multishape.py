@@ -71,6 +71,51 @@ def test_any_size_shufflenet_full_size_vs_oracle(cuda, ssd, oracle_graph, hw):
     eng.close()
 
 
+# (backbone, depth multiplier): the first convolution's 32 physical channels hold 32 (MobileNet 1.0), 16 (0.5: 16 zero-weight
+# pad channels) or ShuffleNet's 24 logical ones; MobileNet 2.0 (64 channels) stays on the rounds-1-5 kernel either way
+FIRST_CONV_NETS = [("mobilenet", 1.0), ("mobilenet", 0.5), ("mobilenet", 2.0), ("shufflenet", 1.0)]
+
+
+@pytest.mark.parametrize("net", FIRST_CONV_NETS, ids=["%s-%g" % n for n in FIRST_CONV_NETS])
+def test_first_convolution_of_resized_frames_both_kernels(cuda, ssd, oracle_graph, net):
+    """Frames that are not the network's size take the general first convolution (resize_keeping_aspect_ratio fused into it,
+    pipeline.py:138-194): round 6's lane-per-pixel kernel (default) and the rounds-1-5 kernel (option first_conv_px = 0) give the
+    same bits as each other and as the oracle -- up-scaling (x3.9) and down-scaling (x0.18: source pixels far apart), odd widths
+    (rows that start at any byte, a buffer whose size is no multiple of 4: the last pixel's second dword), the smallest frames,
+    batches, and frames of DIFFERENT sizes in one batch (per-frame geometry from the kernel's arguments)."""
+    params = dict(TINY_PARAMS, backbone=net[0], depth_multiplier=net[1])
+    W = ssd.synthetic_weights(params, seed=11, logits_bias=-3.0)
+    new, old = ssd.Engine(params, W), ssd.Engine(params, W)
+    old.set_option("first_conv_px", 0)
+    checked = 0
+    for h, w, B in [(100, 151, 1), (97, 203, 3), (300, 129, 2), (513, 701, 1), (33, 77, 5), (2, 3, 1), (1, 1, 2), (131, 128, 1), (255, 1021, 1)]:
+        img = np.random.default_rng(h * 7 + w).integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+        a = [t.cpu().numpy() for t in new.forward(cuda.from_numpy(img).cuda())]
+        b = [t.cpu().numpy() for t in old.forward(cuda.from_numpy(img).cuda())]
+        for k in range(4):
+            assert np.array_equal(a[k], b[k]), (net, h, w, B, k, "the two kernels")
+        for name in ("c3", "p3", "class_predictions"):
+            assert np.array_equal(new.get_tensor(name), old.get_tensor(name)), (net, h, w, name)
+        if B <= 2:                                        # (the oracle costs ~0.1 s per tiny frame)
+            ref = oracle_graph.forward(img, W, params)
+            for a_k, key in zip(a, ("boxes", "labels", "scores", "num_boxes")):
+                assert np.array_equal(a_k, ref[key]), (net, h, w, key, "vs the oracle")
+            checked += int(ref["num_boxes"].sum())
+    assert checked > 50
+    # one batch of frames of different sizes (all -> 128 x 256): both kernels' mixed forms, against each frame alone
+    frames = [np.random.default_rng(40 + i).integers(0, 256, (hh, ww, 3), dtype=np.uint8) for i, (hh, ww) in
+              enumerate([(100, 151), (128, 200), (64, 100), (97, 193), (33, 65), (128, 256), (101, 202)])]
+    assert len({new.network_shape(*f.shape[:2]) for f in frames}) == 1
+    ma = [np.array(v) for v in new.detect_host_mixed(frames)]
+    mb = [np.array(v) for v in old.detect_host_mixed(frames)]
+    for i, f in enumerate(frames):
+        alone = [t.cpu().numpy()[0] for t in new.forward(cuda.from_numpy(f[None]).cuda())]
+        for k in range(4):
+            assert np.array_equal(ma[k][i], mb[k][i]) and np.array_equal(ma[k][i], alone[k]), (net, "mixed", i, k)
+    new.close()
+    old.close()
+
+
 def test_cycle_of_sizes_through_one_detector_full_size(cuda, ssd, oracle_graph):
     """A, B, A, C, B, A (+ D, which shares C's network shape with another resize target, + E at the network's own size) through
     ONE Detector: every call equals a fresh single-plan engine's result and the oracle's, bit for bit; the library built one

@@ -528,7 +528,8 @@ def test_library_reads_one_environment_variable_and_options_go_through_the_abi(s
         assert gone not in blob, gone
     unset = -2 ** 31
     for key in ("streams", "h2d_chunks", "front_fuse", "fuse_dw", "backbone_split", "event_fence", "plan_cache_mb", "igemm_tile", "igemm16", "igemm_96",
-                "igemm_lat", "igemm_deep64", "lateral_split", "fpn_group", "fpn_p7_group", "fpn_early_lat", "nsub", "nms_fast_max", "debug_sync"):
+                "igemm_lat", "igemm_deep64", "lateral_split", "fpn_group", "fpn_p7_group", "fpn_early_lat", "nsub", "nms_fast_max", "first_conv_px",
+                "debug_sync"):
         v = 64 if key == "igemm_tile" else 3
         assert ssd.get_option(key) == unset
         ssd.set_option(key, v)
