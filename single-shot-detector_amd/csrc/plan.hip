@@ -346,6 +346,10 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
     int *const FL = h->flags_dev;
     // ---------------- backbone
     float *C3 = nullptr, *C4 = nullptr, *C5 = nullptr;
+    unsigned char *scratch = nullptr;           // backbone-only memory that later stages of the same forward may reuse (MobileNet)
+    size_t scratch_bytes = 0;
+    // a tensor's slot inside a shared block: its bytes + the 256 bytes of slack every tensor has behind it (DevPool::alloc), 256-aligned
+    auto scratch_slot = [](size_t bytes) { return (bytes + 256 + 255) & ~(size_t)255; };
     const int h2 = H / 2, w2 = W / 2;
     int id_bb_last[4] = {-1, -1, -1, -1};     // last backbone op of each chain (MobileNet split), -1: no such chain
     int id_c4 = -1;                            // the op that completes c4 when the backbone is ONE chain (then c3 precedes it on the same stream)
@@ -380,22 +384,36 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
         unsigned fuse_mask = SSD_FUSE_DW_DEFAULT;
         if (ssd_opt(h, OPT_FUSE_DW, -1) >= 0) fuse_mask = (unsigned)ssd_opt(h, OPT_FUSE_DW, -1);
         std::vector<Op> half_ops[4];
+        // The chains' ping-pong buffers (2 x the largest backbone tensor per chain: 73 MB per 640 x 896 frame, a third of the
+        // arena) as ONE block: nothing reads them once c3 / c4 / c5 exist, so the head towers' buffers -- whose first writer runs
+        // behind the FPN, i.e. behind every backbone launch -- and after them the NMS keys are carved from the same bytes (`scratch`).
+        // The next forward's backbone starts behind this forward's last kernel (one caller stream; another stream waits for
+        // ev_last), and every plan has a block of its own.
+        auto chain_floats = [&](int nb) {
+            long long maxf = (long long)nb * h2 * w2 * h->firstCp;
+            int hh = h2, ww = w2;
+            for (int i = 0; i < 13; ++i) {
+                hh /= MB_STRIDE[i]; ww /= MB_STRIDE[i];
+                maxf = std::max(maxf, std::max((long long)nb * hh * ww * h->dw[i].Cp, (long long)nb * hh * ww * h->pw[i].CoutP));
+            }
+            return maxf;
+        };
+        {
+            size_t total = 0;
+            for (int hf = 0; hf < nhalf; ++hf) {
+                const int nb = (int)((long long)B * (hf + 1) / nhalf) - (int)((long long)B * hf / nhalf);
+                total += 2 * scratch_slot((size_t)chain_floats(nb) * sizeof(float));
+            }
+            SSDCHK(ap.alloc((void **)&scratch, total));
+            scratch_bytes = total;
+        }
+        size_t scratch_used = 0;
         for (int hf = 0; hf < nhalf; ++hf) {
             const int b0 = (int)((long long)B * hf / nhalf), nb = (int)((long long)B * (hf + 1) / nhalf) - b0;
             std::vector<Op> &ops = half_ops[hf];
-            long long maxf = (long long)nb * h2 * w2 * h->firstCp;
-            {
-                int hh = h2, ww = w2;
-                for (int i = 0; i < 13; ++i) {
-                    hh /= MB_STRIDE[i]; ww /= MB_STRIDE[i];
-                    long long a = (long long)nb * hh * ww * h->dw[i].Cp, b = (long long)nb * hh * ww * h->pw[i].CoutP;
-                    if (a > maxf) maxf = a;
-                    if (b > maxf) maxf = b;
-                }
-            }
-            float *X, *Y;
-            SSDCHK(falloc(&X, maxf));
-            SSDCHK(falloc(&Y, maxf));
+            const long long maxf = chain_floats(nb);
+            float *X = (float *)(scratch + scratch_used), *Y = (float *)(scratch + scratch_used + scratch_slot((size_t)maxf * sizeof(float)));
+            scratch_used += 2 * scratch_slot((size_t)maxf * sizeof(float));
             // first convolution + Conv2d_1 as ONE launch (front.hip) when the frames arrive at the network's input size and
             // the three layers have MobileNet-1.0's widths; option front_fuse = 0 / 1 pins it
             bool front = ident && ((fuse_mask >> 0) & 1) && h->first.mean && h->dw[0].pack &&
@@ -816,8 +834,27 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
     SSDCHK(ssd_anchors(H, W, anc.data()));
     float *anc_dev;
     SSDCHK(ap.upload(&anc_dev, anc));
+    // The head towers' four ping-pong buffers as one block: inside the backbone's block when they fit (MobileNet: they do), else
+    // a block of their own (ShuffleNet, whose backbone tensors are stage allocations the FPN still reads).  Either way the block is
+    // dead once the two final head convolutions are done -- and the post-processing starts behind both of them (ev_join) -- so the
+    // NMS candidate keys [B][C][N] u64, 46 of the workspace's 50 MB per frame and the one part of it with no state between
+    // forwards, take their place (when they fit: up to 85 classes).
+    float *TAB[2][2];
+    unsigned char *keys_home = nullptr;
+    {
+        const size_t slot = scratch_slot((size_t)py.total * sizeof(float));
+        unsigned char *tb = scratch;
+        size_t tb_bytes = scratch_bytes;
+        if (!scratch || 4 * slot > scratch_bytes) {
+            SSDCHK(ap.alloc((void **)&tb, 4 * slot));
+            tb_bytes = 4 * slot;
+        }
+        for (int t = 0; t < 2; ++t)
+            for (int k = 0; k < 2; ++k) TAB[t][k] = (float *)(tb + (size_t)(2 * t + k) * slot);
+        if (post_keys_bytes(B, (int)N, C) <= tb_bytes) keys_home = tb;
+    }
     void *ws;
-    const size_t wsb = post_workspace_bytes(B, (int)N, C, h->cfg.max_boxes_per_class);
+    const size_t wsb = post_workspace_bytes(B, (int)N, C, h->cfg.max_boxes_per_class, keys_home == nullptr);
     SSDCHK(ap.alloc(&ws, wsb));
     PostArgs &p = pl.post;
     memset(&p, 0, sizeof(p));
@@ -827,14 +864,11 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
     p.max_per_class = h->cfg.max_boxes_per_class;
     p.fast_max = nms_fast_max(h);
     for (int k = 0; k < 4; ++k) p.box_scaler[k] = 1.0f;               // (model.py:67-68: this call's, set by enqueue_forward)
-    post_carve(p, ws);
+    post_carve(p, ws, keys_home);
     HIPCHK(hipMemset(p.scan_bits, 0, post_scan_bitmap_bytes(B, (int)N, C)));
     HIPCHK(hipMemset(p.counts, 0, (size_t)B * C * sizeof(int)));      // the post-processing kernels leave these zeroed again
     p.self_clean = 1;
     std::vector<Op> tower_ops[2];
-    float *TAB[2][2];
-    for (int t = 0; t < 2; ++t)
-        for (int k = 0; k < 2; ++k) SSDCHK(falloc(&TAB[t][k], py.total));
     bool all_marked = true;
     for (int t = 0; t < 2; ++t) {
         const float *in = P;
@@ -948,7 +982,7 @@ static hipError_t run_op(ssd_handle *h, const Op &op, hipStream_t s)
 // of their own -- robust against what the framework created, but a second engine's batch-1 forward took 2.4 ms instead of 1.64;
 // a CU-masked stream is a BLOCKING stream and would serialise with the legacy default stream.)
 // The arena budget of a handle's cached plans: option plan_cache_mb, default a quarter of the device's memory (a batch-1 plan of
-// MobileNet at 640 x 1024 holds ~0.35 GB, a 32-image one ~7 GB: the COCO mix of a dozen network shapes at batch 1 is ~4 GB).
+// MobileNet at 640 x 1024 holds ~0.16 GB, a 32-image one ~4.9 GB: the COCO mix of a dozen network shapes at batch 1 is ~2 GB).
 size_t plan_cache_limit_bytes(const ssd_handle *h)
 {
     const int mb = ssd_opt(h, OPT_PLAN_CACHE_MB, 0);

@@ -776,10 +776,12 @@ __global__ __launch_bounds__(256) void post_pack_kernel(const PostArgs p)
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 size_t post_scan_bitmap_bytes(int B, int N, int C) { return (((size_t)B * N * C / 8 + 31) / 32) * 4 + 4; }
 
-size_t post_workspace_bytes(int B, int N, int C, int mp)
+size_t post_keys_bytes(int B, int N, int C) { return align_up((size_t)B * C * N * sizeof(u64)); }
+
+size_t post_workspace_bytes(int B, int N, int C, int mp, bool with_keys)
 {
     size_t s = 0;
-    s += align_up((size_t)B * C * N * sizeof(u64));
+    if (with_keys) s += post_keys_bytes(B, N, C);
     s += align_up((size_t)B * C * sizeof(int));
     s += align_up((size_t)B * N * 4 * sizeof(float));
     s += align_up((size_t)B * C * mp * 4 * sizeof(float));
@@ -789,11 +791,14 @@ size_t post_workspace_bytes(int B, int N, int C, int mp)
     return s;
 }
 
-void post_carve(PostArgs &p, void *ws)
+// keys_elsewhere: the candidate keys -- the bulk of the workspace, and the one part with no state between forwards -- live in
+// memory the caller lends (plan.hip: the backbone's ping-pong block, dead by then); `ws` then holds the rest only
+void post_carve(PostArgs &p, void *ws, void *keys_elsewhere)
 {
     unsigned char *q = (unsigned char *)ws;
     const size_t B = p.B, N = p.N, C = p.C, mp = p.max_per_class;
-    p.keys = (u64 *)q;          q += align_up(B * C * N * sizeof(u64));
+    if (keys_elsewhere) p.keys = (u64 *)keys_elsewhere;
+    else { p.keys = (u64 *)q;   q += align_up(B * C * N * sizeof(u64)); }
     p.counts = (int *)q;        q += align_up(B * C * sizeof(int));
     p.dec = (float *)q;         q += align_up(B * N * 4 * sizeof(float));
     p.cls_boxes = (float *)q;   q += align_up(B * C * mp * 4 * sizeof(float));

@@ -256,7 +256,8 @@ struct PostArgs {
     unsigned *scan_bits;
     int scan_fused;
 };
-size_t post_workspace_bytes(int B, int N, int C, int max_per_class);
+size_t post_workspace_bytes(int B, int N, int C, int max_per_class, bool with_keys = true);
+size_t post_keys_bytes(int B, int N, int C);
 size_t post_scan_bitmap_bytes(int B, int N, int C);
-void post_carve(PostArgs &p, void *ws);
+void post_carve(PostArgs &p, void *ws, void *keys_elsewhere = nullptr);
 hipError_t launch_postprocess(const PostArgs &p, hipStream_t s);
