@@ -61,14 +61,16 @@ def detection_records_many(detector, images, image_ids, label_to_coco_id, score_
 
 
 def evaluate(detector, annotations_json, images_dir, read_image=None, predictions_json="coco_predictions.json", out=None,
-             score_threshold=0.15, max_batch=32):
+             score_threshold=0.15, max_batch=32, read_workers=None):
     """Cells 4-17 end to end: every image of the annotation file through the detector (score_threshold 0.15, cell 10), the
     results written as `predictions_json` (cell 11), then the twelve COCO box statistics (cell 17: COCOeval over all image and
     category ids) -- computed by coco_metric.py, this build's restatement of pycocotools' COCOeval (not installed here, not
     vendored by the reference).  `annotations_json`: path of instances_val2017.json or its dict; `read_image(path) -> uint8 RGB
     ndarray`, default PIL (the notebook reads with cv2 and converts BGR -> RGB: the same array when both decoders are built on the
     same libjpeg, which is the usual case but nothing here can check; pass the notebook's reader to be sure); `out`: a stream for
-    the summary table.  Returns the statistics in coco_metric.STAT_NAMES order (AP, AP50, AP75, APs, APm, APl, AR1, ...)."""
+    the summary table; `read_workers`: threads that read and decode images (default min(16, CPUs): a JPEG decodes in ~5 ms on
+    one core, the detector takes ~1.4 ms per image in batches -- the next chunk of files is decoded while this one is detected).
+    Returns the statistics in coco_metric.STAT_NAMES order (AP, AP50, AP75, APs, APm, APl, AR1, ...)."""
     import os
     from . import coco_metric
     if read_image is None:
@@ -81,10 +83,17 @@ def evaluate(detector, annotations_json, images_dir, read_image=None, prediction
     metas = sorted(gt["images"], key=lambda m: m["id"])
     results = []
     chunk = 256           # images read, then detected as batches grouped by network shape (the notebook's loop, one image per sess.run, at batch throughput)
-    for k in range(0, len(metas), chunk):
-        part = metas[k:k + chunk]
-        images = [read_image(os.path.join(images_dir, m["file_name"])) for m in part]
-        results += detection_records_many(detector, images, [m["id"] for m in part], mapping, score_threshold, max_batch)
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, int(read_workers if read_workers is not None else min(16, os.cpu_count() or 1)))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        def start(k):      # (PIL and cv2 release the interpreter lock while they decode)
+            return [pool.submit(read_image, os.path.join(images_dir, m["file_name"])) for m in metas[k:k + chunk]]
+        ahead = start(0)
+        for k in range(0, len(metas), chunk):
+            part = metas[k:k + chunk]
+            images = [f.result() for f in ahead]
+            ahead = start(k + chunk)
+            results += detection_records_many(detector, images, [m["id"] for m in part], mapping, score_threshold, max_batch)
     if predictions_json:
         with open(predictions_json, "w") as f:
             json.dump(results, f)
