@@ -236,6 +236,51 @@ def dominant(prof):
     return k, prof[k]
 
 
+DOMINANT_F32_KERNEL = "igemm_kernel<2, 2, 2, 2, 9, 0, 0"      # the 128x128-tile 3x3 instance: 8 tower layers + fpn p3 + fpn p4 per step
+
+
+def measure_traffic_live(config, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, measured NOW: two child runs of this script (2 timed
+    steps, mode f32 only, every other leg off) under `rocprofv3 --pmc <counter> --kernel-trace`, one counter per pass
+    (MI355X_MICROARCH.md: FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2 -- they do not fit one pass), from /tmp with the
+    program itself behind `--`; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (the guide's gfx950 correction: FETCH_SIZE reports
+    half of a wide coalesced read stream; both counters are in KB).  Returns (bytes per launch, launches averaged, note) or
+    (None, 0, reason) -- then the line keeps the committed measurement of profiles/traffic.json."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, 0, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="ssd_traffic_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-latency", "--no-traffic",
+             "--sustained-seconds", "0", "--no-other-precision", "--no-shufflenet", "--config", config]
+    env = dict(os.environ, TMPDIR="/tmp")
+    means = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, counter)
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            vals = []
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if DOMINANT_F32_KERNEL in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, 0, "no %s rows for the dominant kernel (rocprofv3 rc %d: %s)" % (counter, r.returncode, r.stderr.decode("utf-8", "replace")[-200:])
+            means[counter] = (sum(vals) / len(vals), len(vals))
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        return None, 0, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    n = min(means["FETCH_SIZE"][1], means["WRITE_SIZE"][1])
+    return (2.0 * means["FETCH_SIZE"][0] + means["WRITE_SIZE"][0]) * 1024.0, n, \
+        "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate, --kernel-trace only) of 3 steps of this " \
+        "workload in a child process, FETCH x2 per the gfx950 correction, KB -> bytes, mean over %d launches" % n
+
+
 def roofline_block(prof, precision, steps, traffic_key=None):
     """roofline of the dominant kernel class: algorithmic FLOP of its launches / the union of their HIP-event
     intervals on the forward's own streams inside the timed region (ssd_profile_read)."""
@@ -493,6 +538,9 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
                          "(config_shufflenet.json, 640x640, default --batch 64) as the line's workload: for profiling that network "
                          "alone; the default run already carries it as the shufflenet_config4 object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not re-measure roofline.traffic with two rocprofv3 --pmc child runs at the end (N = 1, mode f32; ~40 s); the "
+                         "line then carries the committed measurement of profiles/traffic.json")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-shufflenet", action="store_true", help="skip the config-4 object (N = 1 only anyway)")
     ap.add_argument("--no-other-precision", action="store_true")
@@ -723,6 +771,19 @@ def main(argv=None, engine_factory=None, backend="nccl", script=None):
                 res["shufflenet_config4"] = shufflenet_leg(local, timed, max(3, args.steps // 2), 2, 64)
             if not args.no_cpu_baseline:          # (rank 0 at any world size: ~12 s of host time while the other ranks wait at the barrier)
                 res["cpu_baseline"] = cpu_baseline()
+            if world == 1 and not use_dist and args.precision == "f32" and not args.no_traffic:
+                # LAST: every timed leg is done; the children profile the same workload while this process sits idle
+                try:
+                    engine.close()
+                except Exception:
+                    pass
+                t_bytes, t_n, t_note = measure_traffic_live(net)
+                rl = res["roofline"]
+                if t_bytes is not None:
+                    rl["traffic_committed"] = rl["traffic"]
+                    rl["traffic"], rl["traffic_source"], rl["traffic_launches_averaged"] = t_bytes, t_note, t_n
+                else:
+                    rl["traffic_live_error"] = t_note
         print(json.dumps(res))
         sys.stdout.flush()
     if use_dist:

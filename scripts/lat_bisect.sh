@@ -2,7 +2,7 @@
 # Which leg of bench.py's sequence moves the batch-1 latency measured behind it?  (one box, the legs switched off one at a time)
 set -e
 mkdir -p gpurun_out
-run() { tag=$1; shift; python bench.py --no-shufflenet --no-cpu-baseline "$@" > gpurun_out/lat_bisect_$tag.json 2> gpurun_out/lat_bisect_$tag.err;
+run() { tag=$1; shift; python bench.py --no-shufflenet --no-cpu-baseline --no-traffic "$@" > gpurun_out/lat_bisect_$tag.json 2> gpurun_out/lat_bisect_$tag.err;
   python - "$tag" <<'P'
 import json, sys
 t = sys.argv[1]

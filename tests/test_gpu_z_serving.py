@@ -249,6 +249,13 @@ def test_bench_collective_path_on_rccl_world_1(cuda):
         assert line["compute_ms_per_step"] + line["allgather_ms_per_step"] < 1.5 * line["ms_per_step"]
     assert forced["engine_first_forward_before_process_group"] is True and plain["engine_first_forward_before_process_group"] is False
     assert forced["allgather_bytes_per_rank"] == 32 * 48004
+    # roofline.traffic: the plain run re-measures it (two rocprofv3 --pmc child passes behind the timed legs); the collective run
+    # carries the committed measurement.  The counter bytes of a tower launch sit between its algorithmic bytes and 3x that.
+    rl = plain["roofline"]
+    assert rl["traffic_source"].startswith("measured in this run"), rl.get("traffic_live_error", rl["traffic_source"])
+    assert rl["traffic_algorithmic_bytes"] < rl["traffic"] < 3 * rl["traffic_algorithmic_bytes"] and rl["traffic_launches_averaged"] >= 20
+    assert abs(rl["traffic"] / rl["traffic_committed"] - 1) < 0.05
+    assert "profiles/traffic.json" in forced["roofline"]["traffic_source"]
     # the form the driver uses for N > 1, at N = 1: torch.distributed.run sets WORLD_SIZE=1
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"] + common[4:],
