@@ -23,7 +23,8 @@ def _frame(h, w, seed=None):
 # (source height, width) -> what the network sees at min_dimension 640 (pipeline.py:160-192):
 #   427 x 640 -> 640 x 959 -> pad 1024      480 x 640 -> 640 x 853 -> 896      640 x 480 -> 853 x 640 -> 896 x 640
 #   375 x 500 -> 640 x 853 -> 896           256 x 257 -> 640 x 642.5 -> half-to-even 642 -> 768 (the long side lands on x.5)
-FULL_SIZES = [(427, 640), (480, 640), (640, 480), (375, 500), (256, 257)]
+#   1200 x 1600 -> 640 x 853 -> 896 (a camera frame: DOWN-scaling, source pixels 1.875 apart, 5.8 MB of source)
+FULL_SIZES = [(427, 640), (480, 640), (640, 480), (375, 500), (256, 257), (1200, 1600)]
 
 
 @pytest.mark.parametrize("hw", FULL_SIZES, ids=["%dx%d" % s for s in FULL_SIZES])
