@@ -38,15 +38,15 @@ def detection_records(detector, image, image_id, label_to_coco_id, score_thresho
     height, width, _ = image.shape
     boxes, labels, scores = detections if detections is not None else detector(image, score_threshold=score_threshold)
     scaler = np.array([height, width, height, width], dtype="float32")
-    boxes = boxes * scaler
-    out = []
-    for i in range(len(boxes)):
-        ymin, xmin, ymax, xmax = boxes[i]
-        x, y = int(xmin), int(ymin)
-        w, h = int(xmax - xmin), int(ymax - ymin)
-        out.append({"image_id": int(image_id), "category_id": int(label_to_coco_id[int(labels[i])]),
-                    "bbox": [x, y, w, h], "score": float(scores[i])})
-    return out
+    boxes = np.asarray(boxes, np.float32).reshape(-1, 4) * scaler
+    # cell 10 per detection: x, y = int(xmin), int(ymin); w, h = int(xmax - xmin), int(ymax - ymin) on float32 values -- the same
+    # float32 differences and truncations toward zero, for all rows at once
+    x, y = boxes[:, 1].astype(np.int64).tolist(), boxes[:, 0].astype(np.int64).tolist()
+    w, h = (boxes[:, 3] - boxes[:, 1]).astype(np.int64).tolist(), (boxes[:, 2] - boxes[:, 0]).astype(np.int64).tolist()
+    cats = [int(label_to_coco_id[int(l)]) for l in np.asarray(labels).reshape(-1).tolist()]
+    sc = np.asarray(scores, np.float32).reshape(-1).astype(np.float64).tolist()         # float(np.float32) per element
+    image_id = int(image_id)
+    return [{"image_id": image_id, "category_id": c, "bbox": [xi, yi, wi, hi], "score": s} for c, xi, yi, wi, hi, s in zip(cats, x, y, w, h, sc)]
 
 
 def detection_records_many(detector, images, image_ids, label_to_coco_id, score_threshold=0.15, max_batch=32):

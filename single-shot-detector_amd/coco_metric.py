@@ -28,6 +28,7 @@ MAX_DETS = (1, 10, 100)
 AREA_RNG = ((0 ** 2, 1e5 ** 2), (0 ** 2, 32 ** 2), (32 ** 2, 96 ** 2), (96 ** 2, 1e5 ** 2))
 AREA_LBL = ("all", "small", "medium", "large")
 STAT_NAMES = ("AP", "AP50", "AP75", "APs", "APm", "APl", "AR1", "AR10", "AR100", "ARs", "ARm", "ARl")
+THR_L = [min(float(t), 1 - 1e-10) for t in IOU_THRS]        # cocoeval.py evaluateImg: iou = min([t, 1 - 1e-10])
 
 
 def bbox_iou(dt, gt, iscrowd):
@@ -94,6 +95,10 @@ class CocoBoxEval:
                 garea = np.array([g[1] for g in gts], np.float64)
                 ious_all = bbox_iou(dbox, [g[0] for g in gts], gcrowd) if gts and dts else np.zeros((len(dbox), len(gts)))
                 for ai, (lo, hi) in enumerate(AREA_RNG):
+                    if not gts:            # (most cells of a real run: detections of a category the image does not have)
+                        oor = (darea < lo) | (darea > hi)
+                        self.eval_imgs[(cat, ai, img)] = (dscore, np.zeros((T, len(dbox)), bool), np.broadcast_to(oor, (T, len(dbox))), np.zeros(0, bool))
+                        continue
                     gig = (gcrowd != 0) | (garea < lo) | (garea > hi)
                     gind = np.argsort(gig.astype(np.int64), kind="mergesort")
                     gig_s, crowd_s = gig[gind], gcrowd[gind]
@@ -102,24 +107,28 @@ class CocoBoxEval:
                     dtm = np.zeros((T, D), bool)
                     dtig = np.zeros((T, D), bool)
                     if G and D:
-                        for ti, t in enumerate(IOU_THRS):
-                            gtm = np.zeros(G, bool)
+                        # (plain Python lists inside the loops: indexing numpy scalars costs more than the comparisons)
+                        iou_l, ig_l, cr_l = ious.tolist(), gig_s.tolist(), [bool(c) for c in crowd_s.tolist()]
+                        for ti, t in enumerate(THR_L):
+                            gtm = [False] * G
+                            row_m, row_ig = dtm[ti], dtig[ti]
                             for di in range(D):
-                                best = min(t, 1 - 1e-10)
+                                best = t
                                 m = -1
+                                row = iou_l[di]
                                 for gi in range(G):
-                                    if gtm[gi] and not crowd_s[gi]:
+                                    if gtm[gi] and not cr_l[gi]:
                                         continue                       # already matched, and not a crowd
-                                    if m > -1 and not gig_s[m] and gig_s[gi]:
+                                    if m > -1 and not ig_l[m] and ig_l[gi]:
                                         break                          # a regular match is held: ignore boxes (sorted last) cannot take it
-                                    if ious[di, gi] < best:
+                                    if row[gi] < best:
                                         continue
-                                    best = ious[di, gi]
+                                    best = row[gi]
                                     m = gi
                                 if m == -1:
                                     continue
-                                dtig[ti, di] = gig_s[m]
-                                dtm[ti, di] = True
+                                row_ig[di] = ig_l[m]
+                                row_m[di] = True
                                 gtm[m] = True
                     out_of_range = (darea < lo) | (darea > hi)
                     dtig = dtig | (~dtm & out_of_range[None, :])
