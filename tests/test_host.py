@@ -239,6 +239,28 @@ def test_convert_any_container_to_npz(ssd, tmp_path):
         convert.load_any(str(tmp_path / "nothing"), p)
 
 
+def test_checkpoint_index_table_round_trips_any_keys(ssd, tmp_path):
+    """The .index file's table format under random contents (hypothesis): keys with long shared prefixes, empty values, values
+    larger than a block, any block size and restart interval -- what the independent writer wrote is what the reader returns, in
+    key order."""
+    from hypothesis import given, settings, strategies as st
+    from helpers.tf_bundle_writer import write_table
+    ck = __import__("importlib").import_module("ssd_amd.ckpt_import")
+    path = str(tmp_path / "t.index")
+    stem = st.sampled_from([b"", b"MobilenetV1/Conv2d_", b"fpn/p", b"class_net/batch_norm_", b"\xff\x00"])
+    key = st.builds(lambda a, b: a + b, stem, st.binary(min_size=0, max_size=12))
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.dictionaries(key, st.binary(min_size=0, max_size=300), min_size=0, max_size=60),
+           st.integers(min_value=16, max_value=5000), st.integers(min_value=1, max_value=20))
+    def run(items, block_size, restart_interval):
+        ordered = sorted(items.items())
+        write_table(path, ordered, block_size=block_size, restart_interval=restart_interval)
+        got = ck.read_table(path)
+        assert list(got.items()) == ordered
+    run()
+
+
 def test_checkpoint_reader_detects_damage(ssd, tmp_path):
     """What TensorFlow's BundleReader reports as DataLoss: a flipped bit in an index block, in a tensor's bytes, a truncated
     index, a missing shard, a file that is no table at all."""
