@@ -239,7 +239,7 @@ def dominant(prof):
 DOMINANT_F32_KERNEL = "igemm_kernel<2, 2, 2, 2, 9, 0, 0"      # the 128x128-tile 3x3 instance: 8 tower layers + fpn p3 + fpn p4 per step
 
 
-def measure_traffic_live(config, timeout_s=150):
+def measure_traffic_live(config, timeout_s=90):
     """HBM bytes per launch of the dominant kernel from the PMC counters, measured NOW: two child runs of this script (2 timed
     steps, mode f32 only, every other leg off) under `rocprofv3 --pmc <counter> --kernel-trace`, one counter per pass
     (MI355X_MICROARCH.md: FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2 -- they do not fit one pass), from /tmp with the
