@@ -262,7 +262,19 @@ def measure_traffic_live(config, timeout_s=90):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(out, counter)
             cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            # (its own process group: a pass that outlives its limit is killed together with the program it profiles)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                _, err = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.communicate()
+                return None, 0, "the %s pass did not finish within %d s" % (counter, timeout_s)
+            r = subprocess.CompletedProcess(cmd, pr.returncode, None, err)
             vals = []
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for row in csv.DictReader(open(f)):
