@@ -80,22 +80,96 @@ static __device__ __forceinline__ void frame_unpack(const unsigned (&raw)[9], in
     }
 }
 
+// Round 6: the same for a RESIZED frame (resize_keeping_aspect_ratio fused, pipeline.py:138-194 -- the index rule of
+// elementwise.hip K1 / K1d, value for value) whose width is not reduced (srcW <= nw, i.e. every COCO image at min_dimension 640):
+// the three taps of a filter row then read source columns sx(2 cx), sx(2 cx + 1), sx(2 cx + 2) that lie at most two pixels apart,
+// so a filter row is still 9 contiguous source bytes from the first tap's pixel -- three aligned dwords, like the frame of the
+// network's own size -- and tap kx takes the pixel sx(2 cx + kx) - sx(2 cx) in {0, 1, 2} of them.  Rows are three independent
+// source rows (any vertical scale).  Beyond the resize's target (the zero pad band) a tap is 0 before the normalisation, beyond
+// the padded frame 0 after it.
+struct FrontGeom { int srcH, srcW, nh, nw; float hs, ws; };
+
+static __device__ __forceinline__ int front_src(int dst, float scale, int n)
+{
+    const int v = (int)floorf((float)dst * scale);
+    return v < n - 1 ? v : n - 1;
+}
+
+static __device__ __forceinline__ void frame_fetch_gen(const __amdgpu_buffer_rsrc_t irsrc, bool live, int b, const FrontGeom &g, int cy, int cx,
+                                                       unsigned (&raw)[9])
+{
+    const int sx0 = front_src(2 * cx, g.ws, g.srcW);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int sy = front_src(2 * cy + ky, g.hs, g.srcH);
+        const int ad = ((b * g.srcH + sy) * g.srcW + sx0) * 3;
+        const int a0 = live ? (ad & ~3) : (int)0x80000000u;
+        raw[ky * 3 + 0] = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 0, 0);
+        raw[ky * 3 + 1] = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 4, 0);
+        raw[ky * 3 + 2] = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 8, 0);
+    }
+}
+
+static __device__ __forceinline__ void frame_unpack_gen(const unsigned (&raw)[9], int b, int H, int W, const FrontGeom &g, int cy, int cx, float (&x)[27])
+{
+    const float inv255 = (float)(1.0 / 255.0);
+    const int sx0 = front_src(2 * cx, g.ws, g.srcW);
+    int off[3];
+    bool xin[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        off[kx] = 3 * (front_src(2 * cx + kx, g.ws, g.srcW) - sx0);      // 0, 3 or 6
+        xin[kx] = 2 * cx + kx < g.nw;
+    }
+    const bool xok = 2 * cx + 2 < W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * cy + ky;
+        const bool yok = ky < 2 || iy < H;
+        const bool yin = iy < g.nh;
+        const int sy = front_src(iy, g.hs, g.srcH);
+        const int sh = (((b * g.srcH + sy) * g.srcW + sx0) * 3) & 3;
+        const unsigned w0 = raw[ky * 3], w1 = raw[ky * 3 + 1], w2 = raw[ky * 3 + 2];
+        const unsigned d0 = __builtin_amdgcn_alignbyte(w1, w0, sh);      // source bytes 0..3 of the row's span
+        const unsigned d1 = __builtin_amdgcn_alignbyte(w2, w1, sh);      // 4..7
+        const unsigned d2 = w2 >> (8 * sh);                              // 8..
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const unsigned lo = off[kx] < 4 ? d0 : d1, hi = off[kx] < 4 ? d1 : d2;
+            const unsigned px = __builtin_amdgcn_alignbyte(hi, lo, off[kx] & 3);
+            const bool inimg = yin && xin[kx];
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                float v = inimg ? (float)((px >> (8 * ci)) & 0xffu) : 0.0f;
+                v = v * inv255;
+                v = 2.0f * v - 1.0f;
+                if (!yok || (kx == 2 && !xok)) v = 0.0f;
+                x[ky * 9 + kx * 3 + ci] = v;
+            }
+        }
+    }
+}
+
 // (the read-only operands as `const __restrict__` kernel parameters: with them inside the by-value struct the compiler cannot
 //  prove the first convolution's weights invariant and loads them per lane into vector registers instead of with scalar loads)
 struct FrontDims { int B, H, W, act0, dact, act, tiles_y, tiles_x; };
+// GEN: the frames are resized on the fly (geometry gg); else they have the network's size H x W
+template <bool GEN>
 __global__ __launch_bounds__(256, 2) void front_kernel(const uint8_t *__restrict__ a_img, const float *__restrict__ a_w0,
                                                         const float *__restrict__ a_m0, const float *__restrict__ a_s0,
                                                         const float *__restrict__ a_b0, const float *__restrict__ a_dwpack,
                                                         const float *__restrict__ a_wt, const float *__restrict__ a_mean,
                                                         const float *__restrict__ a_sf, const float *__restrict__ a_beta,
-                                                        float *__restrict__ a_out, const FrontDims a)
+                                                        float *__restrict__ a_out, const FrontDims a, const FrontGeom gg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = a.H, W = a.W, OH = H >> 1, OW = W >> 1;
     const int tiles_img = a.tiles_y * a.tiles_x, total = a.B * tiles_img;
-    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_img, 0, (int)((long long)a.B * H * W * 3), 0x00020000);
+    // (GEN: the size rounded up to whole dwords -- a row's third dword may reach <= 3 bytes past a size that is no multiple of 4)
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)a_img, 0, GEN ? (int)((((long long)a.B * gg.srcH * gg.srcW * 3) + 3) & ~3LL) : (int)((long long)a.B * H * W * 3), 0x00020000);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_out, 0, (int)((long long)a.B * OH * OW * 64 * 4), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
@@ -138,7 +212,8 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const uint8_t *__restrict
         int fy = ty * TY - 1 + ppy, fx = tx * TX - 1 + ppx;
         fy = fy < 0 ? 0 : (fy >= OH ? OH - 1 : fy);
         fx = fx < 0 ? 0 : (fx >= OW ? OW - 1 : fx);
-        frame_fetch(irsrc, tid < NSLOT, b, H, W, fy, fx, raw);
+        if constexpr (GEN) frame_fetch_gen(irsrc, tid < NSLOT, b, gg, fy, fx, raw);
+        else frame_fetch(irsrc, tid < NSLOT, b, H, W, fy, fx, raw);
     };
     int t = blockIdx.x;
     if (t < total) fetch(t);
@@ -152,7 +227,8 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const uint8_t *__restrict
             const bool inside = tid < NSLOT && (unsigned)fy < (unsigned)OH && (unsigned)fx < (unsigned)OW;
             const int cy = fy < 0 ? 0 : (fy >= OH ? OH - 1 : fy), cx = fx < 0 ? 0 : (fx >= OW ? OW - 1 : fx);
             float x[27];
-            frame_unpack(raw, b, H, W, cy, cx, x);
+            if constexpr (GEN) frame_unpack_gen(raw, b, H, W, gg, cy, cx, x);
+            else frame_unpack(raw, b, H, W, cy, cx, x);
             // the next tile's bytes: in flight until the next iteration's phase 1
             if (t + (int)gridDim.x < total) fetch(t + (int)gridDim.x);
             unsigned char *prow = lds + tid * 128;
@@ -400,10 +476,17 @@ bool front_supports(int B, int H, int W, int C0, int K, int Cout)
     return (long long)B * H * W * 3 < (1LL << 31) && (long long)B * (H / 2) * (W / 2) * 64 * 4 < (1LL << 31);
 }
 
+// resized frames: the width must not shrink (a filter row = 9 contiguous source bytes), 32-bit byte offsets into the frames
+bool front_gen_supports(int B, int srcH, int srcW, int nh, int nw)
+{
+    return B >= 1 && srcH >= 1 && srcW >= 1 && nh >= 1 && nw >= srcW && (long long)B * srcH * srcW * 3 + 3 < (1LL << 31);
+}
+
 hipError_t launch_front(const FrontArgs &q, hipStream_t s)
 {
     if (!q.img || !q.w0 || !q.m0 || !q.s0 || !q.b0 || !q.dwpack || !q.wt || !q.mean || !q.sf || !q.beta || !q.out) return hipErrorInvalidValue;
     if (!front_supports(q.B, q.H, q.W, 32, 32, 64)) return hipErrorInvalidValue;
+    if (q.resized && (!front_gen_supports(q.B, q.srcH, q.srcW, q.nh, q.nw) || q.nh > q.H || q.nw > q.W)) return hipErrorInvalidValue;
     const int OH = q.H / 2, OW = q.W / 2;
     if (q.tiles_y != (OH + TY - 1) / TY || q.tiles_x != (OW + TX - 1) / TX) return hipErrorInvalidValue;
     const long long total = (long long)q.B * q.tiles_y * q.tiles_x;
@@ -412,8 +495,16 @@ hipError_t launch_front(const FrontArgs &q, hipStream_t s)
     // 512 / 756 blocks -> 34.2 / 32.8 / 28.8 / 32.1 us; 32 frames: 512 / 1024 / 2048 the same step time)
     const int grid = (int)(total < 512 ? total : 512);
     const FrontDims d = {q.B, q.H, q.W, q.act0, q.dact, q.act, q.tiles_y, q.tiles_x};
-    hipLaunchKernelGGL(front_kernel, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, q.img, q.w0, q.m0, q.s0, q.b0, q.dwpack, q.wt, q.mean, q.sf,
-                       q.beta, q.out, d);
+    if (q.resized) {
+        // (the scale factors as launch_first_conv forms them: the same float expressions as elementwise.hip K1 / K1d)
+        const FrontGeom g = {q.srcH, q.srcW, q.nh, q.nw, (float)q.srcH / (float)q.nh, (float)q.srcW / (float)q.nw};
+        hipLaunchKernelGGL(front_kernel<true>, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, q.img, q.w0, q.m0, q.s0, q.b0, q.dwpack, q.wt, q.mean,
+                           q.sf, q.beta, q.out, d, g);
+    } else {
+        const FrontGeom g = {q.H, q.W, q.H, q.W, 1.0f, 1.0f};
+        hipLaunchKernelGGL(front_kernel<false>, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, q.img, q.w0, q.m0, q.s0, q.b0, q.dwpack, q.wt, q.mean,
+                           q.sf, q.beta, q.out, d, g);
+    }
     return hipGetLastError();
 }
 

@@ -420,6 +420,20 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
                          h->pw[0].taps == 1 && h->pw[0].mean && !h->pw[0].bias && front_supports(nb, H, W, h->firstCp, h->dw[0].Cp, h->pw[0].CoutP) &&
                          h->pw[0].CinP == 32 && MB_STRIDE[0] == 1;
             { const int pin = ssd_opt(h, OPT_FRONT_FUSE, -1); if (pin >= 0) front = front && pin != 0; }
+            // RESIZED frames whose width does not shrink (every COCO image at min_dimension 640) take the same fused launch with the
+            // gather in its loads (front.hip, GEN).  Decided per CALL: the source geometry is a launch argument and a plan serves any
+            // source size that lands on its network shape, so such a plan keeps both forms -- the first-convolution op launches the
+            // fused kernel and the Conv2d_1 op does nothing, or (a frame that is reduced in width, a batch of mixed sizes) the two
+            // run as themselves.  Same conditions as the static form, plus Conv2d_1 being ONE op (the fused depthwise + pointwise).
+            bool front_rt = !ident && ((fuse_mask >> 0) & 1) && h->first.mean && h->dw[0].pack &&
+                            h->pw[0].taps == 1 && h->pw[0].mean && !h->pw[0].bias && front_supports(nb, H, W, h->firstCp, h->dw[0].Cp, h->pw[0].CoutP) &&
+                            h->pw[0].CinP == 32 && MB_STRIDE[0] == 1 && dwpws_eligible(h->dw[0], h->pw[0], nb, h2, w2, MB_STRIDE[0]);
+            { const int pin = ssd_opt(h, OPT_FRONT_FUSE, -1); if (pin >= 0) front_rt = front_rt && pin != 0; }
+            ssd_handle *const hrt = h;
+            auto fused_now = [hrt, nb, front_rt]() {
+                const SrcGeom &g = hrt->src;
+                return front_rt && !hrt->mixed && front_gen_supports(nb, g.srcH, g.srcW, g.nh, g.nw);
+            };
             if (!front) {
                 Op op;
                 op.cls = 3;
@@ -430,10 +444,26 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
                 const int act = h->firstAct;
                 const int first_img = img0 + b0;
                 const int variant = ssd_opt(h, OPT_FIRST_CONV_PX, 1) == 0 ? 1 : 0;
+                FrontArgs fq;
+                memset(&fq, 0, sizeof(fq));
+                if (front_rt) {
+                    const ConvW &c0 = h->pw[0];
+                    fq.w0 = f.w; fq.m0 = f.mean; fq.s0 = f.sf; fq.b0 = f.beta; fq.dwpack = h->dw[0].pack;
+                    fq.wt = c0.wt; fq.mean = c0.mean; fq.sf = c0.sf; fq.beta = c0.beta; fq.out = Y;      // (Conv2d_1's output: `dwo` of layer 0 below)
+                    fq.B = nb; fq.H = H; fq.W = W; fq.act0 = act; fq.dact = SSD_ACT_RELU6; fq.act = SSD_ACT_RELU6;
+                    fq.tiles_y = (H / 2 + front_tile_y() - 1) / front_tile_y();
+                    fq.tiles_x = (W / 2 + front_tile_x() - 1) / front_tile_x();
+                }
                 op.run = [=](hipStream_t s) {      // the source's size and the resize's target: this call's (SrcGeom), any that lands on H x W
                     if (hh->mixed)                 // ... or every frame's own (a batch of frames of different sizes)
                         return launch_first_conv_mixed(hh->cur_images, hh->mixed->geom, first_img, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, X, s, variant);
                     const SrcGeom &g = hh->src;
+                    if (fused_now()) {
+                        FrontArgs r = fq;
+                        r.img = hh->cur_images + (size_t)first_img * g.srcH * g.srcW * 3;
+                        r.resized = 1; r.srcH = g.srcH; r.srcW = g.srcW; r.nh = g.nh; r.nw = g.nw;
+                        return launch_front(r, s);
+                    }
                     return launch_first_conv(hh->cur_images + (size_t)first_img * g.srcH * g.srcW * 3, nb, g.srcH, g.srcW, g.nh, g.nw, H, W, f.w, f.Cp,
                                              f.mean, f.sf, f.beta, act, X, s, variant);
                 };
@@ -465,9 +495,14 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
                 } else {
                     pwo = fuse ? dwo : ((dwo == X) ? Y : X);    // fused: input `cur` is live until the launch ends
                 }
-                if (fuse)
-                    ops.push_back(make_dwpws_op(h->dw[i], cw, cur, nb, dh, dwid, s, SSD_ACT_RELU6, SSD_ACT_RELU6, pwo));
-                else   // c5 feeds only the FPN (lateral5, p6): in f16x3 mode it is written in split-fp16 rows
+                if (fuse) {
+                    Op o = make_dwpws_op(h->dw[i], cw, cur, nb, dh, dwid, s, SSD_ACT_RELU6, SSD_ACT_RELU6, pwo);
+                    if (i == 0 && front_rt) {        // (its work was done by the fused launch of the op before it when fused_now())
+                        const auto inner = o.run;
+                        o.run = [inner, fused_now](hipStream_t st) { return fused_now() ? hipSuccess : inner(st); };
+                    }
+                    ops.push_back(o);
+                } else   // c5 feeds only the FPN (lateral5, p6): in f16x3 mode it is written in split-fp16 rows
                     ops.push_back(make_conv_op(h, cw, dwo, pwo, nullptr, nullptr, nb, 1, 0, SSD_ACT_RELU6,
                                                {dense_level(ch, cwid, ch, cwid, cw.CoutP)}, true, pw16, (i == 12 && X16) ? 1 : 0, 0, h->flags_dev));
                 if (i == 10 && nhalf == 1) id_c4 = (int)ops.size() - 1;          // Conv2d_11_pointwise = c4 (one chain: pl.ops keeps this index)

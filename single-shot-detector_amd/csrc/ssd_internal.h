@@ -182,8 +182,11 @@ struct FrontArgs {
     int B, H, W;
     int act0, dact, act;
     int tiles_y, tiles_x;                  // ceil((H/2) / front_tile_y()), ceil((W/2) / front_tile_x())
+    int resized;                           // 1: img holds [B,srcH,srcW,3] frames that are resized to [nh,nw] and padded to [H,W] on the fly
+    int srcH, srcW, nh, nw;                //    (resize_keeping_aspect_ratio; needs front_gen_supports: the width does not shrink)
 };
 bool front_supports(int B, int H, int W, int C0, int K, int Cout);
+bool front_gen_supports(int B, int srcH, int srcW, int nh, int nw);
 int front_tile_y();
 int front_tile_x();
 hipError_t launch_front(const FrontArgs &q, hipStream_t s);

@@ -86,17 +86,23 @@ def test_first_convolution_of_resized_frames_both_kernels(cuda, ssd, oracle_grap
     batches, and frames of DIFFERENT sizes in one batch (per-frame geometry from the kernel's arguments)."""
     params = dict(TINY_PARAMS, backbone=net[0], depth_multiplier=net[1])
     W = ssd.synthetic_weights(params, seed=11, logits_bias=-3.0)
-    new, old = ssd.Engine(params, W), ssd.Engine(params, W)
+    # three forms of a resized frame's first layers: the fused launch with the gather in its loads (front.hip GEN: MobileNet 1.0,
+    # frames whose width does not shrink -- every size below but 513 x 701 and 255 x 1021), the lane-per-pixel first convolution +
+    # Conv2d_1 as its own launch (front_fuse = 0), and the rounds-1-5 first convolution (first_conv_px = 0 on top)
+    new, mid, old = ssd.Engine(params, W), ssd.Engine(params, W), ssd.Engine(params, W)
+    mid.set_option("front_fuse", 0)
+    old.set_option("front_fuse", 0)
     old.set_option("first_conv_px", 0)
     checked = 0
     for h, w, B in [(100, 151, 1), (97, 203, 3), (300, 129, 2), (513, 701, 1), (33, 77, 5), (2, 3, 1), (1, 1, 2), (131, 128, 1), (255, 1021, 1)]:
         img = np.random.default_rng(h * 7 + w).integers(0, 256, (B, h, w, 3), dtype=np.uint8)
         a = [t.cpu().numpy() for t in new.forward(cuda.from_numpy(img).cuda())]
-        b = [t.cpu().numpy() for t in old.forward(cuda.from_numpy(img).cuda())]
-        for k in range(4):
-            assert np.array_equal(a[k], b[k]), (net, h, w, B, k, "the two kernels")
-        for name in ("c3", "p3", "class_predictions"):
-            assert np.array_equal(new.get_tensor(name), old.get_tensor(name)), (net, h, w, name)
+        for other, what in ((mid, "fused front vs first convolution + Conv2d_1"), (old, "vs the rounds-1-5 first convolution")):
+            b = [t.cpu().numpy() for t in other.forward(cuda.from_numpy(img).cuda())]
+            for k in range(4):
+                assert np.array_equal(a[k], b[k]), (net, h, w, B, k, what)
+            for name in ("c3", "p3", "class_predictions"):
+                assert np.array_equal(new.get_tensor(name), other.get_tensor(name)), (net, h, w, name, what)
         if B <= 2:                                        # (the oracle costs ~0.1 s per tiny frame)
             ref = oracle_graph.forward(img, W, params)
             for a_k, key in zip(a, ("boxes", "labels", "scores", "num_boxes")):
@@ -110,11 +116,20 @@ def test_first_convolution_of_resized_frames_both_kernels(cuda, ssd, oracle_grap
     ma = [np.array(v) for v in new.detect_host_mixed(frames)]
     mb = [np.array(v) for v in old.detect_host_mixed(frames)]
     for i, f in enumerate(frames):
-        alone = [t.cpu().numpy()[0] for t in new.forward(cuda.from_numpy(f[None]).cuda())]
+        alone = [t.cpu().numpy()[0] for t in new.forward(cuda.from_numpy(f[None]).cuda())]      # (alone: the fused launch; in the batch: per-frame geometry)
         for k in range(4):
             assert np.array_equal(ma[k][i], mb[k][i]) and np.array_equal(ma[k][i], alone[k]), (net, "mixed", i, k)
-    new.close()
-    old.close()
+    # one plan, both forms: a frame reduced in width (first convolution + Conv2d_1) between two that are not (fused), same network shape
+    seq = [np.random.default_rng(70 + i).integers(0, 256, (1, hh, ww, 3), dtype=np.uint8) for i, (hh, ww) in enumerate([(100, 151), (200, 300), (100, 151)])]
+    assert len({new.network_shape(*f.shape[1:3]) for f in seq}) == 1
+    outs = [[t.cpu().numpy() for t in new.forward(cuda.from_numpy(f).cuda())] for f in seq]
+    refs = [[t.cpu().numpy() for t in old.forward(cuda.from_numpy(f).cuda())] for f in seq]
+    for o, r in zip(outs, refs):
+        for k in range(4):
+            assert np.array_equal(o[k], r[k])
+    assert new.plan_cache_stats()["misses"] == mid.plan_cache_stats()["misses"]
+    for e in (new, mid, old):
+        e.close()
 
 
 def test_cycle_of_sizes_through_one_detector_full_size(cuda, ssd, oracle_graph):
