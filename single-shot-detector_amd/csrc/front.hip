@@ -363,17 +363,19 @@ struct FrontPoolDims { int B, H, W, act0, tiles_y, tiles_x; };
 // COUT: channels the convolution computes (24: the layer's width is 3 whole octets, so its physical channels are 0 .. 23);
 // CS: physical channels of a stored row -- 24, or 32 inside the network, whose tensors carry 8 zero pad channels (stored as zeros
 // here: round 5 -- computing them cost a quarter of the kernel's multiply-adds)
-template <int COUT, int CS>
+// GEN: resized frames whose width does not shrink (geometry gg), as front_kernel<true>
+template <int COUT, int CS, bool GEN>
 __global__ __launch_bounds__(256, 2) void front_pool_kernel(const uint8_t *__restrict__ a_img, const float *__restrict__ a_w0,
                                                              const float *__restrict__ a_m0, const float *__restrict__ a_s0,
                                                              const float *__restrict__ a_b0, float *__restrict__ a_out,
-                                                             const FrontPoolDims a)
+                                                             const FrontPoolDims a, const FrontGeom gg)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[QSLOT * 128];      // patch rows of 128 B: 6 chunks used, chunk c at slot c ^ (row & 7)
     const int tid = threadIdx.x;
     const int H = a.H, W = a.W, OH = H >> 1, OW = W >> 1, PH2 = OH >> 1, PW2 = OW >> 1;
     const int tiles_img = a.tiles_y * a.tiles_x, total = a.B * tiles_img;
-    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_img, 0, (int)((long long)a.B * H * W * 3), 0x00020000);
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)a_img, 0, GEN ? (int)((((long long)a.B * gg.srcH * gg.srcW * 3) + 3) & ~3LL) : (int)((long long)a.B * H * W * 3), 0x00020000);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_out, 0, (int)((long long)a.B * PH2 * PW2 * CS * 4), 0x00020000);
     const int ppy = tid / QPW, ppx = tid - ppy * QPW;
     unsigned raw[9];
@@ -382,7 +384,8 @@ __global__ __launch_bounds__(256, 2) void front_pool_kernel(const uint8_t *__res
         int fy = 2 * QY * ty + ppy, fx = 2 * QX * tx + ppx;
         fy = fy >= OH ? OH - 1 : fy;
         fx = fx >= OW ? OW - 1 : fx;
-        frame_fetch(irsrc, tid < QSLOT, b, H, W, fy, fx, raw);
+        if constexpr (GEN) frame_fetch_gen(irsrc, tid < QSLOT, b, gg, fy, fx, raw);
+        else frame_fetch(irsrc, tid < QSLOT, b, H, W, fy, fx, raw);
     };
     int t = blockIdx.x;
     if (t < total) fetch(t);
@@ -393,7 +396,8 @@ __global__ __launch_bounds__(256, 2) void front_pool_kernel(const uint8_t *__res
             const bool inside = tid < QSLOT && fy < OH && fx < OW;
             const int cy = fy >= OH ? OH - 1 : fy, cx = fx >= OW ? OW - 1 : fx;
             float x[27];
-            frame_unpack(raw, b, H, W, cy, cx, x);
+            if constexpr (GEN) frame_unpack_gen(raw, b, H, W, gg, cy, cx, x);
+            else frame_unpack(raw, b, H, W, cy, cx, x);
             if (t + (int)gridDim.x < total) fetch(t + (int)gridDim.x);
             unsigned char *prow = lds + tid * 128;
             {                                                // all COUT accumulators in one pass over the 27 taps
@@ -457,16 +461,26 @@ bool front_pool_supports(int B, int H, int W, int C0)
     return (long long)B * H * W * 3 < (1LL << 31);
 }
 
+// src: null = frames of the network's size [B,H,W,3]; else {srcH, srcW, nh, nw}: frames [B,srcH,srcW,3] resized to [nh,nw] and padded
+// to [H,W] on the fly (front_gen_supports: the width does not shrink)
 hipError_t launch_front_pool(const uint8_t *img, int B, int H, int W, const float *w0, int C0, const float *m0, const float *s0, const float *b0,
-                             int act0, float *out, hipStream_t s)
+                             int act0, float *out, hipStream_t s, const int *src)
 {
     if (!img || !w0 || !m0 || !s0 || !b0 || !out || !front_pool_supports(B, H, W, C0)) return hipErrorInvalidValue;
+    if (src && (!front_gen_supports(B, src[0], src[1], src[2], src[3]) || src[2] > H || src[3] > W)) return hipErrorInvalidValue;
     FrontPoolDims d = {B, H, W, act0, (H / 4 + QY - 1) / QY, (W / 4 + QX - 1) / QX};
     const long long total = (long long)B * d.tiles_y * d.tiles_x;
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
     const int grid = (int)(total < 4096 ? total : 4096);
-    if (C0 == 24) hipLaunchKernelGGL((front_pool_kernel<24, 24>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d);
-    else hipLaunchKernelGGL((front_pool_kernel<24, 32>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d);
+    const FrontGeom g = src ? FrontGeom{src[0], src[1], src[2], src[3], (float)src[0] / (float)src[2], (float)src[1] / (float)src[3]}
+                            : FrontGeom{H, W, H, W, 1.0f, 1.0f};
+    if (src) {
+        if (C0 == 24) hipLaunchKernelGGL((front_pool_kernel<24, 24, true>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, g);
+        else hipLaunchKernelGGL((front_pool_kernel<24, 32, true>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, g);
+    } else {
+        if (C0 == 24) hipLaunchKernelGGL((front_pool_kernel<24, 24, false>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, g);
+        else hipLaunchKernelGGL((front_pool_kernel<24, 32, false>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, g);
+    }
     return hipGetLastError();
 }
 

@@ -622,10 +622,22 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
                     SSDCHK(falloc(&F, (long long)nb * h2 * w2 * fc));
                     op.bytes = (double)nb * H * W * 3 + (double)nb * h2 * w2 * 24 * 4.0;
                     const int variant = ssd_opt(h, OPT_FIRST_CONV_PX, 1) == 0 ? 1 : 0;
+                    // resized frames whose width does not shrink: the fused launch with the gather in its loads, chosen per call (as
+                    // MobileNet's above): this op then writes the pooled tensor and the max-pool op does nothing
+                    bool front_rt = !ident && h->first.mean && front_pool_supports(nb, H, W, fc);
+                    { const int pin = ssd_opt(h, OPT_FRONT_FUSE, -1); if (pin >= 0) front_rt = front_rt && pin != 0; }
+                    auto fused_now = [hh, nb, front_rt]() {
+                        const SrcGeom &g = hh->src;
+                        return front_rt && !hh->mixed && front_gen_supports(nb, g.srcH, g.srcW, g.nh, g.nw);
+                    };
                     op.run = [=](hipStream_t s) {
                         if (hh->mixed)
                             return launch_first_conv_mixed(hh->cur_images, hh->mixed->geom, first_img, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s, variant);
                         const SrcGeom &g = hh->src;
+                        if (fused_now()) {
+                            const int src[4] = {g.srcH, g.srcW, g.nh, g.nw};
+                            return launch_front_pool(hh->cur_images + (size_t)first_img * g.srcH * g.srcW * 3, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, MP, s, src);
+                        }
                         return launch_first_conv(hh->cur_images + (size_t)first_img * g.srcH * g.srcW * 3, nb, g.srcH, g.srcW, g.nh, g.nw, H, W, f.w, f.Cp,
                                                  f.mean, f.sf, f.beta, act, F, s, variant);
                     };
@@ -633,7 +645,7 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
                     Op mp;
                     mp.cls = 5; mp.flops = 0;
                     mp.bytes = ((double)nb * h2 * w2 + (double)nb * h4 * w4) * 24 * 4.0;
-                    mp.run = [=](hipStream_t s) { return launch_maxpool(F, nb, h2, w2, fc, MP, s); };
+                    mp.run = [=](hipStream_t s) { return fused_now() ? hipSuccess : launch_maxpool(F, nb, h2, w2, fc, MP, s); };
                     ops.push_back(mp);
                 }
             }

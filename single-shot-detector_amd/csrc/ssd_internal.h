@@ -195,7 +195,7 @@ hipError_t launch_front(const FrontArgs &q, hipStream_t s);
 // multiples of 4), w0 [27][C0] -> out [B,H/4,W/4,C0]
 bool front_pool_supports(int B, int H, int W, int C0);
 hipError_t launch_front_pool(const uint8_t *img, int B, int H, int W, const float *w0, int C0, const float *m0, const float *s0, const float *b0,
-                             int act0, float *out, hipStream_t s);
+                             int act0, float *out, hipStream_t s, const int *src = nullptr /* {srcH, srcW, nh, nw}: resized frames */);
 
 // elementwise / memory-bound kernels -----------------------------------------------------
 // source image [B,srcH,srcW,3] is NN-resized to [nh,nw], zero padded to [H,W] (even), normalised and convolved
