@@ -88,6 +88,24 @@ static __device__ __forceinline__ void frame_unpack(const unsigned (&raw)[9], in
 // source rows (any vertical scale).  Beyond the resize's target (the zero pad band) a tap is 0 before the normalisation, beyond
 // the padded frame 0 after it.
 struct FrontGeom { int srcH, srcW, nh, nw; float hs, ws; };
+// MODE of the two kernels below: 0 = frames of the network's size, 1 = resized frames of ONE size (FrontGeom; frame b starts at byte
+// b * srcH * srcW * 3), 2 = a batch of frames of DIFFERENT sizes (ssd_forward_mixed): frame b's geometry and byte offset are entry
+// first + b of the table in the kernel's arguments -- a tile belongs to one frame, so the entry is read with scalar loads
+struct FrontMixed { MixedGeom mg; int first; unsigned bytes4; };
+template <int MODE> struct FrontGeomArg { typedef FrontGeom type; };
+template <> struct FrontGeomArg<2> { typedef FrontMixed type; };
+template <int MODE>
+static __device__ __forceinline__ void front_geom_of(const typename FrontGeomArg<MODE>::type &ga, int b, FrontGeom &g, unsigned &base)
+{
+    if constexpr (MODE == 2) {
+        const FrameGeom f = ga.mg.f[ga.first + b];
+        g.srcH = f.srcH; g.srcW = f.srcW; g.nh = f.nh; g.nw = f.nw; g.hs = f.hs; g.ws = f.ws;
+        base = f.off;
+    } else {
+        g = ga;
+        base = (unsigned)b * (unsigned)ga.srcH * (unsigned)ga.srcW * 3u;
+    }
+}
 
 static __device__ __forceinline__ int front_src(int dst, float scale, int n)
 {
@@ -95,14 +113,14 @@ static __device__ __forceinline__ int front_src(int dst, float scale, int n)
     return v < n - 1 ? v : n - 1;
 }
 
-static __device__ __forceinline__ void frame_fetch_gen(const __amdgpu_buffer_rsrc_t irsrc, bool live, int b, const FrontGeom &g, int cy, int cx,
+static __device__ __forceinline__ void frame_fetch_gen(const __amdgpu_buffer_rsrc_t irsrc, bool live, unsigned base, const FrontGeom &g, int cy, int cx,
                                                        unsigned (&raw)[9])
 {
     const int sx0 = front_src(2 * cx, g.ws, g.srcW);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int sy = front_src(2 * cy + ky, g.hs, g.srcH);
-        const int ad = ((b * g.srcH + sy) * g.srcW + sx0) * 3;
+        const int ad = (int)(base + (unsigned)(sy * g.srcW + sx0) * 3u);
         const int a0 = live ? (ad & ~3) : (int)0x80000000u;
         raw[ky * 3 + 0] = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 0, 0);
         raw[ky * 3 + 1] = __builtin_amdgcn_raw_buffer_load_b32(irsrc, a0, 4, 0);
@@ -110,7 +128,7 @@ static __device__ __forceinline__ void frame_fetch_gen(const __amdgpu_buffer_rsr
     }
 }
 
-static __device__ __forceinline__ void frame_unpack_gen(const unsigned (&raw)[9], int b, int H, int W, const FrontGeom &g, int cy, int cx, float (&x)[27])
+static __device__ __forceinline__ void frame_unpack_gen(const unsigned (&raw)[9], unsigned base, int H, int W, const FrontGeom &g, int cy, int cx, float (&x)[27])
 {
     const float inv255 = (float)(1.0 / 255.0);
     const int sx0 = front_src(2 * cx, g.ws, g.srcW);
@@ -128,7 +146,7 @@ static __device__ __forceinline__ void frame_unpack_gen(const unsigned (&raw)[9]
         const bool yok = ky < 2 || iy < H;
         const bool yin = iy < g.nh;
         const int sy = front_src(iy, g.hs, g.srcH);
-        const int sh = (((b * g.srcH + sy) * g.srcW + sx0) * 3) & 3;
+        const int sh = (int)((base + (unsigned)(sy * g.srcW + sx0) * 3u) & 3u);
         const unsigned w0 = raw[ky * 3], w1 = raw[ky * 3 + 1], w2 = raw[ky * 3 + 2];
         const unsigned d0 = __builtin_amdgcn_alignbyte(w1, w0, sh);      // source bytes 0..3 of the row's span
         const unsigned d1 = __builtin_amdgcn_alignbyte(w2, w1, sh);      // 4..7
@@ -153,23 +171,26 @@ static __device__ __forceinline__ void frame_unpack_gen(const unsigned (&raw)[9]
 // (the read-only operands as `const __restrict__` kernel parameters: with them inside the by-value struct the compiler cannot
 //  prove the first convolution's weights invariant and loads them per lane into vector registers instead of with scalar loads)
 struct FrontDims { int B, H, W, act0, dact, act, tiles_y, tiles_x; };
-// GEN: the frames are resized on the fly (geometry gg); else they have the network's size H x W
-template <bool GEN>
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void front_kernel(const uint8_t *__restrict__ a_img, const float *__restrict__ a_w0,
                                                         const float *__restrict__ a_m0, const float *__restrict__ a_s0,
                                                         const float *__restrict__ a_b0, const float *__restrict__ a_dwpack,
                                                         const float *__restrict__ a_wt, const float *__restrict__ a_mean,
                                                         const float *__restrict__ a_sf, const float *__restrict__ a_beta,
-                                                        float *__restrict__ a_out, const FrontDims a, const FrontGeom gg)
+                                                        float *__restrict__ a_out, const FrontDims a, const typename FrontGeomArg<MODE>::type gg)
 {
+    constexpr bool GEN = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = a.H, W = a.W, OH = H >> 1, OW = W >> 1;
     const int tiles_img = a.tiles_y * a.tiles_x, total = a.B * tiles_img;
     // (GEN: the size rounded up to whole dwords -- a row's third dword may reach <= 3 bytes past a size that is no multiple of 4)
-    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)a_img, 0, GEN ? (int)((((long long)a.B * gg.srcH * gg.srcW * 3) + 3) & ~3LL) : (int)((long long)a.B * H * W * 3), 0x00020000);
+    int ibytes;
+    if constexpr (MODE == 2) ibytes = (int)gg.bytes4;
+    else if constexpr (MODE == 1) ibytes = (int)((((long long)a.B * gg.srcH * gg.srcW * 3) + 3) & ~3LL);
+    else ibytes = (int)((long long)a.B * H * W * 3);
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_img, 0, ibytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_out, 0, (int)((long long)a.B * OH * OW * 64 * 4), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
@@ -212,8 +233,12 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const uint8_t *__restrict
         int fy = ty * TY - 1 + ppy, fx = tx * TX - 1 + ppx;
         fy = fy < 0 ? 0 : (fy >= OH ? OH - 1 : fy);
         fx = fx < 0 ? 0 : (fx >= OW ? OW - 1 : fx);
-        if constexpr (GEN) frame_fetch_gen(irsrc, tid < NSLOT, b, gg, fy, fx, raw);
-        else frame_fetch(irsrc, tid < NSLOT, b, H, W, fy, fx, raw);
+        if constexpr (GEN) {
+            FrontGeom g;
+            unsigned base;
+            front_geom_of<MODE>(gg, b, g, base);
+            frame_fetch_gen(irsrc, tid < NSLOT, base, g, fy, fx, raw);
+        } else frame_fetch(irsrc, tid < NSLOT, b, H, W, fy, fx, raw);
     };
     int t = blockIdx.x;
     if (t < total) fetch(t);
@@ -227,8 +252,12 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const uint8_t *__restrict
             const bool inside = tid < NSLOT && (unsigned)fy < (unsigned)OH && (unsigned)fx < (unsigned)OW;
             const int cy = fy < 0 ? 0 : (fy >= OH ? OH - 1 : fy), cx = fx < 0 ? 0 : (fx >= OW ? OW - 1 : fx);
             float x[27];
-            if constexpr (GEN) frame_unpack_gen(raw, b, H, W, gg, cy, cx, x);
-            else frame_unpack(raw, b, H, W, cy, cx, x);
+            if constexpr (GEN) {
+                FrontGeom g;
+                unsigned base;
+                front_geom_of<MODE>(gg, b, g, base);
+                frame_unpack_gen(raw, base, H, W, g, cy, cx, x);
+            } else frame_unpack(raw, b, H, W, cy, cx, x);
             // the next tile's bytes: in flight until the next iteration's phase 1
             if (t + (int)gridDim.x < total) fetch(t + (int)gridDim.x);
             unsigned char *prow = lds + tid * 128;
@@ -363,19 +392,23 @@ struct FrontPoolDims { int B, H, W, act0, tiles_y, tiles_x; };
 // COUT: channels the convolution computes (24: the layer's width is 3 whole octets, so its physical channels are 0 .. 23);
 // CS: physical channels of a stored row -- 24, or 32 inside the network, whose tensors carry 8 zero pad channels (stored as zeros
 // here: round 5 -- computing them cost a quarter of the kernel's multiply-adds)
-// GEN: resized frames whose width does not shrink (geometry gg), as front_kernel<true>
-template <int COUT, int CS, bool GEN>
+// MODE: as front_kernel
+template <int COUT, int CS, int MODE>
 __global__ __launch_bounds__(256, 2) void front_pool_kernel(const uint8_t *__restrict__ a_img, const float *__restrict__ a_w0,
                                                              const float *__restrict__ a_m0, const float *__restrict__ a_s0,
                                                              const float *__restrict__ a_b0, float *__restrict__ a_out,
-                                                             const FrontPoolDims a, const FrontGeom gg)
+                                                             const FrontPoolDims a, const typename FrontGeomArg<MODE>::type gg)
 {
+    constexpr bool GEN = MODE != 0;
     __shared__ __attribute__((aligned(16))) unsigned char lds[QSLOT * 128];      // patch rows of 128 B: 6 chunks used, chunk c at slot c ^ (row & 7)
     const int tid = threadIdx.x;
     const int H = a.H, W = a.W, OH = H >> 1, OW = W >> 1, PH2 = OH >> 1, PW2 = OW >> 1;
     const int tiles_img = a.tiles_y * a.tiles_x, total = a.B * tiles_img;
-    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)a_img, 0, GEN ? (int)((((long long)a.B * gg.srcH * gg.srcW * 3) + 3) & ~3LL) : (int)((long long)a.B * H * W * 3), 0x00020000);
+    int ibytes;
+    if constexpr (MODE == 2) ibytes = (int)gg.bytes4;
+    else if constexpr (MODE == 1) ibytes = (int)((((long long)a.B * gg.srcH * gg.srcW * 3) + 3) & ~3LL);
+    else ibytes = (int)((long long)a.B * H * W * 3);
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_img, 0, ibytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_out, 0, (int)((long long)a.B * PH2 * PW2 * CS * 4), 0x00020000);
     const int ppy = tid / QPW, ppx = tid - ppy * QPW;
     unsigned raw[9];
@@ -384,8 +417,12 @@ __global__ __launch_bounds__(256, 2) void front_pool_kernel(const uint8_t *__res
         int fy = 2 * QY * ty + ppy, fx = 2 * QX * tx + ppx;
         fy = fy >= OH ? OH - 1 : fy;
         fx = fx >= OW ? OW - 1 : fx;
-        if constexpr (GEN) frame_fetch_gen(irsrc, tid < QSLOT, b, gg, fy, fx, raw);
-        else frame_fetch(irsrc, tid < QSLOT, b, H, W, fy, fx, raw);
+        if constexpr (GEN) {
+            FrontGeom g;
+            unsigned base;
+            front_geom_of<MODE>(gg, b, g, base);
+            frame_fetch_gen(irsrc, tid < QSLOT, base, g, fy, fx, raw);
+        } else frame_fetch(irsrc, tid < QSLOT, b, H, W, fy, fx, raw);
     };
     int t = blockIdx.x;
     if (t < total) fetch(t);
@@ -396,8 +433,12 @@ __global__ __launch_bounds__(256, 2) void front_pool_kernel(const uint8_t *__res
             const bool inside = tid < QSLOT && fy < OH && fx < OW;
             const int cy = fy >= OH ? OH - 1 : fy, cx = fx >= OW ? OW - 1 : fx;
             float x[27];
-            if constexpr (GEN) frame_unpack_gen(raw, b, H, W, gg, cy, cx, x);
-            else frame_unpack(raw, b, H, W, cy, cx, x);
+            if constexpr (GEN) {
+                FrontGeom g;
+                unsigned base;
+                front_geom_of<MODE>(gg, b, g, base);
+                frame_unpack_gen(raw, base, H, W, g, cy, cx, x);
+            } else frame_unpack(raw, b, H, W, cy, cx, x);
             if (t + (int)gridDim.x < total) fetch(t + (int)gridDim.x);
             unsigned char *prow = lds + tid * 128;
             {                                                // all COUT accumulators in one pass over the 27 taps
@@ -461,10 +502,32 @@ bool front_pool_supports(int B, int H, int W, int C0)
     return (long long)B * H * W * 3 < (1LL << 31);
 }
 
+// resized frames: the width must not shrink (a filter row = 9 contiguous source bytes), 32-bit byte offsets into the frames
+bool front_gen_supports(int B, int srcH, int srcW, int nh, int nw)
+{
+    return B >= 1 && srcH >= 1 && srcW >= 1 && nh >= 1 && nw >= srcW && (long long)B * srcH * srcW * 3 + 3 < (1LL << 31);
+}
+
+// ... frames first .. first + B - 1 of a mixed-size batch: each of them, and the table's byte range (*bytes4: its end, rounded up)
+bool front_mixed_supports(const MixedGeom &mg, int first, int B, int H, int W, unsigned *bytes4)
+{
+    if (B < 1 || first < 0 || first + B > SSD_MIXED_MAX) return false;
+    unsigned long long end = 0;
+    for (int b = first; b < first + B; ++b) {
+        const FrameGeom &g = mg.f[b];
+        if (g.srcH < 1 || g.srcW < 1 || g.nh < 1 || g.nw < g.srcW || g.nh > H || g.nw > W) return false;
+        end = std::max(end, (unsigned long long)g.off + (unsigned long long)g.srcH * g.srcW * 3);
+    }
+    if (end + 3 >= (1ull << 31)) return false;
+    if (bytes4) *bytes4 = (unsigned)((end + 3) & ~3ull);
+    return true;
+}
+
 // src: null = frames of the network's size [B,H,W,3]; else {srcH, srcW, nh, nw}: frames [B,srcH,srcW,3] resized to [nh,nw] and padded
-// to [H,W] on the fly (front_gen_supports: the width does not shrink)
+// to [H,W] on the fly (front_gen_supports: the width does not shrink); mixed: frames of different sizes, entries first .. of the table
+// (then img is the base the entries' byte offsets count from)
 hipError_t launch_front_pool(const uint8_t *img, int B, int H, int W, const float *w0, int C0, const float *m0, const float *s0, const float *b0,
-                             int act0, float *out, hipStream_t s, const int *src)
+                             int act0, float *out, hipStream_t s, const int *src, const MixedGeom *mixed, int first)
 {
     if (!img || !w0 || !m0 || !s0 || !b0 || !out || !front_pool_supports(B, H, W, C0)) return hipErrorInvalidValue;
     if (src && (!front_gen_supports(B, src[0], src[1], src[2], src[3]) || src[2] > H || src[3] > W)) return hipErrorInvalidValue;
@@ -472,14 +535,23 @@ hipError_t launch_front_pool(const uint8_t *img, int B, int H, int W, const floa
     const long long total = (long long)B * d.tiles_y * d.tiles_x;
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
     const int grid = (int)(total < 4096 ? total : 4096);
+    if (mixed) {
+        FrontMixed fm;
+        if (!front_mixed_supports(*mixed, first, B, H, W, &fm.bytes4)) return hipErrorInvalidValue;
+        fm.mg = *mixed;
+        fm.first = first;
+        if (C0 == 24) hipLaunchKernelGGL((front_pool_kernel<24, 24, 2>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, fm);
+        else hipLaunchKernelGGL((front_pool_kernel<24, 32, 2>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, fm);
+        return hipGetLastError();
+    }
     const FrontGeom g = src ? FrontGeom{src[0], src[1], src[2], src[3], (float)src[0] / (float)src[2], (float)src[1] / (float)src[3]}
                             : FrontGeom{H, W, H, W, 1.0f, 1.0f};
     if (src) {
-        if (C0 == 24) hipLaunchKernelGGL((front_pool_kernel<24, 24, true>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, g);
-        else hipLaunchKernelGGL((front_pool_kernel<24, 32, true>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, g);
+        if (C0 == 24) hipLaunchKernelGGL((front_pool_kernel<24, 24, 1>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, g);
+        else hipLaunchKernelGGL((front_pool_kernel<24, 32, 1>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, g);
     } else {
-        if (C0 == 24) hipLaunchKernelGGL((front_pool_kernel<24, 24, false>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, g);
-        else hipLaunchKernelGGL((front_pool_kernel<24, 32, false>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, g);
+        if (C0 == 24) hipLaunchKernelGGL((front_pool_kernel<24, 24, 0>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, g);
+        else hipLaunchKernelGGL((front_pool_kernel<24, 32, 0>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, g);
     }
     return hipGetLastError();
 }
@@ -490,17 +562,11 @@ bool front_supports(int B, int H, int W, int C0, int K, int Cout)
     return (long long)B * H * W * 3 < (1LL << 31) && (long long)B * (H / 2) * (W / 2) * 64 * 4 < (1LL << 31);
 }
 
-// resized frames: the width must not shrink (a filter row = 9 contiguous source bytes), 32-bit byte offsets into the frames
-bool front_gen_supports(int B, int srcH, int srcW, int nh, int nw)
-{
-    return B >= 1 && srcH >= 1 && srcW >= 1 && nh >= 1 && nw >= srcW && (long long)B * srcH * srcW * 3 + 3 < (1LL << 31);
-}
-
 hipError_t launch_front(const FrontArgs &q, hipStream_t s)
 {
     if (!q.img || !q.w0 || !q.m0 || !q.s0 || !q.b0 || !q.dwpack || !q.wt || !q.mean || !q.sf || !q.beta || !q.out) return hipErrorInvalidValue;
     if (!front_supports(q.B, q.H, q.W, 32, 32, 64)) return hipErrorInvalidValue;
-    if (q.resized && (!front_gen_supports(q.B, q.srcH, q.srcW, q.nh, q.nw) || q.nh > q.H || q.nw > q.W)) return hipErrorInvalidValue;
+    if (!q.mixed && q.resized && (!front_gen_supports(q.B, q.srcH, q.srcW, q.nh, q.nw) || q.nh > q.H || q.nw > q.W)) return hipErrorInvalidValue;
     const int OH = q.H / 2, OW = q.W / 2;
     if (q.tiles_y != (OH + TY - 1) / TY || q.tiles_x != (OW + TX - 1) / TX) return hipErrorInvalidValue;
     const long long total = (long long)q.B * q.tiles_y * q.tiles_x;
@@ -509,14 +575,21 @@ hipError_t launch_front(const FrontArgs &q, hipStream_t s)
     // 512 / 756 blocks -> 34.2 / 32.8 / 28.8 / 32.1 us; 32 frames: 512 / 1024 / 2048 the same step time)
     const int grid = (int)(total < 512 ? total : 512);
     const FrontDims d = {q.B, q.H, q.W, q.act0, q.dact, q.act, q.tiles_y, q.tiles_x};
-    if (q.resized) {
+    if (q.mixed) {
+        FrontMixed fm;
+        if (!front_mixed_supports(*q.mixed, q.mixed_first, q.B, q.H, q.W, &fm.bytes4)) return hipErrorInvalidValue;
+        fm.mg = *q.mixed;
+        fm.first = q.mixed_first;
+        hipLaunchKernelGGL(front_kernel<2>, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, q.img, q.w0, q.m0, q.s0, q.b0, q.dwpack, q.wt, q.mean,
+                           q.sf, q.beta, q.out, d, fm);
+    } else if (q.resized) {
         // (the scale factors as launch_first_conv forms them: the same float expressions as elementwise.hip K1 / K1d)
         const FrontGeom g = {q.srcH, q.srcW, q.nh, q.nw, (float)q.srcH / (float)q.nh, (float)q.srcW / (float)q.nw};
-        hipLaunchKernelGGL(front_kernel<true>, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, q.img, q.w0, q.m0, q.s0, q.b0, q.dwpack, q.wt, q.mean,
+        hipLaunchKernelGGL(front_kernel<1>, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, q.img, q.w0, q.m0, q.s0, q.b0, q.dwpack, q.wt, q.mean,
                            q.sf, q.beta, q.out, d, g);
     } else {
         const FrontGeom g = {q.H, q.W, q.H, q.W, 1.0f, 1.0f};
-        hipLaunchKernelGGL(front_kernel<false>, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, q.img, q.w0, q.m0, q.s0, q.b0, q.dwpack, q.wt, q.mean,
+        hipLaunchKernelGGL(front_kernel<0>, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, q.img, q.w0, q.m0, q.s0, q.b0, q.dwpack, q.wt, q.mean,
                            q.sf, q.beta, q.out, d, g);
     }
     return hipGetLastError();

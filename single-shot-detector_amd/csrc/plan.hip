@@ -423,16 +423,20 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
             // RESIZED frames whose width does not shrink (every COCO image at min_dimension 640) take the same fused launch with the
             // gather in its loads (front.hip, GEN).  Decided per CALL: the source geometry is a launch argument and a plan serves any
             // source size that lands on its network shape, so such a plan keeps both forms -- the first-convolution op launches the
-            // fused kernel and the Conv2d_1 op does nothing, or (a frame that is reduced in width, a batch of mixed sizes) the two
-            // run as themselves.  Same conditions as the static form, plus Conv2d_1 being ONE op (the fused depthwise + pointwise).
+            // fused kernel and the Conv2d_1 op does nothing, or (a frame that is reduced in width) the two run as themselves.  A
+            // batch of frames of DIFFERENT sizes takes the fused launch too (per-frame geometry from its arguments) when none of its
+            // frames is reduced in width.  Same conditions as the static form, plus Conv2d_1 being ONE op (the fused depthwise + pointwise).
             bool front_rt = !ident && ((fuse_mask >> 0) & 1) && h->first.mean && h->dw[0].pack &&
                             h->pw[0].taps == 1 && h->pw[0].mean && !h->pw[0].bias && front_supports(nb, H, W, h->firstCp, h->dw[0].Cp, h->pw[0].CoutP) &&
                             h->pw[0].CinP == 32 && MB_STRIDE[0] == 1 && dwpws_eligible(h->dw[0], h->pw[0], nb, h2, w2, MB_STRIDE[0]);
             { const int pin = ssd_opt(h, OPT_FRONT_FUSE, -1); if (pin >= 0) front_rt = front_rt && pin != 0; }
             ssd_handle *const hrt = h;
-            auto fused_now = [hrt, nb, front_rt]() {
+            const int rt_first = img0 + b0;
+            auto fused_now = [hrt, nb, front_rt, rt_first, H, W]() {
+                if (!front_rt) return false;
+                if (hrt->mixed) return front_mixed_supports(hrt->mixed->geom, rt_first, nb, H, W);      // every frame of this chain's share
                 const SrcGeom &g = hrt->src;
-                return front_rt && !hrt->mixed && front_gen_supports(nb, g.srcH, g.srcW, g.nh, g.nw);
+                return front_gen_supports(nb, g.srcH, g.srcW, g.nh, g.nw);
             };
             if (!front) {
                 Op op;
@@ -455,8 +459,16 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
                     fq.tiles_x = (W / 2 + front_tile_x() - 1) / front_tile_x();
                 }
                 op.run = [=](hipStream_t s) {      // the source's size and the resize's target: this call's (SrcGeom), any that lands on H x W
-                    if (hh->mixed)                 // ... or every frame's own (a batch of frames of different sizes)
+                    if (hh->mixed) {               // ... or every frame's own (a batch of frames of different sizes)
+                        if (fused_now()) {
+                            FrontArgs r = fq;
+                            r.img = hh->cur_images;
+                            r.mixed = &hh->mixed->geom;
+                            r.mixed_first = first_img;
+                            return launch_front(r, s);
+                        }
                         return launch_first_conv_mixed(hh->cur_images, hh->mixed->geom, first_img, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, X, s, variant);
+                    }
                     const SrcGeom &g = hh->src;
                     if (fused_now()) {
                         FrontArgs r = fq;
@@ -626,13 +638,18 @@ static int build_plan(ssd_handle *h, Plan &pl, int B, int H, int W, bool ident, 
                     // MobileNet's above): this op then writes the pooled tensor and the max-pool op does nothing
                     bool front_rt = !ident && h->first.mean && front_pool_supports(nb, H, W, fc);
                     { const int pin = ssd_opt(h, OPT_FRONT_FUSE, -1); if (pin >= 0) front_rt = front_rt && pin != 0; }
-                    auto fused_now = [hh, nb, front_rt]() {
+                    auto fused_now = [hh, nb, front_rt, first_img, H, W]() {
+                        if (!front_rt) return false;
+                        if (hh->mixed) return front_mixed_supports(hh->mixed->geom, first_img, nb, H, W);
                         const SrcGeom &g = hh->src;
-                        return front_rt && !hh->mixed && front_gen_supports(nb, g.srcH, g.srcW, g.nh, g.nw);
+                        return front_gen_supports(nb, g.srcH, g.srcW, g.nh, g.nw);
                     };
                     op.run = [=](hipStream_t s) {
-                        if (hh->mixed)
+                        if (hh->mixed) {
+                            if (fused_now())
+                                return launch_front_pool(hh->cur_images, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, MP, s, nullptr, &hh->mixed->geom, first_img);
                             return launch_first_conv_mixed(hh->cur_images, hh->mixed->geom, first_img, nb, H, W, f.w, f.Cp, f.mean, f.sf, f.beta, act, F, s, variant);
+                        }
                         const SrcGeom &g = hh->src;
                         if (fused_now()) {
                             const int src[4] = {g.srcH, g.srcW, g.nh, g.nw};

@@ -172,6 +172,11 @@ hipError_t launch_pw_gather(const PwGArgs &a, hipStream_t s);
 
 // MobileNet's first three layers in one launch (front.hip): first convolution 3x3 stride 2 on the uint8 frame (3 -> 32) ->
 // depthwise 3x3 -> pointwise 32 -> 64, each with its batch norm and activation; the 32-channel tensor stays in LDS --------
+// a batch of frames of DIFFERENT sizes that resize to the same [H,W] (ssd_forward_mixed): per frame its byte offset in the image
+// block, its size, its resize target and the two scale factors; the table travels in kernel arguments, at most SSD_MIXED_MAX frames
+#define SSD_MIXED_MAX 64
+struct FrameGeom { unsigned off; int srcH, srcW, nh, nw; float hs, ws; };
+struct MixedGeom { FrameGeom f[SSD_MIXED_MAX]; };
 struct FrontArgs {
     const uint8_t *img;                    // [B,H,W,3] uint8 frames at the network's input size (identity resize), H and W even
     const float *w0, *m0, *s0, *b0;        // first convolution: [27][32] weights (physical output order), batch norm [32]
@@ -184,9 +189,12 @@ struct FrontArgs {
     int tiles_y, tiles_x;                  // ceil((H/2) / front_tile_y()), ceil((W/2) / front_tile_x())
     int resized;                           // 1: img holds [B,srcH,srcW,3] frames that are resized to [nh,nw] and padded to [H,W] on the fly
     int srcH, srcW, nh, nw;                //    (resize_keeping_aspect_ratio; needs front_gen_supports: the width does not shrink)
+    const MixedGeom *mixed;                // non-null: frames of different sizes, entries mixed_first .. + B - 1 (img = the offsets' base)
+    int mixed_first;
 };
 bool front_supports(int B, int H, int W, int C0, int K, int Cout);
 bool front_gen_supports(int B, int srcH, int srcW, int nh, int nw);
+bool front_mixed_supports(const MixedGeom &mg, int first, int B, int H, int W, unsigned *bytes4 = nullptr);
 int front_tile_y();
 int front_tile_x();
 hipError_t launch_front(const FrontArgs &q, hipStream_t s);
@@ -195,7 +203,8 @@ hipError_t launch_front(const FrontArgs &q, hipStream_t s);
 // multiples of 4), w0 [27][C0] -> out [B,H/4,W/4,C0]
 bool front_pool_supports(int B, int H, int W, int C0);
 hipError_t launch_front_pool(const uint8_t *img, int B, int H, int W, const float *w0, int C0, const float *m0, const float *s0, const float *b0,
-                             int act0, float *out, hipStream_t s, const int *src = nullptr /* {srcH, srcW, nh, nw}: resized frames */);
+                             int act0, float *out, hipStream_t s, const int *src = nullptr /* {srcH, srcW, nh, nw}: resized frames */,
+                             const MixedGeom *mixed = nullptr, int first = 0);
 
 // elementwise / memory-bound kernels -----------------------------------------------------
 // source image [B,srcH,srcW,3] is NN-resized to [nh,nw], zero padded to [H,W] (even), normalised and convolved
@@ -206,9 +215,6 @@ hipError_t launch_first_conv(const uint8_t *img, int B, int srcH, int srcW, int 
 // ... the same for a batch of frames of DIFFERENT sizes that resize to the same [H,W] (ssd_forward_mixed): frame b of the launch is
 // geometry entry first + b -- its byte offset in `img`, its size, its resize target and the two scale factors -- and the table
 // travels in the kernel's arguments (no upload, nothing to keep alive): at most SSD_MIXED_MAX frames per batch
-#define SSD_MIXED_MAX 64
-struct FrameGeom { unsigned off; int srcH, srcW, nh, nw; float hs, ws; };
-struct MixedGeom { FrameGeom f[SSD_MIXED_MAX]; };
 hipError_t launch_first_conv_mixed(const uint8_t *img, const MixedGeom &mg, int first, int B, int H, int W, const float *w, int Cout,
                                    const float *mean, const float *sf, const float *beta, int act, float *out, hipStream_t s, int variant = 0);
 hipError_t launch_depthwise(const float *in, int B, int H, int W, int C, const float *w /*[9][C]*/,
