@@ -403,6 +403,19 @@ def test_coco_box_metric_known_answers(ssd):
     # ... and a MISSED small object shows in APs / ARs only
     st = cm.evaluate_boxes(gt, dt[1:])
     assert np.isclose(st[3], 0.0) and np.isclose(st[9], 0.0) and np.isclose(st[5], 1.0) and np.isclose(st[8], 0.5)
+    # (6) the ignore rules between area ranges.  Two objects whose boxes overlap: A (annotation area 40 000: large) and B (its box is
+    #     large too, its segmentation area 5 000: medium); one detection with IoU 0.92 to A and 0.674 to B, itself large.
+    #     all:    it takes A (the higher IoU) up to t = 0.90, B is never found: 9 x (51 / 101) / 10
+    #     medium: A is out of range = ignore, sorted behind B.  t <= 0.65: B matches and holds against the ignore box -> a true
+    #             positive although the detection's own area is out of range; above: only A matches -> the detection is ignored
+    #             (no false positive), B stays unfound: 4 / 10
+    #     large:  B is ignore; the detection takes A up to 0.90 -> 1; at 0.95 it matches nothing and counts as a false positive: 0.9
+    gt = _coco_gt({(1, 1): [[0, 0, 200, 200], [0, 0, 200, 124]]}, areas={(1, 1, 0): 40000.0, (1, 1, 1): 5000.0})
+    dt = [{"image_id": 1, "category_id": 1, "bbox": [0, 0, 200, 184], "score": 0.8}]
+    assert np.allclose(cm.bbox_iou([dt[0]["bbox"]], [a["bbox"] for a in gt["annotations"]], [0, 0]), [[0.92, 124 / 184]])
+    st = cm.evaluate_boxes(gt, dt)
+    assert np.isclose(st[0], 9 * (51 / 101) / 10) and np.isclose(st[4], 0.4) and np.isclose(st[5], 0.9) and st[3] == -1
+    assert np.isclose(st[10], 0.4) and np.isclose(st[11], 0.9) and np.isclose(st[8], 0.45)
     with pytest.raises(ValueError):
         cm.evaluate_boxes(gt, [{"image_id": 99, "category_id": 1, "bbox": [0, 0, 1, 1], "score": 1.0}])
     import io
