@@ -133,6 +133,52 @@ def test_first_convolution_of_resized_frames_both_kernels(cuda, ssd, oracle_grap
         e.close()
 
 
+@pytest.mark.parametrize("backbone", ["mobilenet", "shufflenet"])
+def test_first_layers_of_resized_frames_random_sizes(cuda, ssd, oracle_graph, backbone):
+    """A seeded sweep of source sizes (1 .. 300 in either direction: every byte alignment of a row's first pixel, spans that end at
+    the last pixel of a row or of the buffer, widths that shrink and widths that do not) through the three forms of the first
+    layers -- fused launch with the gather (where the width does not shrink), lane-per-pixel first convolution, rounds-1-5 first
+    convolution: identical bits; every eighth size against the oracle as well.  Then the same frames as mixed-size batches (the
+    fused launch with per-frame geometry) against each frame alone."""
+    params = dict(TINY_PARAMS, backbone=backbone)
+    W = ssd.synthetic_weights(params, seed=21, logits_bias=-3.0)
+    new, mid, old = ssd.Engine(params, W), ssd.Engine(params, W), ssd.Engine(params, W)
+    mid.set_option("front_fuse", 0)
+    old.set_option("front_fuse", 0)
+    old.set_option("first_conv_px", 0)
+    rng = np.random.default_rng(2024)
+    by_shape, fused_sizes = {}, 0
+    for n in range(48):
+        h, w = int(rng.integers(1, 301)), int(rng.integers(1, 301))
+        img = rng.integers(0, 256, (1, h, w, 3), dtype=np.uint8)
+        a = [t.cpu().numpy() for t in new.forward(cuda.from_numpy(img).cuda())]
+        for other in (mid, old):
+            b = [t.cpu().numpy() for t in other.forward(cuda.from_numpy(img).cuda())]
+            for k in range(4):
+                assert np.array_equal(a[k], b[k]), (backbone, h, w, k)
+            assert np.array_equal(new.get_tensor("c3"), other.get_tensor("c3")), (backbone, h, w)
+        if n % 8 == 0:
+            ref = oracle_graph.forward(img, W, params)
+            for a_k, key in zip(a, ("boxes", "labels", "scores", "num_boxes")):
+                assert np.array_equal(a_k, ref[key]), (backbone, h, w, key)
+        nh, nw, _ = ssd.network_input_size(h, w, params["min_dimension"])
+        fused_sizes += int(w <= nw * 1.0 and (h, w) != (nh, nw))
+        by_shape.setdefault((nh, nw), []).append((img[0], [x[0] for x in a]))
+    assert fused_sizes > 20 and len(by_shape) >= 3
+    checked = 0
+    for shape, items in by_shape.items():
+        for k0 in range(0, len(items), 7):
+            part = items[k0:k0 + 7]
+            got = [np.array(v) for v in new.detect_host_mixed([f for f, _ in part])]
+            for i, (_f, alone) in enumerate(part):
+                for k in range(4):
+                    assert np.array_equal(got[k][i], alone[k]), (backbone, shape, i, k)
+            checked += len(part)
+    assert checked == 48
+    for e in (new, mid, old):
+        e.close()
+
+
 def test_cycle_of_sizes_through_one_detector_full_size(cuda, ssd, oracle_graph):
     """A, B, A, C, B, A (+ D, which shares C's network shape with another resize target, + E at the network's own size) through
     ONE Detector: every call equals a fresh single-plan engine's result and the oracle's, bit for bit; the library built one
