@@ -385,15 +385,27 @@ __global__ __launch_bounds__(256) void first_conv_gen_mixed_kernel(const uint8_t
 static bool launch_first_conv_gen(const uint8_t *img, unsigned long long img_bytes, const FrameGeom *one, const MixedGeom *mg, int first, int B, int H, int W,
                                   const float *w, int Cout, const float *mean, const float *sf, const float *beta, int act, float *out, hipStream_t s)
 {
-    if (Cout != 32 || img_bytes + 3 >= (1ull << 31)) return false;
+    if (Cout != 32 || img_bytes + 6 >= (1ull << 31)) return false;
+    // The kernel's dword loads are aligned RELATIVE TO ITS BASE: a base that is not a multiple of 4 itself (the second chain's or
+    // sub-batch's first frame when a frame's byte size is odd, a caller's slice) is rounded down and the remainder added to every
+    // frame's byte offset, so that no load depends on the device's unaligned-access mode.
+    const unsigned adj = (unsigned)((uintptr_t)img & 3u);
+    img -= adj;
     const size_t lds = (size_t)256 * 32 * sizeof(float);
-    const unsigned bytes4 = (unsigned)((img_bytes + 3) & ~3ull);      // (a pixel's second dword may reach <= 3 bytes past a size that is no multiple of 4: the same word)
+    const unsigned bytes4 = (unsigned)((img_bytes + adj + 3) & ~3ull);      // (a pixel's second dword may reach <= 3 bytes past a size that is no multiple of 4: the same word)
     const long long px = (long long)B * (H / 2) * (W / 2);
     long long blocks = (px + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     const dim3 grid((unsigned)blocks), blk(256);
-    if (one) hipLaunchKernelGGL(first_conv_gen_kernel<32>, grid, blk, lds, s, img, bytes4, *one, B, H, W, w, Cout, mean, sf, beta, act, out);
-    else hipLaunchKernelGGL(first_conv_gen_mixed_kernel<32>, grid, blk, lds, s, img, bytes4, *mg, first, B, H, W, w, Cout, mean, sf, beta, act, out);
+    if (one) {
+        FrameGeom g = *one;
+        g.off += adj;
+        hipLaunchKernelGGL(first_conv_gen_kernel<32>, grid, blk, lds, s, img, bytes4, g, B, H, W, w, Cout, mean, sf, beta, act, out);
+    } else {
+        MixedGeom t = *mg;
+        for (int b = first; b < first + B; ++b) t.f[b].off += adj;
+        hipLaunchKernelGGL(first_conv_gen_mixed_kernel<32>, grid, blk, lds, s, img, bytes4, t, first, B, H, W, w, Cout, mean, sf, beta, act, out);
+    }
     return true;
 }
 

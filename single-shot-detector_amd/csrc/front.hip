@@ -87,7 +87,7 @@ static __device__ __forceinline__ void frame_unpack(const unsigned (&raw)[9], in
 // network's own size -- and tap kx takes the pixel sx(2 cx + kx) - sx(2 cx) in {0, 1, 2} of them.  Rows are three independent
 // source rows (any vertical scale).  Beyond the resize's target (the zero pad band) a tap is 0 before the normalisation, beyond
 // the padded frame 0 after it.
-struct FrontGeom { int srcH, srcW, nh, nw; float hs, ws; };
+struct FrontGeom { int srcH, srcW, nh, nw; float hs, ws; unsigned off0; };      // off0: byte offset of frame 0 from the (4-byte aligned) base
 // MODE of the two kernels below: 0 = frames of the network's size, 1 = resized frames of ONE size (FrontGeom; frame b starts at byte
 // b * srcH * srcW * 3), 2 = a batch of frames of DIFFERENT sizes (ssd_forward_mixed): frame b's geometry and byte offset are entry
 // first + b of the table in the kernel's arguments -- a tile belongs to one frame, so the entry is read with scalar loads
@@ -103,7 +103,7 @@ static __device__ __forceinline__ void front_geom_of(const typename FrontGeomArg
         base = f.off;
     } else {
         g = ga;
-        base = (unsigned)b * (unsigned)ga.srcH * (unsigned)ga.srcW * 3u;
+        base = ga.off0 + (unsigned)b * (unsigned)ga.srcH * (unsigned)ga.srcW * 3u;
     }
 }
 
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const uint8_t *__restrict
     // (GEN: the size rounded up to whole dwords -- a row's third dword may reach <= 3 bytes past a size that is no multiple of 4)
     int ibytes;
     if constexpr (MODE == 2) ibytes = (int)gg.bytes4;
-    else if constexpr (MODE == 1) ibytes = (int)((((long long)a.B * gg.srcH * gg.srcW * 3) + 3) & ~3LL);
+    else if constexpr (MODE == 1) ibytes = (int)((((long long)a.B * gg.srcH * gg.srcW * 3) + gg.off0 + 3) & ~3LL);
     else ibytes = (int)((long long)a.B * H * W * 3);
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_img, 0, ibytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_out, 0, (int)((long long)a.B * OH * OW * 64 * 4), 0x00020000);
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void front_pool_kernel(const uint8_t *__res
     const int tiles_img = a.tiles_y * a.tiles_x, total = a.B * tiles_img;
     int ibytes;
     if constexpr (MODE == 2) ibytes = (int)gg.bytes4;
-    else if constexpr (MODE == 1) ibytes = (int)((((long long)a.B * gg.srcH * gg.srcW * 3) + 3) & ~3LL);
+    else if constexpr (MODE == 1) ibytes = (int)((((long long)a.B * gg.srcH * gg.srcW * 3) + gg.off0 + 3) & ~3LL);
     else ibytes = (int)((long long)a.B * H * W * 3);
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_img, 0, ibytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_out, 0, (int)((long long)a.B * PH2 * PW2 * CS * 4), 0x00020000);
@@ -505,11 +505,11 @@ bool front_pool_supports(int B, int H, int W, int C0)
 // resized frames: the width must not shrink (a filter row = 9 contiguous source bytes), 32-bit byte offsets into the frames
 bool front_gen_supports(int B, int srcH, int srcW, int nh, int nw)
 {
-    return B >= 1 && srcH >= 1 && srcW >= 1 && nh >= 1 && nw >= srcW && (long long)B * srcH * srcW * 3 + 3 < (1LL << 31);
+    return B >= 1 && srcH >= 1 && srcW >= 1 && nh >= 1 && nw >= srcW && (long long)B * srcH * srcW * 3 + 6 < (1LL << 31);
 }
 
-// ... frames first .. first + B - 1 of a mixed-size batch: each of them, and the table's byte range (*bytes4: its end, rounded up)
-bool front_mixed_supports(const MixedGeom &mg, int first, int B, int H, int W, unsigned *bytes4)
+// ... frames first .. first + B - 1 of a mixed-size batch: each of them, and the table's byte range (*end_bytes: its exact end)
+bool front_mixed_supports(const MixedGeom &mg, int first, int B, int H, int W, unsigned *end_bytes)
 {
     if (B < 1 || first < 0 || first + B > SSD_MIXED_MAX) return false;
     unsigned long long end = 0;
@@ -518,8 +518,8 @@ bool front_mixed_supports(const MixedGeom &mg, int first, int B, int H, int W, u
         if (g.srcH < 1 || g.srcW < 1 || g.nh < 1 || g.nw < g.srcW || g.nh > H || g.nw > W) return false;
         end = std::max(end, (unsigned long long)g.off + (unsigned long long)g.srcH * g.srcW * 3);
     }
-    if (end + 3 >= (1ull << 31)) return false;
-    if (bytes4) *bytes4 = (unsigned)((end + 3) & ~3ull);
+    if (end + 6 >= (1ull << 31)) return false;
+    if (end_bytes) *end_bytes = (unsigned)end;                // (the exact end; the launch rounds it up behind its base adjustment)
     return true;
 }
 
@@ -535,17 +535,23 @@ hipError_t launch_front_pool(const uint8_t *img, int B, int H, int W, const floa
     const long long total = (long long)B * d.tiles_y * d.tiles_x;
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
     const int grid = (int)(total < 4096 ? total : 4096);
+    // (resized / mixed: the kernel's dword loads are aligned relative to its base -- a base that is no multiple of 4 is rounded down
+    //  and the remainder added to the frames' byte offsets, elementwise.hip launch_first_conv_gen)
+    const unsigned adj = (src || mixed) ? (unsigned)((uintptr_t)img & 3u) : 0u;
+    img -= adj;
     if (mixed) {
         FrontMixed fm;
         if (!front_mixed_supports(*mixed, first, B, H, W, &fm.bytes4)) return hipErrorInvalidValue;
         fm.mg = *mixed;
+        for (int b = first; b < first + B; ++b) fm.mg.f[b].off += adj;
+        fm.bytes4 = (fm.bytes4 + adj + 3u) & ~3u;
         fm.first = first;
         if (C0 == 24) hipLaunchKernelGGL((front_pool_kernel<24, 24, 2>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, fm);
         else hipLaunchKernelGGL((front_pool_kernel<24, 32, 2>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, fm);
         return hipGetLastError();
     }
-    const FrontGeom g = src ? FrontGeom{src[0], src[1], src[2], src[3], (float)src[0] / (float)src[2], (float)src[1] / (float)src[3]}
-                            : FrontGeom{H, W, H, W, 1.0f, 1.0f};
+    const FrontGeom g = src ? FrontGeom{src[0], src[1], src[2], src[3], (float)src[0] / (float)src[2], (float)src[1] / (float)src[3], adj}
+                            : FrontGeom{H, W, H, W, 1.0f, 1.0f, 0u};
     if (src) {
         if (C0 == 24) hipLaunchKernelGGL((front_pool_kernel<24, 24, 1>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, g);
         else hipLaunchKernelGGL((front_pool_kernel<24, 32, 1>), dim3((unsigned)grid), dim3(256), 0, s, img, w0, m0, s0, b0, out, d, g);
@@ -575,20 +581,25 @@ hipError_t launch_front(const FrontArgs &q, hipStream_t s)
     // 512 / 756 blocks -> 34.2 / 32.8 / 28.8 / 32.1 us; 32 frames: 512 / 1024 / 2048 the same step time)
     const int grid = (int)(total < 512 ? total : 512);
     const FrontDims d = {q.B, q.H, q.W, q.act0, q.dact, q.act, q.tiles_y, q.tiles_x};
+    // (resized / mixed: loads aligned relative to a base that is itself a multiple of 4, as in launch_front_pool)
+    const unsigned adj = (q.mixed || q.resized) ? (unsigned)((uintptr_t)q.img & 3u) : 0u;
+    const uint8_t *img = q.img - adj;
     if (q.mixed) {
         FrontMixed fm;
         if (!front_mixed_supports(*q.mixed, q.mixed_first, q.B, q.H, q.W, &fm.bytes4)) return hipErrorInvalidValue;
         fm.mg = *q.mixed;
+        for (int b = q.mixed_first; b < q.mixed_first + q.B; ++b) fm.mg.f[b].off += adj;
+        fm.bytes4 = (fm.bytes4 + adj + 3u) & ~3u;
         fm.first = q.mixed_first;
-        hipLaunchKernelGGL(front_kernel<2>, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, q.img, q.w0, q.m0, q.s0, q.b0, q.dwpack, q.wt, q.mean,
+        hipLaunchKernelGGL(front_kernel<2>, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, img, q.w0, q.m0, q.s0, q.b0, q.dwpack, q.wt, q.mean,
                            q.sf, q.beta, q.out, d, fm);
     } else if (q.resized) {
         // (the scale factors as launch_first_conv forms them: the same float expressions as elementwise.hip K1 / K1d)
-        const FrontGeom g = {q.srcH, q.srcW, q.nh, q.nw, (float)q.srcH / (float)q.nh, (float)q.srcW / (float)q.nw};
-        hipLaunchKernelGGL(front_kernel<1>, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, q.img, q.w0, q.m0, q.s0, q.b0, q.dwpack, q.wt, q.mean,
+        const FrontGeom g = {q.srcH, q.srcW, q.nh, q.nw, (float)q.srcH / (float)q.nh, (float)q.srcW / (float)q.nw, adj};
+        hipLaunchKernelGGL(front_kernel<1>, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, img, q.w0, q.m0, q.s0, q.b0, q.dwpack, q.wt, q.mean,
                            q.sf, q.beta, q.out, d, g);
     } else {
-        const FrontGeom g = {q.H, q.W, q.H, q.W, 1.0f, 1.0f};
+        const FrontGeom g = {q.H, q.W, q.H, q.W, 1.0f, 1.0f, 0u};
         hipLaunchKernelGGL(front_kernel<0>, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, q.img, q.w0, q.m0, q.s0, q.b0, q.dwpack, q.wt, q.mean,
                            q.sf, q.beta, q.out, d, g);
     }

@@ -194,7 +194,7 @@ struct FrontArgs {
 };
 bool front_supports(int B, int H, int W, int C0, int K, int Cout);
 bool front_gen_supports(int B, int srcH, int srcW, int nh, int nw);
-bool front_mixed_supports(const MixedGeom &mg, int first, int B, int H, int W, unsigned *bytes4 = nullptr);
+bool front_mixed_supports(const MixedGeom &mg, int first, int B, int H, int W, unsigned *end_bytes = nullptr);
 int front_tile_y();
 int front_tile_x();
 hipError_t launch_front(const FrontArgs &q, hipStream_t s);

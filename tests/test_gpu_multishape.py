@@ -151,9 +151,18 @@ def test_first_layers_of_resized_frames_random_sizes(cuda, ssd, oracle_graph, ba
     for n in range(48):
         h, w = int(rng.integers(1, 301)), int(rng.integers(1, 301))
         img = rng.integers(0, 256, (1, h, w, 3), dtype=np.uint8)
-        a = [t.cpu().numpy() for t in new.forward(cuda.from_numpy(img).cuda())]
-        for other in (mid, old):
-            b = [t.cpu().numpy() for t in other.forward(cuda.from_numpy(img).cuda())]
+        # the fused and the lane-per-pixel forms read the frame through dword loads: give them a base pointer at every offset
+        # inside a dword (a caller's slice of a byte buffer; the library aligns its base itself)
+        dev = [cuda.from_numpy(img).cuda()]
+        for o in (n % 4, (n + 2) % 4):
+            flat = cuda.empty((img.size + 8,), dtype=cuda.uint8, device="cuda")
+            view = flat[o:o + img.size].view(1, h, w, 3)
+            view.copy_(dev[0])
+            assert view.data_ptr() % 4 == o
+            dev.append(view)
+        a = [t.cpu().numpy() for t in new.forward(dev[1])]
+        for other, src in ((mid, dev[2]), (old, dev[0])):
+            b = [t.cpu().numpy() for t in other.forward(src)]
             for k in range(4):
                 assert np.array_equal(a[k], b[k]), (backbone, h, w, k)
             assert np.array_equal(new.get_tensor("c3"), other.get_tensor("c3")), (backbone, h, w)
