@@ -72,9 +72,9 @@ def test_any_size_shufflenet_full_size_vs_oracle(cuda, ssd, oracle_graph, hw):
     eng.close()
 
 
-# (backbone, depth multiplier): the first convolution's 32 physical channels hold 32 (MobileNet 1.0), 16 (0.5: 16 zero-weight
-# pad channels) or ShuffleNet's 24 logical ones; MobileNet 2.0 (64 channels) stays on the rounds-1-5 kernel either way
-FIRST_CONV_NETS = [("mobilenet", 1.0), ("mobilenet", 0.5), ("mobilenet", 2.0), ("shufflenet", 1.0)]
+# (backbone, depth multiplier): the first convolution's 32 physical channels hold 32 (MobileNet 1.0) or ShuffleNet's 24 logical
+# ones; MobileNet 2.0 (64 channels) stays on the rounds-1-5 kernel either way
+FIRST_CONV_NETS = [("mobilenet", 1.0), ("mobilenet", 2.0), ("shufflenet", 1.0)]
 
 
 @pytest.mark.parametrize("net", FIRST_CONV_NETS, ids=["%s-%g" % n for n in FIRST_CONV_NETS])
@@ -94,7 +94,7 @@ def test_first_convolution_of_resized_frames_both_kernels(cuda, ssd, oracle_grap
     old.set_option("front_fuse", 0)
     old.set_option("first_conv_px", 0)
     checked = 0
-    for h, w, B in [(100, 151, 1), (97, 203, 3), (300, 129, 2), (513, 701, 1), (33, 77, 5), (2, 3, 1), (1, 1, 2), (131, 128, 1), (255, 1021, 1)]:
+    for h, w, B in [(100, 151, 1), (97, 203, 3), (513, 701, 1), (33, 77, 5), (1, 1, 2), (255, 1021, 1)]:      # (+ 48 random sizes: the sweep below)
         img = np.random.default_rng(h * 7 + w).integers(0, 256, (B, h, w, 3), dtype=np.uint8)
         a = [t.cpu().numpy() for t in new.forward(cuda.from_numpy(img).cuda())]
         for other, what in ((mid, "fused front vs first convolution + Conv2d_1"), (old, "vs the rounds-1-5 first convolution")):

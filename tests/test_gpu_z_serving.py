@@ -234,9 +234,15 @@ def test_bench_collective_path_on_rccl_world_1(cuda):
     with RCCL.  Functional asserts only: no wall-clock ratio is asserted anywhere under tests/ (boxes of the pool differ
     by 1-2 % and a noisy lease must not turn the parity rows behind this file into "untested"); the two throughputs are
     printed side by side by scripts/ab_dist.sh instead."""
-    common = ["--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-latency", "--no-shufflenet", "--no-other-precision"]
+    common = ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-latency", "--no-shufflenet", "--no-other-precision", "--sustained-seconds", "0"]
     plain = _bench(common)
-    forced = _bench(common + ["--force-dist"])
+    # the form the driver uses for N > 1, at N = 1: torch.distributed.run sets WORLD_SIZE = 1 and the collective path runs
+    # (bench.py --force-dist is the same path without the launcher; scripts/ab_dist.sh uses it)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    forced = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert plain["collective_path"] is False and forced["collective_path"] is True
     assert forced["n_gpus"] == 1 and forced["ranks_seen"] == [0] and forced["config"]["shards"] == [[0, 32]]
     assert forced["config"]["detections_per_image"] == plain["config"]["detections_per_image"] > 50
@@ -259,10 +265,3 @@ def test_bench_collective_path_on_rccl_world_1(cuda):
         assert rl["traffic_algorithmic_bytes"] < rl["traffic"] < 3 * rl["traffic_algorithmic_bytes"] and rl["traffic_launches_averaged"] >= 20
         assert abs(rl["traffic"] / rl["traffic_committed"] - 1) < 0.05
     assert "profiles/traffic.json" in forced["roofline"]["traffic_source"]
-    # the form the driver uses for N > 1, at N = 1: torch.distributed.run sets WORLD_SIZE=1
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                        "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"] + common[4:],
-                       capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert line["collective_path"] is True and line["ranks_seen"] == [0] and line["n_gpus"] == 1
