@@ -303,7 +303,9 @@ def _same_within_tolerance(a, b, what):
     ("mobilenet", 40, 256, 384, {}),                       # 40 images: the 256x256-tile kernel carries towers, p3 and logits
     ("mobilenet", 40, 256, 384, {"igemm16": 0}),     # the same on the 128x128 kernel's S16 path
     ("mobilenet", 5, 256, 128, {"nsub": 3}),         # consecutive sub-batch plans
-    ("mobilenet", 2, 300, 500, {}),                        # resize_keeping_aspect_ratio path (min_dimension 256)
+    ("mobilenet", 2, 300, 500, {}),                        # resize_keeping_aspect_ratio path (min_dimension 256): reduced in width, two launches
+    ("mobilenet", 5, 200, 300, {}),                        # ... enlarged: the fused first-layers launch with the gather (front.hip), two chains
+    ("shufflenet", 2, 200, 300, {}),
     ("mobilenet", 1, 256, 256, {"streams": 1}),      # every launch on the caller's stream
     ("mobilenet", 8, 256, 256, {"backbone_split": 4}),   # four backbone chains on four streams
     ("shufflenet", 6, 256, 256, {}),
